@@ -1,0 +1,91 @@
+/*
+ * cpi_oracle.h -- CPU restatement of the rpng/cpi continuous-preintegration hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load or call it, and only
+ * as the checker / the CPU baseline.  The shipped path is the HIP library (libcpi_amd.so).
+ *
+ * Parity status
+ *   - cpi_oracle_window (CpiV1 / CpiV2 feed_IMU): PINNED against the reference's own headers,
+ *     compiled unchanged from /root/reference into oracle/_ref/libcpi_ref.so (see Makefile,
+ *     ref_shim.cpp) and against the committed golden vectors in tests/golden/.
+ *   - cpi_oracle_factor_v1/v2 (ImuFactorCPIv1/v2::evaluateError), cpi_oracle_predict,
+ *     cpi_oracle_retract: PARITY UNPINNED.  The reference translation units need GTSAM + Boost,
+ *     which are not in this image, and stand-in headers are not allowed; the reference has no
+ *     tests or golden vectors for them.  They are a line-by-line restatement, cross-checked
+ *     by finite differences against JPLNavState::retract semantics (tests/test_factor_oracle.py).
+ *
+ * Storage convention at this API: every 3x3 / 15x15 matrix is COLUMN-MAJOR (Eigen default),
+ * quaternions are JPL [x y z w], state/tangent order is [theta b_g v b_a p].
+ */
+#ifndef CPI_ORACLE_H
+#define CPI_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    double sigma_w, sigma_wb, sigma_a, sigma_ab; /* CpiBase.h:52 */
+    double grav[3];                              /* CpiBase.h:118 */
+    int model;                                   /* 1 = CpiV1, 2 = CpiV2 */
+    int imu_avg;                                 /* CpiBase.h:95 */
+    int state_transition_jacobians;              /* CpiV2.h:58 (V2 only) */
+} cpi_oracle_params;
+
+typedef struct {
+    double DT, alpha[3], beta[3], q[4];          /* CpiBase.h:99-102 */
+    double R[9];                                 /* CpiBase.h:103 */
+    double J_q[9], J_a[9], J_b[9], H_a[9], H_b[9]; /* CpiBase.h:106-110 */
+    double O_a[9], O_b[9];                       /* CpiV2.h:62-63 */
+    double P[225];                               /* CpiBase.h:124 */
+} cpi_oracle_out;
+
+/* One window.  knots = (n+1) records {t, w[3], a[3]}; interval i = feed_IMU(t_i, t_{i+1},
+ * w_i, a_i, w_{i+1}, a_{i+1}) and is skipped when t_{i+1}-t_i < 0 (GraphSolver_IMU.cpp:50-53).
+ * lin = {b_w_lin[3], b_a_lin[3]}; q_k_lin may be NULL for model 1. */
+void cpi_oracle_window(const cpi_oracle_params *prm, int n, const double *knots,
+                       const double *lin, const double *q_k_lin, cpi_oracle_out *out);
+
+/* Per-sample trace of one window (test localisation): after every interval i writes
+ * trace[i] = full cpi_oracle_out snapshot. */
+void cpi_oracle_window_trace(const cpi_oracle_params *prm, int n, const double *knots,
+                             const double *lin, const double *q_k_lin, cpi_oracle_out *trace);
+
+/* W windows, fixed n, dense layout knots[W][n+1][7], lin[W][6], q_k_lin[W][4] (or NULL). */
+void cpi_oracle_batch(const cpi_oracle_params *prm, long W, int n, const double *knots,
+                      const double *lin, const double *q_k_lin, cpi_oracle_out *out);
+
+/* Same, spread over nthreads pthreads (CPU baseline on all host cores). */
+void cpi_oracle_batch_mt(const cpi_oracle_params *prm, long W, int n, const double *knots,
+                         const double *lin, const double *q_k_lin, cpi_oracle_out *out,
+                         int nthreads);
+
+/* Factor measurement record (what the ImuFactorCPIv1/v2 constructors copy,
+ * ImuFactorCPIv1.h:78-100, ImuFactorCPIv2.h:82-102). */
+typedef struct {
+    double alpha[3], beta[3], q_KtoK1[4];
+    double ba_lin[3], bg_lin[3];
+    double J_q[9], J_beta[9], J_alpha[9], H_beta[9], H_alpha[9];
+    double deltatime, grav[3];
+    double q_K_lin[4], O_beta[9], O_alpha[9]; /* v2 only */
+} cpi_oracle_factor;
+
+/* state = JPLNavState 16 doubles [q(4) bg(3) v(3) ba(3) p(3)] (JPLNavState.h:62-66).
+ * err[15]; H1,H2 15x15 column-major, may be NULL. */
+void cpi_oracle_factor_v1(const cpi_oracle_factor *f, const double *xi, const double *xj,
+                          double *err, double *H1, double *H2);
+void cpi_oracle_factor_v2(const cpi_oracle_factor *f, const double *xi, const double *xj,
+                          double *err, double *H1, double *H2);
+
+/* GraphSolver_IMU.cpp:263-281 (model 1) / 289-307 (model 2). */
+void cpi_oracle_predict(int model, const cpi_oracle_factor *f, const double *xi, double *xj);
+
+/* JPLNavState::retract (JPLNavState.cpp:37-71) and localCoordinates (:80-88). */
+void cpi_oracle_retract(const double *x, const double *xi15, double *xout);
+void cpi_oracle_local(const double *x, const double *other, double *xi15);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

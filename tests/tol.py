@@ -1,0 +1,40 @@
+"""Parity gates (BASELINE.json north_star; SURVEY.md section 8(d) 'Parity gates')."""
+import numpy as np
+
+TOL_MEAN = 1e-9      # alpha, beta, q, R, DT : max-abs
+TOL_COV = 1e-6       # |dP_ij| <= TOL_COV * sqrt(P_ii P_jj)
+TOL_JAC = 1e-8       # bias / orientation Jacobians: max-abs (our choice; north_star is silent)
+TOL_FACTOR = 1e-9    # evaluateError residual and H1/H2 : max-abs
+
+
+def cov_rel_err(P, Pref):
+    """max_ij |P-Pref|_ij / sqrt(Pref_ii Pref_jj) over a batch of column-major 15x15."""
+    P = np.asarray(P).reshape(-1, 15, 15)
+    Pref = np.asarray(Pref).reshape(-1, 15, 15)
+    d = np.sqrt(np.abs(np.diagonal(Pref, axis1=1, axis2=2)))
+    den = d[:, :, None] * d[:, None, :]
+    den = np.where(den > 0, den, np.inf)
+    rel = np.abs(P - Pref) / den
+    # entries whose scale is exactly zero must be exactly (abs 1e-30) zero
+    zero_scale = ~np.isfinite(den)
+    assert np.all(np.abs((P - Pref)[zero_scale]) < 1e-30)
+    return float(rel.max())
+
+
+def check_pre(out, ref, what=("mean", "jac", "cov"), v2=False, label=""):
+    msgs = []
+    if "mean" in what:
+        for k in ("DT", "alpha", "beta", "q"):
+            e = float(np.abs(np.asarray(out[k]) - np.asarray(ref[k])).max())
+            if not e <= TOL_MEAN:
+                msgs.append("%s %s err %.3e" % (label, k, e))
+    if "jac" in what:
+        for k in ("J_q", "J_a", "J_b", "H_a", "H_b") + (("O_a", "O_b") if v2 else ()):
+            e = float(np.abs(np.asarray(out[k]) - np.asarray(ref[k])).max())
+            if not e <= TOL_JAC:
+                msgs.append("%s %s err %.3e" % (label, k, e))
+    if "cov" in what:
+        e = cov_rel_err(out["P"], ref["P"])
+        if not e <= TOL_COV:
+            msgs.append("%s P rel err %.3e" % (label, e))
+    assert not msgs, "; ".join(msgs)
