@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- preintegration windows/sec on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-extra] [--no-cpu]
+
+A "step" is one pass of the hot path (one cpi_preintegrate_batch call = one kernel launch) over one
+batch of synthetic windows already resident in HBM.  The default workload is BASELINE.json
+configs[1]: 10 000 windows x 50 samples, CPI model 1, mean-only.  Successive steps walk a pool of
+distinct batches larger than the 256 MiB Infinity Cache, so the inputs really stream from HBM.
+Prints ONE JSON line (rank 0).  For N>1 launch with torch.distributed.run (one rank per GPU, RCCL):
+every rank processes its own pool (weak scaling) with no data-path collective; the output slabs of
+the last step are all-gathered once at the end, inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernels are VALU-bound
+# Algorithmic HBM bytes per unit: read + write, f64, compulsory traffic only
+BYTES = {"v1_mean": 2856 + 88, "v1_full": 2856 + 2320, "v2_full": 2888 + 2392,
+         "factor_v1": 776 + 3720, "factor_v2": 952 + 3720}
+MALL_BYTES = 256 << 20
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="v1_mean", choices=sorted(BYTES))
+    ap.add_argument("--windows", type=int, default=0, help="windows (factors) per step; 0 = BASELINE config size")
+    ap.add_argument("--samples", type=int, default=50)
+    ap.add_argument("--lanes", type=int, default=0, help="mean kernel lanes per window (0 = auto)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the additional BASELINE configs")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    return ap.parse_args()
+
+
+def default_size(workload):
+    return {"v1_mean": 10000, "v1_full": 100000, "v2_full": 100000, "factor_v1": 1000000, "factor_v2": 1000000}[workload]
+
+
+class Workload:
+    """A pool of resident batches + preallocated outputs + a step() closure."""
+
+    def __init__(self, eng, name, W, N, seed, lanes=0, pool_bytes=MALL_BYTES * 5 // 4):
+        from cpi_amd import synth
+        self.name, self.W, self.N = name, W, N
+        dev = eng.device
+        self.eng = eng
+        if name.startswith("factor"):
+            model = 1 if name.endswith("v1") else 2
+            self.model = model
+            kn, lin, q = synth.make_windows(W, N, seed=seed, device=dev)
+            self.meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac"))
+            torch.cuda.synchronize()
+            del kn
+            xi, xj = synth.make_states(self.meas["alpha"], self.meas["beta"], self.meas["q"], self.meas["DT"], lin,
+                                       model, device=dev)
+            self.states = torch.cat([xi, xj[-1:]], dim=0).contiguous()   # chained states: idx_i=f, idx_j=f+1
+            self.lin, self.q = lin, (q if model == 2 else None)
+            self.out = {"err": torch.empty((W, 15), dtype=torch.float64, device=dev),
+                        "H1": torch.empty((W, 225), dtype=torch.float64, device=dev),
+                        "H2": torch.empty((W, 225), dtype=torch.float64, device=dev)}
+            self.nbatch = 1   # 4.5 GB per sweep: far beyond the Infinity Cache by itself
+            return
+        model = 2 if name.startswith("v2") else 1
+        self.model = model
+        want = ("mean",) if name.endswith("mean") else ("mean", "jac", "cov")
+        self.want = want
+        self.prm = eng.make_params(model, lanes_per_window=lanes)
+        batch_bytes = W * (N + 1) * 56
+        self.nbatch = max(1, min(64, -(-pool_bytes // batch_bytes)))
+        self.batches = [synth.make_windows(W, N, seed=seed + 101 * b, device=dev) for b in range(self.nbatch)]
+        self.outs = [eng.alloc_outputs(W, want, model) for _ in range(min(self.nbatch, 4))]
+        self.i = 0
+
+    def step(self):
+        if self.name.startswith("factor"):
+            self.eng.factor_eval(self.model, self.meas, self.lin, self.q, self.states, out=self.out)
+            return self.out
+        kn, lin, q = self.batches[self.i % self.nbatch]
+        out = self.outs[self.i % len(self.outs)]
+        self.i += 1
+        self.eng.preintegrate(kn, lin, q, self.prm, want=self.want, out=out)
+        return out
+
+
+def time_steps(wl, steps, warmup, dist_on=False):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    out = None
+    for _ in range(steps):
+        out = wl.step()
+    e1.record()                                  # HIP events on the launch stream: kernel time only
+    gathered = None
+    if dist_on:                                  # the one exchange step: final gather of the output slabs
+        from cpi_amd.dist import gather_outputs
+        world = dist.get_world_size()
+        gathered = gather_outputs({k: v for k, v in out.items()}, wl.W * world)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1)
+    del gathered
+    return wall, kern_ms
+
+
+def cpu_baseline(wl, min_seconds=8.0):
+    """The reference's own CpiV1/CpiV2 (oracle/_ref, kind 'reference') or the C restatement (kind
+    'port') timed on this box's host cores on a bounded sample of the SAME windows."""
+    from oracle import oracle_py as op
+    ref = op.reference()
+    lib, kind = (ref, "reference") if ref is not None else (op.oracle(), "port")
+    cores = os.cpu_count() or 1
+    kn, lin, q = [t.cpu().numpy() for t in wl.batches[0]]
+    Wc = min(wl.W, 10000)
+    kn, lin, q = kn[:Wc], lin[:Wc], q[:Wc]
+    prm = op.make_params(wl.model, 0, 1)
+    lib.run(prm, kn[:256], lin[:256], q[:256], nthreads=cores)     # warm
+    t0, done = time.perf_counter(), 0
+    while True:
+        lib.run(prm, kn, lin, q, nthreads=cores)
+        done += Wc
+        el = time.perf_counter() - t0
+        if el >= min_seconds:
+            break
+    # single-thread figure on a smaller slice
+    ws = min(Wc, 1500 if wl.model == 1 else 600)
+    t1 = time.perf_counter(); lib.run(prm, kn[:ws], lin[:ws], q[:ws], nthreads=1); t1 = time.perf_counter() - t1
+    return {"value": done / el, "unit": "windows/s", "cores": cores, "kind": kind,
+            "single_core_value": ws / t1,
+            "sample": "%d passes over %d of the workload's %d-sample windows, %d threads; the reference feed_IMU "
+                      "always integrates means + bias Jacobians + covariance (it has no mean-only mode)"
+                      % (done // Wc, Wc, wl.N, cores)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import cpi_amd
+    eng = cpi_amd.Engine(device=local_rank)
+    W = a.windows or default_size(a.workload)
+    wl = Workload(eng, a.workload, W, a.samples, seed=20190101 + 7919 * rank, lanes=a.lanes)
+    wall, kern_ms = time_steps(wl, a.steps, a.warmup, dist_on)
+    if dist_on:
+        import torch.distributed as dist
+        t = torch.tensor([wall, kern_ms], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kern_ms = t[0].item(), t[1].item()
+    units = W * world * a.steps
+    value = units / wall
+    launch_s = kern_ms * 1e-3 / a.steps
+    achieved = BYTES[a.workload] * W / launch_s / 1e9
+    is_factor = a.workload.startswith("factor")
+    res = {
+        "metric": "evaluateError factors/sec" if is_factor else "preintegration windows/sec (50-sample windows)",
+        "value": value, "unit": "factors/s" if is_factor else "windows/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %d %s x %d samples per GPU per step%s" % (
+            a.workload, W, "factors" if is_factor else "windows", a.samples,
+            ", CPI model 1, mean-only (BASELINE.json configs[1])" if a.workload == "v1_mean" and W == 10000 else ""),
+            "pool_batches": wl.nbatch, "parallelism": "windows sharded over %d GPU(s), final all_gather" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": {"v1_mean": "cpi_mean_kernel", "v1_full": "cpi_cov_kernel<1>", "v2_full": "cpi_cov_kernel<2>",
+                                "factor_v1": "cpi_factor_kernel<1>", "factor_v2": "cpi_factor_kernel<2>"}[a.workload],
+                     "launch_us": launch_s * 1e6, "algorithmic_bytes_per_unit": BYTES[a.workload]},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu and not is_factor:
+        res["cpu_baseline"] = cpu_baseline(wl)
+    if rank == 0 and world == 1 and not a.no_extra:
+        extra = []
+        del wl
+        torch.cuda.empty_cache()
+        for name, Wx, steps in (("v1_mean", 1000000, 10), ("v1_full", 100000, 10), ("v2_full", 100000, 10),
+                                ("factor_v1", 1000000, 10), ("factor_v2", 1000000, 10)):
+            try:
+                w2 = Workload(eng, name, Wx, a.samples, seed=4242, pool_bytes=MALL_BYTES * 5 // 4)
+                wall2, k2 = time_steps(w2, steps, 2)
+                ls = k2 * 1e-3 / steps
+                ach = BYTES[name] * Wx / ls / 1e9
+                extra.append({"workload": name, "units_per_step": Wx, "value": Wx * steps / wall2,
+                              "unit": "factors/s" if name.startswith("factor") else "windows/s",
+                              "launch_ms": ls * 1e3, "hbm_GBs": ach, "hbm_frac": ach / HBM_PEAK_GBS})
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as ex:  # an extra config must never take the headline down
+                extra.append({"workload": name, "error": repr(ex)})
+        res["extra"] = extra
+    if rank == 0:
+        print(json.dumps(res))
+    if dist_on:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,14 @@
+"""cpi_amd -- MI355X-native batched IMU continuous preintegration (CPI) engine.
+
+The product is the HIP library cpi_amd/libcpi_amd.so behind the C-ABI of include/cpi_amd.h;
+this package is the thin host-side mirror of the reference's CpiV1/CpiV2 and ImuFactorCPIv1/v2
+interfaces over that ABI.  There is no CPU fallback.
+"""
+from ._lib import CpiError, LIB_PATH  # noqa: F401
+
+
+def __getattr__(name):  # lazy: importing the package must not need torch / a GPU
+    if name in ("Engine", "CpiV1", "CpiV2", "ImuFactorCPIv1", "ImuFactorCPIv2", "default_engine"):
+        from . import engine
+        return getattr(engine, name)
+    raise AttributeError(name)

@@ -1,0 +1,64 @@
+"""ctypes binding of include/cpi_amd.h -> cpi_amd/libcpi_amd.so (the HIP library).
+
+There is NO CPU fallback: if the library is missing and cannot be built with hipcc this module
+raises, and creating a context on a machine without a GPU raises (CPI_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpi_amd.so")
+
+CPI_OK, CPI_ERR_INVALID, CPI_ERR_HIP, CPI_ERR_NO_DEVICE = 0, 1, 2, 3
+OUT_FIELDS = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9),
+              ("H_a", 9), ("H_b", 9), ("O_a", 9), ("O_b", 9), ("P", 225)]
+
+
+class CpiParams(C.Structure):
+    _fields_ = [("sigma_w", C.c_double), ("sigma_wb", C.c_double), ("sigma_a", C.c_double),
+                ("sigma_ab", C.c_double), ("grav", C.c_double * 3), ("model", C.c_int32),
+                ("imu_avg", C.c_int32), ("state_transition_jacobians", C.c_int32),
+                ("lanes_per_window", C.c_int32)]
+
+
+class CpiOutputs(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _ in OUT_FIELDS]
+
+
+class CpiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cpi_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build  # hipcc cross-compiles without a GPU; raises if hipcc fails
+        _build.build()
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("cpi_amd: %s is missing and could not be built (no CPU fallback exists)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+    lib.cpi_abi_version.restype = C.c_int
+    lib.cpi_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.cpi_ctx_destroy.argtypes = [vp]
+    lib.cpi_ctx_destroy.restype = None
+    lib.cpi_last_error.argtypes = [vp]
+    lib.cpi_last_error.restype = C.c_char_p
+    lib.cpi_ctx_synchronize.argtypes = [vp]
+    lib.cpi_preintegrate_batch.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, vp, dp, dp, C.POINTER(CpiOutputs)]
+    lib.cpi_factor_eval_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, vp, vp, dp, dp, dp]
+    lib.cpi_predict_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, vp, dp]
+    lib.cpi_preintegrate_batch_host.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, vp, i64, dp, dp, C.POINTER(CpiOutputs)]
+    lib.cpi_factor_eval_batch_host.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp]
+    for f in (lib.cpi_ctx_create, lib.cpi_ctx_synchronize, lib.cpi_preintegrate_batch, lib.cpi_factor_eval_batch,
+              lib.cpi_predict_batch, lib.cpi_preintegrate_batch_host, lib.cpi_factor_eval_batch_host):
+        f.restype = C.c_int
+    _lib = lib
+    return lib

@@ -1,0 +1,718 @@
+// cpi_kernels.hip -- CDNA4 (gfx950) kernels + C-ABI of the batched continuous-preintegration engine.
+//
+// Kernels (one 64-lane wavefront per workgroup; all arithmetic f64 VALU, no MFMA -- the
+// contractions are 3x3 / sparse 15x15):
+//   cpi_mean_kernel<MODEL,JAC,AVG,L>   means (+ analytic bias Jacobians).  L lanes per window, each lane
+//        integrates a contiguous run of intervals read through an LDS-staged, coalesced tile of IMU
+//        knots, then an order-preserving shuffle tree composes the L segments.
+//        Replaces CpiV1.h:67-259 / CpiV2.h:88-305.
+//   cpi_cov_kernel<MODEL,AVG>          covariance (model 2: + compounded state transition -> Jacobians)
+//        and means.  A 16- (model 1) or 32-lane (model 2) group owns one window; lane j owns column j
+//        of P (or of Discrete_J_b).  Phase A computes the per-interval closed forms lane-parallel over
+//        samples into LDS; phase C walks the samples sequentially: F x is lane-local, P F^T arrives
+//        through a 9-row LDS transpose exchange; classic RK4.  Replaces CpiV1.h:266-353 / CpiV2.h:314-464.
+//   cpi_factor_kernel<MODEL>           evaluateError residual + dense 15x15 H1/H2; 16 lanes per
+//        factor, lane c emits column c.  Replaces ImuFactorCPIv1.cpp:37-208 / ImuFactorCPIv2.cpp:38-212.
+//   cpi_predict_kernel<MODEL>          GraphSolver_IMU.cpp:263-307.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/cpi_amd.h"
+#include "cpi_math.hpp"
+
+using namespace cpi;
+
+// ============================================================================================
+// device helpers
+// ============================================================================================
+namespace {
+
+__device__ __forceinline__ V3 ldv3(const double *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ Q4 ldq4(const double *p) { Q4 q; q.x = p[0]; q.y = p[1]; q.z = p[2]; q.w = p[3]; return q; }
+__device__ __forceinline__ M3 ldm3_cm(const double *p) {  // column-major 3x3
+    M3 A;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) A.m[i][j] = p[j * 3 + i];
+    return A;
+}
+__device__ __forceinline__ void stm3_cm(double *p, const M3 &A) {
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) p[j * 3 + i] = A.m[i][j];
+}
+__device__ __forceinline__ void stv3(double *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+__device__ __forceinline__ V3 shfl_down(V3 v, int d) {
+    return mk(__shfl_down(v.x, d), __shfl_down(v.y, d), __shfl_down(v.z, d));
+}
+__device__ __forceinline__ M3 shfl_down(const M3 &A, int d) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = __shfl_down(A.m[i][j], d);
+    return r;
+}
+template <bool JAC>
+__device__ __forceinline__ MeanState<JAC> shfl_down(const MeanState<JAC> &s, int d) {
+    MeanState<JAC> r;
+    r.R = shfl_down(s.R, d);
+    r.alpha = shfl_down(s.alpha, d);
+    r.beta = shfl_down(s.beta, d);
+    r.DT = __shfl_down(s.DT, d);
+    if (JAC) {
+        r.Jq = shfl_down(s.Jq, d); r.Ja = shfl_down(s.Ja, d); r.Jb = shfl_down(s.Jb, d);
+        r.Ha = shfl_down(s.Ha, d); r.Hb = shfl_down(s.Hb, d);
+        r.Oa = s.Oa; r.Ob = s.Ob;
+    }
+    return r;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+struct PreArgs {
+    long long W;
+    int N;
+    const double *knots;
+    const long long *first;
+    const int *count;
+    const double *lin;
+    const double *qk;
+    double grav[3];
+    double q4[4];      // sigma^2 of the four diagonal blocks of Q_c (CpiBase.h:54-57)
+    int write_means;   // kernel writes DT/alpha/beta/q
+    int write_jac;     // kernel writes the Jacobians it owns
+    cpi_outputs out;
+};
+
+// ============================================================================================
+// mean (+ analytic Jacobian) kernel
+// ============================================================================================
+template <int MODEL, bool JAC, bool AVG, int L>
+__global__ __launch_bounds__(64) void cpi_mean_kernel(PreArgs A) {
+    constexpr int WPB = 64 / L;       // windows per wavefront
+    constexpr int C = 4;              // knots staged per lane per chunk
+    constexpr int SEGD = 7 * C;       // doubles per lane per chunk
+    constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
+    __shared__ double tile[64 * PITCH];
+    __shared__ long long segbase[64];
+    __shared__ int seglen[64];
+
+    const int lane = threadIdx.x;
+    const int l = lane % L;
+    long long w = (long long)blockIdx.x * WPB + lane / L;
+    const bool valid = w < A.W;
+    if (!valid) w = A.W - 1;
+    const int n = A.count ? A.count[w] : A.N;
+    const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
+    const int per = (n + L - 1) / L;
+    const int s0 = min(n, l * per), s1 = min(n, s0 + per);
+    const int len = s1 - s0;
+    const int maxlen = wave_max(len);
+
+    segbase[lane] = (k0 + s0) * 7;
+    seglen[lane] = len;
+
+    const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
+    V3 gk = mk(0, 0, 0);
+    if (MODEL == 2) gk = mul(quat_2_Rot(ldq4(A.qk + w * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
+
+    double pk[7];
+    {
+        const double *kb = A.knots + (k0 + s0) * 7;
+#pragma unroll
+        for (int i = 0; i < 7; i++) pk[i] = (len > 0) ? kb[i] : 0.0;
+    }
+    MeanState<JAC> st;
+    mean_init(st);
+    __syncthreads();
+
+    const int nchunks = (maxlen + C - 1) / C;
+    for (int it = 0; it < nchunks; ++it) {
+        // cooperative, coalesced copy of 64 segments x C knots: element idx of the tile belongs to
+        // segment idx / SEGD; consecutive lanes read consecutive doubles of (mostly) one segment.
+#pragma unroll 4
+        for (int e = 0; e < SEGD; ++e) {
+            const int idx = e * 64 + lane;
+            const int seg = idx / SEGD, off = idx - seg * SEGD;
+            const int kk = it * C + 1 + off / 7;  // knot index relative to the segment's first knot
+            double v = 0.0;
+            if (kk <= seglen[seg]) v = A.knots[segbase[seg] + (long long)(it * C + 1) * 7 + off];
+            tile[seg * PITCH + off] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) {
+            const int s = it * C + c;
+            if (s < len) {
+                const double *nk = &tile[lane * PITCH + c * 7];
+                double q[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) q[i] = nk[i];
+                mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                           mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk);
+#pragma unroll
+                for (int i = 0; i < 7; i++) pk[i] = q[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // order-preserving composition tree over the L lanes of a window (earlier = lower lane)
+#pragma unroll
+    for (int stp = 1; stp < L; stp <<= 1) {
+        const MeanState<JAC> B = shfl_down(st, stp);
+        mean_combine(st, B);
+    }
+
+    if (valid && l == 0) {
+        if (A.write_means) {
+            if (A.out.DT) A.out.DT[w] = st.DT;
+            if (A.out.alpha) stv3(A.out.alpha + w * 3, st.alpha);
+            if (A.out.beta) stv3(A.out.beta + w * 3, st.beta);
+            if (A.out.q) {
+                const Q4 q = rot_2_quat(st.R);
+                double *p = A.out.q + w * 4;
+                p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+            }
+        }
+        if (JAC && A.write_jac) {
+            if (A.out.J_q) stm3_cm(A.out.J_q + w * 9, st.Jq);
+            if (A.out.J_a) stm3_cm(A.out.J_a + w * 9, st.Ja);
+            if (A.out.J_b) stm3_cm(A.out.J_b + w * 9, st.Jb);
+            if (A.out.H_a) stm3_cm(A.out.H_a + w * 9, st.Ha);
+            if (A.out.H_b) stm3_cm(A.out.H_b + w * 9, st.Hb);
+            if (MODEL == 2) {
+                if (A.out.O_a) stm3_cm(A.out.O_a + w * 9, st.Oa);
+                if (A.out.O_b) stm3_cm(A.out.O_b + w * 9, st.Ob);
+            }
+        }
+    }
+}
+
+// ============================================================================================
+// covariance (+ state transition) kernel
+// ============================================================================================
+template <int MODEL, bool AVG>
+__global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
+    typedef CovDims<MODEL> D;
+    constexpr int GROUP = D::GROUP;   // lanes per window
+    constexpr int G = 64 / GROUP;     // windows per wavefront
+    constexpr int CH = GROUP;         // intervals per window processed by one phase-A pass
+    constexpr int RD = SAMPLE_REC_DOUBLES;
+    constexpr int EP = 18;            // exchange row pitch (doubles): 16-B aligned rows, distinct bank slots
+    __shared__ __attribute__((aligned(16))) double recs[64 * RD];
+    __shared__ __attribute__((aligned(16))) double exch[G * 9 * EP];
+
+    const int lane = threadIdx.x;
+    const int g = lane / GROUP, j = lane % GROUP;
+    long long w = (long long)blockIdx.x * G + g;
+    const bool valid = w < A.W;
+    if (!valid) w = A.W - 1;
+    const int n = A.count ? A.count[w] : A.N;
+    const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
+    const int nmax = wave_max(n);
+
+    const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
+    V3 gk = mk(0, 0, 0);
+    if (MODEL == 2) gk = mul(quat_2_Rot(ldq4(A.qk + w * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
+    const double q4[4] = { A.q4[0], A.q4[1], A.q4[2], A.q4[3] };
+
+    const int jj = min(j, (int)D::NCOL);  // idle lanes (j >= NCOL) run as a harmless zero transition column
+    CovLane<MODEL> Ln;
+    cov_init(Ln, jj);
+    const int er = cov_exch_row(jj);
+    double *ex_g = exch + g * 9 * EP;
+    const double *ex_row = ex_g + (er < 0 ? 0 : er) * EP;
+
+    for (int base = 0; base < nmax; base += CH) {
+        // ---- phase A: lane (g, j) evaluates the closed forms of interval base + j of its window
+        {
+            const int s = base + j;
+            double *rp = recs + (g * CH + j) * RD;
+            SampleRec r;
+            if (s < n) {
+                const double *ka = A.knots + (k0 + s) * 7;
+                double a[14];
+#pragma unroll
+                for (int i = 0; i < 14; i++) a[i] = ka[i];
+                r = make_sample_rec<MODEL, AVG>(a[0], a[7], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]),
+                                                mk(a[8], a[9], a[10]), mk(a[11], a[12], a[13]), bw, ba);
+            } else {  // padding: an exact no-op interval
+                r.dt = 0; r.w = mk(0, 0, 0); r.a0 = mk(0, 0, 0); r.a1 = mk(0, 0, 0);
+                r.f1 = r.f2 = r.f3 = r.f4 = 0; r.Rstep = eye(); r.Rhalf = eye();
+            }
+            rp[0] = r.dt;
+            stv3(rp + 1, r.w); stv3(rp + 4, r.a0); stv3(rp + 7, r.a1);
+            rp[10] = r.f1; rp[11] = r.f2; rp[12] = r.f3; rp[13] = r.f4;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { rp[14 + i * 3 + k] = r.Rstep.m[i][k]; rp[23 + i * 3 + k] = r.Rhalf.m[i][k]; }
+        }
+        __syncthreads();
+
+        // ---- phase C: sequential recursion over the staged intervals
+        const int cnt = min(CH, nmax - base);
+        for (int sl = 0; sl < cnt; ++sl) {
+            const double *rp = recs + (g * CH + sl) * RD;  // group-uniform address: LDS broadcast
+            SampleRec r;
+            r.dt = rp[0];
+            r.w = ldv3(rp + 1); r.a0 = ldv3(rp + 4); r.a1 = ldv3(rp + 7);
+            r.f1 = rp[10]; r.f2 = rp[11]; r.f3 = rp[12]; r.f4 = rp[13];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { r.Rstep.m[i][k] = rp[14 + i * 3 + k]; r.Rhalf.m[i][k] = rp[23 + i * 3 + k]; }
+            cov_begin<MODEL, AVG>(Ln, r, gk);
+#pragma unroll
+            for (int stg = 0; stg < 4; ++stg) {
+                double M[9];
+                cov_stage_M(Ln, stg, M);
+                if (j < D::NPCOL) {
+#pragma unroll
+                    for (int rr = 0; rr < 9; rr++) ex_g[rr * EP + j] = M[rr];
+                }
+                __syncthreads();
+                double Mt[D::NR];
+#pragma unroll
+                for (int i = 0; i < D::NR; i++) Mt[i] = ex_row[i];
+                cov_stage_finish(Ln, stg, M, Mt, jj, q4);
+                __syncthreads();
+            }
+            cov_end(Ln);
+            if (MODEL == 2) {  // column clone: columns 15:18 := columns 0:3 (CpiV2.h:436-441)
+                const int src = (j >= 15 && j < 18) ? lane - 15 : lane;
+#pragma unroll
+                for (int i = 0; i < D::NR; i++) {
+                    const double t = __shfl(Ln.P0[i], src);
+                    Ln.P0[i] = t;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!valid) return;
+    if (A.out.P && j < 15) {
+        double *p = A.out.P + w * 225 + j * 15;
+#pragma unroll
+        for (int i = 0; i < 15; i++) p[i] = Ln.P0[i];
+    }
+    if (A.write_means && j == 0) {
+        if (A.out.DT) A.out.DT[w] = Ln.DT;
+        if (A.out.alpha) stv3(A.out.alpha + w * 3, Ln.alpha);
+        if (A.out.beta) stv3(A.out.beta + w * 3, Ln.beta);
+        if (A.out.q) {
+            const Q4 q = rot_2_quat(Ln.R);
+            double *p = A.out.q + w * 4;
+            p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+        }
+    }
+    if (MODEL == 2 && A.write_jac && j >= D::NPCOL && j < D::NCOL) {
+        // Jacobian read-out of Discrete_J_b (CpiV2.h:450-458); d = which column, c = column within the block
+        const int d = (j - D::NPCOL) / 3, c = (j - D::NPCOL) % 3;
+        const V3 th = mk(Ln.P0[0], Ln.P0[1], Ln.P0[2]);
+        const V3 vv = mk(Ln.P0[6], Ln.P0[7], Ln.P0[8]);
+        const V3 pp = mk(Ln.P0[12], Ln.P0[13], Ln.P0[14]);
+        if (d == 0) {
+            if (A.out.J_q) stv3(A.out.J_q + w * 9 + c * 3, -th);
+            if (A.out.J_a) stv3(A.out.J_a + w * 9 + c * 3, pp);
+            if (A.out.J_b) stv3(A.out.J_b + w * 9 + c * 3, vv);
+        } else if (d == 1) {
+            if (A.out.H_a) stv3(A.out.H_a + w * 9 + c * 3, pp);
+            if (A.out.H_b) stv3(A.out.H_b + w * 9 + c * 3, vv);
+        } else {
+            if (A.out.O_a) stv3(A.out.O_a + w * 9 + c * 3, pp);
+            if (A.out.O_b) stv3(A.out.O_b + w * 9 + c * 3, vv);
+        }
+    }
+}
+
+// ============================================================================================
+// factor kernels
+// ============================================================================================
+struct FactorArgs {
+    long long F;
+    double grav[3];
+    cpi_outputs meas;
+    const double *lin;
+    const double *qk;
+    const double *states;
+    const int *idx_i;
+    const int *idx_j;
+    double *err;
+    double *H1;
+    double *H2;
+};
+
+__device__ __forceinline__ NavState ld_state(const double *p) {
+    NavState s;
+    s.q = ldq4(p); s.bg = ldv3(p + 4); s.v = ldv3(p + 7); s.ba = ldv3(p + 10); s.p = ldv3(p + 13);
+    return s;
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(64) void cpi_factor_kernel(FactorArgs A) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15;
+    long long f = (long long)blockIdx.x * 4 + (lane >> 4);
+    const bool valid = f < A.F;
+    if (!valid) f = A.F - 1;
+    FactorMeas m;
+    m.alpha = ldv3(A.meas.alpha + f * 3);
+    m.beta = ldv3(A.meas.beta + f * 3);
+    m.q_KtoK1 = ldq4(A.meas.q + f * 4);
+    m.bg_lin = ldv3(A.lin + f * 6);
+    m.ba_lin = ldv3(A.lin + f * 6 + 3);
+    m.J_q = ldm3_cm(A.meas.J_q + f * 9);
+    m.J_beta = ldm3_cm(A.meas.J_b + f * 9);
+    m.J_alpha = ldm3_cm(A.meas.J_a + f * 9);
+    m.H_beta = ldm3_cm(A.meas.H_b + f * 9);
+    m.H_alpha = ldm3_cm(A.meas.H_a + f * 9);
+    m.dt = A.meas.DT[f];
+    m.grav = mk(A.grav[0], A.grav[1], A.grav[2]);
+    if (MODEL == 2) {
+        m.q_K_lin = ldq4(A.qk + f * 4);
+        m.O_beta = ldm3_cm(A.meas.O_b + f * 9);
+        m.O_alpha = ldm3_cm(A.meas.O_a + f * 9);
+    } else {
+        m.q_K_lin.x = 0; m.q_K_lin.y = 0; m.q_K_lin.z = 0; m.q_K_lin.w = 1;
+        m.O_beta = zero3(); m.O_alpha = zero3();
+    }
+    const long long ii = A.idx_i ? A.idx_i[f] : f;
+    const long long ij = A.idx_j ? A.idx_j[f] : f + 1;
+    const NavState xi = ld_state(A.states + ii * 16), xj = ld_state(A.states + ij * 16);
+    FactorBlocks o;
+    factor_eval<MODEL>(m, xi, xj, o);
+    if (!valid || c >= 15) return;
+    A.err[f * 15 + c] = pick15(o.err, c);
+    if (A.H1) {
+        double h[15];
+        factor_H1_col(o, m, c, h);
+        double *p = A.H1 + f * 225 + c * 15;
+#pragma unroll
+        for (int i = 0; i < 15; i++) p[i] = h[i];
+    }
+    if (A.H2) {
+        double h[15];
+        factor_H2_col(o, c, h);
+        double *p = A.H2 + f * 225 + c * 15;
+#pragma unroll
+        for (int i = 0; i < 15; i++) p[i] = h[i];
+    }
+}
+
+struct PredictArgs {
+    long long F;
+    double grav[3];
+    cpi_outputs meas;
+    const double *states_i;
+    const int *idx_i;
+    double *states_j;
+};
+template <int MODEL>
+__global__ __launch_bounds__(256) void cpi_predict_kernel(PredictArgs A) {
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= A.F) return;
+    const long long ii = A.idx_i ? A.idx_i[f] : f;
+    const NavState xi = ld_state(A.states_i + ii * 16);
+    const NavState o = predict_state<MODEL>(xi, ldv3(A.meas.alpha + f * 3), ldv3(A.meas.beta + f * 3),
+                                            ldq4(A.meas.q + f * 4), A.meas.DT[f], mk(A.grav[0], A.grav[1], A.grav[2]));
+    double *d = A.states_j + f * 16;
+    d[0] = o.q.x; d[1] = o.q.y; d[2] = o.q.z; d[3] = o.q.w;
+    stv3(d + 4, o.bg); stv3(d + 7, o.v); stv3(d + 10, o.ba); stv3(d + 13, o.p);
+}
+
+}  // namespace
+
+// ============================================================================================
+// C-ABI
+// ============================================================================================
+struct cpi_ctx {
+    int device;
+    hipStream_t stream;
+    std::string err;
+};
+static thread_local std::string g_create_err;
+
+static int fail(cpi_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return code;
+}
+#define CPI_HIP(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, CPI_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+extern "C" int cpi_abi_version(void) { return CPI_ABI_VERSION; }
+
+extern "C" int cpi_ctx_create(int device, void *stream, cpi_ctx **out) {
+    if (!out) return fail(nullptr, CPI_ERR_INVALID, "cpi_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, CPI_ERR_NO_DEVICE, "cpi_ctx_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0) {
+        e = hipGetDevice(&device);
+        if (e != hipSuccess) return fail(nullptr, CPI_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    }
+    if (device >= ndev) return fail(nullptr, CPI_ERR_INVALID, "cpi_ctx_create: device index out of range");
+    cpi_ctx *c = new cpi_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    *out = c;
+    return CPI_OK;
+}
+extern "C" void cpi_ctx_destroy(cpi_ctx *ctx) { delete ctx; }
+extern "C" const char *cpi_last_error(const cpi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+extern "C" int cpi_ctx_synchronize(cpi_ctx *ctx) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    CPI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CPI_OK;
+}
+
+static int pick_lanes(const cpi_params *prm, int64_t W, int N) {
+    if (prm->model == CPI_MODEL_V2) return 1;  // model 2 means depend on the running rotation: sequential per window
+    int L = prm->lanes_per_window;
+    if (L <= 0) {  // enough wavefronts to fill 256 CUs x 4 SIMDs a few times over
+        L = 1;
+        while (L < 64 && W * L < (int64_t)262144 && 2 * L <= N) L *= 2;
+    }
+    return L;
+}
+
+template <int MODEL, bool JAC, bool AVG>
+static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
+#define CPI_LAUNCH_L(LL)                                                                         \
+    case LL: {                                                                                   \
+        const long long nb = (a.W * LL + 63) / 64;                                               \
+        hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL>), dim3((unsigned)nb), dim3(64), 0, st, a); \
+    } break;
+    if constexpr (MODEL == 2) { switch (L) { CPI_LAUNCH_L(1) default: break; } } else
+    switch (L) {
+        CPI_LAUNCH_L(1) CPI_LAUNCH_L(2) CPI_LAUNCH_L(4) CPI_LAUNCH_L(8) CPI_LAUNCH_L(16) CPI_LAUNCH_L(32) CPI_LAUNCH_L(64)
+        default: break;
+    }
+#undef CPI_LAUNCH_L
+}
+template <int MODEL>
+static void launch_mean(bool jac, bool avg, int L, const PreArgs &a, hipStream_t st) {
+    if (jac) { if (avg) launch_mean_L<MODEL, true, true>(L, a, st); else launch_mean_L<MODEL, true, false>(L, a, st); }
+    else     { if (avg) launch_mean_L<MODEL, false, true>(L, a, st); else launch_mean_L<MODEL, false, false>(L, a, st); }
+}
+template <int MODEL>
+static void launch_cov(bool avg, const PreArgs &a, hipStream_t st) {
+    constexpr int G = 64 / CovDims<MODEL>::GROUP;
+    const long long nb = (a.W + G - 1) / G;
+    if (avg) hipLaunchKernelGGL((cpi_cov_kernel<MODEL, true>), dim3((unsigned)nb), dim3(64), 0, st, a);
+    else     hipLaunchKernelGGL((cpi_cov_kernel<MODEL, false>), dim3((unsigned)nb), dim3(64), 0, st, a);
+}
+
+extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
+                                      const double *knots, const int64_t *first, const int32_t *count,
+                                      const double *lin, const double *q_k_lin, const cpi_outputs *out) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (!prm || !out) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: prm/out is NULL");
+    if (prm->model != CPI_MODEL_V1 && prm->model != CPI_MODEL_V2)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: model must be 1 or 2");
+    if (W < 0 || N < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: negative size");
+    if (W == 0) return CPI_OK;
+    if (!knots || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: knots/lin is NULL");
+    if (prm->model == CPI_MODEL_V2 && !q_k_lin)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: model 2 needs q_k_lin");
+    if (W > ((int64_t)1 << 31) * 4) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: W too large for one launch");
+    int L = prm->lanes_per_window;
+    if (L != 0 && (L < 1 || L > 64 || (L & (L - 1)))) return fail(ctx, CPI_ERR_INVALID, "lanes_per_window must be 0 or a power of two <= 64");
+
+    const bool want_mean = out->DT || out->alpha || out->beta || out->q;
+    const bool want_jac = out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b;
+    const bool want_cov = out->P != nullptr;
+    if (!want_mean && !want_jac && !want_cov) return CPI_OK;
+
+    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    PreArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = W; a.N = N; a.knots = knots; a.first = (const long long *)first; a.count = count;
+    a.lin = lin; a.qk = q_k_lin;
+    for (int i = 0; i < 3; i++) a.grav[i] = prm->grav[i];
+    a.q4[0] = prm->sigma_w * prm->sigma_w; a.q4[1] = prm->sigma_wb * prm->sigma_wb;
+    a.q4[2] = prm->sigma_a * prm->sigma_a; a.q4[3] = prm->sigma_ab * prm->sigma_ab;
+    a.out = *out;
+    const bool avg = prm->imu_avg != 0;
+    const bool v2 = prm->model == CPI_MODEL_V2;
+    const bool stj = v2 && prm->state_transition_jacobians != 0;
+
+    // Which kernel owns what:
+    //   covariance kernel : P, and (model 2 + state_transition_jacobians) the Jacobians read out of
+    //                       Discrete_J_b; it also carries the means, so it writes them when it runs.
+    //   mean kernel       : means when no covariance kernel runs; the ANALYTIC Jacobians (model 1 always,
+    //                       model 2 when state_transition_jacobians == 0).
+    const bool run_cov = want_cov || (stj && want_jac);
+    const bool mean_jac = want_jac && !stj;
+    const bool run_mean = mean_jac || (want_mean && !run_cov);
+    if (run_cov) {
+        PreArgs c = a;
+        c.write_means = want_mean ? 1 : 0;
+        c.write_jac = (stj && want_jac) ? 1 : 0;
+        if (!want_cov) c.out.P = nullptr;
+        if (v2) launch_cov<2>(avg, c, ctx->stream); else launch_cov<1>(avg, c, ctx->stream);
+    }
+    if (run_mean) {
+        PreArgs m = a;
+        m.write_means = (want_mean && !run_cov) ? 1 : 0;
+        m.write_jac = mean_jac ? 1 : 0;
+        const int LL = mean_jac && v2 ? 1 : pick_lanes(prm, W, N);
+        if (v2) launch_mean<2>(mean_jac, avg, LL, m, ctx->stream); else launch_mean<1>(mean_jac, avg, LL, m, ctx->stream);
+    }
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+
+extern "C" int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                     const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                     const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                     double *err, double *H1, double *H2) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: model must be 1 or 2");
+    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: negative size");
+    if (F == 0) return CPI_OK;
+    if (!grav || !meas || !lin || !states || !err) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: NULL argument");
+    if (!meas->DT || !meas->alpha || !meas->beta || !meas->q || !meas->J_q || !meas->J_a || !meas->J_b || !meas->H_a || !meas->H_b)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
+    if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
+        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: model 2 needs q_k_lin, O_a, O_b");
+    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    FactorArgs a;
+    memset(&a, 0, sizeof a);
+    a.F = F;
+    for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
+    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.idx_i = idx_i; a.idx_j = idx_j;
+    a.err = err; a.H1 = H1; a.H2 = H2;
+    const long long nb = (F + 3) / 4;
+    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_kernel<1>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((cpi_factor_kernel<2>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+
+extern "C" int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                 const cpi_outputs *meas, const double *states_i, const int32_t *idx_i,
+                                 double *states_j) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_predict_batch: model must be 1 or 2");
+    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_predict_batch: negative size");
+    if (F == 0) return CPI_OK;
+    if (!grav || !meas || !states_i || !states_j || !meas->DT || !meas->alpha || !meas->beta || !meas->q)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_predict_batch: NULL argument");
+    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    PredictArgs a;
+    memset(&a, 0, sizeof a);
+    a.F = F;
+    for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
+    a.meas = *meas; a.states_i = states_i; a.idx_i = idx_i; a.states_j = states_j;
+    const long long nb = (F + 255) / 256;
+    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_predict_kernel<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((cpi_predict_kernel<2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a);
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+
+// -------------------------------------------------------------------------------- host-pointer variants
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+#define CPI_UP(buf, host, bytes)                                                          \
+    do {                                                                                  \
+        if (host) {                                                                       \
+            CPI_HIP(ctx, hipMalloc(&buf.p, (bytes)));                                     \
+            CPI_HIP(ctx, hipMemcpyAsync(buf.p, host, (bytes), hipMemcpyHostToDevice, ctx->stream)); \
+        }                                                                                 \
+    } while (0)
+
+static const int OUT_N[12] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225 };
+static double **out_field(cpi_outputs *o, int k) {
+    double **f[12] = { &o->DT, &o->alpha, &o->beta, &o->q, &o->J_q, &o->J_a, &o->J_b, &o->H_a, &o->H_b, &o->O_a, &o->O_b, &o->P };
+    return f[k];
+}
+
+extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
+                                           const double *knots, const int64_t *first, const int32_t *count,
+                                           int64_t n_knots, const double *lin, const double *q_k_lin,
+                                           const cpi_outputs *out) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (!prm || !out || !knots || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch_host: NULL argument");
+    if (W <= 0) return W == 0 ? CPI_OK : fail(ctx, CPI_ERR_INVALID, "negative size");
+    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    if (!first) n_knots = W * (int64_t)(N + 1);
+    DevBuf dk, df, dc, dl, dq, dout[12];
+    CPI_UP(dk, knots, (size_t)n_knots * 7 * sizeof(double));
+    CPI_UP(df, first, (size_t)W * sizeof(int64_t));
+    CPI_UP(dc, count, (size_t)W * sizeof(int32_t));
+    CPI_UP(dl, lin, (size_t)W * 6 * sizeof(double));
+    CPI_UP(dq, q_k_lin, (size_t)W * 4 * sizeof(double));
+    cpi_outputs d = *out, h = *out;
+    for (int k = 0; k < 12; k++)
+        if (*out_field(&h, k)) {
+            CPI_HIP(ctx, hipMalloc(&dout[k].p, (size_t)W * OUT_N[k] * sizeof(double)));
+            *out_field(&d, k) = (double *)dout[k].p;
+        }
+    int rc = cpi_preintegrate_batch(ctx, prm, W, N, (const double *)dk.p, (const int64_t *)df.p, (const int32_t *)dc.p,
+                                    (const double *)dl.p, (const double *)dq.p, &d);
+    if (rc != CPI_OK) return rc;
+    for (int k = 0; k < 12; k++)
+        if (*out_field(&h, k))
+            CPI_HIP(ctx, hipMemcpyAsync(*out_field(&h, k), dout[k].p, (size_t)W * OUT_N[k] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CPI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CPI_OK;
+}
+
+extern "C" int cpi_factor_eval_batch_host(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                          const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                          const double *states, int64_t S, const int32_t *idx_i,
+                                          const int32_t *idx_j, double *err, double *H1, double *H2) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (!meas || !lin || !states || !err || !grav) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch_host: NULL argument");
+    if (F <= 0) return F == 0 ? CPI_OK : fail(ctx, CPI_ERR_INVALID, "negative size");
+    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf dl, dq, ds, di, dj, de, dh1, dh2, dm[11];
+    cpi_outputs hm = *meas, d;
+    memset(&d, 0, sizeof d);
+    for (int k = 0; k < 11; k++)
+        if (*out_field(&hm, k)) {
+            CPI_UP(dm[k], *out_field(&hm, k), (size_t)F * OUT_N[k] * sizeof(double));
+            *out_field(&d, k) = (double *)dm[k].p;
+        }
+    CPI_UP(dl, lin, (size_t)F * 6 * sizeof(double));
+    CPI_UP(dq, q_k_lin, (size_t)F * 4 * sizeof(double));
+    CPI_UP(ds, states, (size_t)S * 16 * sizeof(double));
+    CPI_UP(di, idx_i, (size_t)F * sizeof(int32_t));
+    CPI_UP(dj, idx_j, (size_t)F * sizeof(int32_t));
+    CPI_HIP(ctx, hipMalloc(&de.p, (size_t)F * 15 * sizeof(double)));
+    if (H1) CPI_HIP(ctx, hipMalloc(&dh1.p, (size_t)F * 225 * sizeof(double)));
+    if (H2) CPI_HIP(ctx, hipMalloc(&dh2.p, (size_t)F * 225 * sizeof(double)));
+    int rc = cpi_factor_eval_batch(ctx, model, grav, F, &d, (const double *)dl.p, (const double *)dq.p, (const double *)ds.p,
+                                   (const int32_t *)di.p, (const int32_t *)dj.p, (double *)de.p, (double *)dh1.p, (double *)dh2.p);
+    if (rc != CPI_OK) return rc;
+    CPI_HIP(ctx, hipMemcpyAsync(err, de.p, (size_t)F * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (H1) CPI_HIP(ctx, hipMemcpyAsync(H1, dh1.p, (size_t)F * 225 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (H2) CPI_HIP(ctx, hipMemcpyAsync(H2, dh2.p, (size_t)F * 225 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CPI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CPI_OK;
+}

@@ -1,0 +1,748 @@
+// cpi_math.hpp -- per-lane arithmetic of the MI355X continuous-preintegration kernels.
+//
+// Everything here is straight-line f64 code on 3-vectors / 3x3 blocks that lives in VGPRs: the
+// contractions are far too small for MFMA.  The kernels (cpi_kernels.hip) own the lane mapping,
+// LDS staging and cross-lane exchange; this header owns the mathematics so that it can also be
+// compiled for the host by tests/hostsim (a lane-by-lane emulator used ONLY by the CPU test suite
+// to validate kernel logic where no GPU is available -- it is not reachable from the C-ABI).
+//
+// What is computed (reference file:line):
+//   per-sample closed forms        cpi_compare/src/cpi/CpiV1.h:67-154 (means), :161-259 (analytic
+//                                  bias Jacobians); CpiV2.h:88-305 (model 2 incl. O_a/O_b)
+//   covariance / state transition  CpiV1.h:266-353 (15x15 RK4), CpiV2.h:314-464 (21x21 RK4 + Phi,
+//                                  clone / marginalise, Jacobian read-out)
+//   SO(3) / JPL quaternion helpers cpi_compare/src/utils/quat_ops.h:45-197
+//   factor residual + Jacobians    cpi_compare/src/gtsam/ImuFactorCPIv1.cpp:37-208, v2.cpp:38-212
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define CPI_HD __host__ __device__ __forceinline__
+#else
+#define CPI_HD inline
+#endif
+// Pin a value in a VGPR before it feeds a runtime select chain: stops LLVM from folding
+// "select of loads" into "load of a selected address", which would force the whole block to scratch.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CPI_REG(x) asm volatile("" : "+v"(x))
+#else
+#define CPI_REG(x) ((void)0)
+#endif
+
+namespace cpi {
+
+// ------------------------------------------------------------------------------------------
+// small fixed-size types (all register-resident)
+struct V3 { double x, y, z; };
+struct M3 { double m[3][3]; };  // row-major
+struct Q4 { double x, y, z, w; };  // JPL
+
+CPI_HD V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+CPI_HD V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+CPI_HD V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+CPI_HD V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+CPI_HD V3 operator*(double s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+CPI_HD V3 axpy(double s, V3 a, V3 b) { return mk(fma(s, a.x, b.x), fma(s, a.y, b.y), fma(s, a.z, b.z)); }
+CPI_HD V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+CPI_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+CPI_HD double get(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+CPI_HD V3 unit(int i) { return mk(i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0); }
+
+CPI_HD M3 eye() {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = (i == j) ? 1.0 : 0.0;
+    return r;
+}
+CPI_HD M3 zero3() {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = 0.0;
+    return r;
+}
+CPI_HD V3 mul(const M3 &A, V3 v) {  // A v
+    return mk(A.m[0][0] * v.x + A.m[0][1] * v.y + A.m[0][2] * v.z,
+              A.m[1][0] * v.x + A.m[1][1] * v.y + A.m[1][2] * v.z,
+              A.m[2][0] * v.x + A.m[2][1] * v.y + A.m[2][2] * v.z);
+}
+CPI_HD V3 mulT(const M3 &A, V3 v) {  // A^T v
+    return mk(A.m[0][0] * v.x + A.m[1][0] * v.y + A.m[2][0] * v.z,
+              A.m[0][1] * v.x + A.m[1][1] * v.y + A.m[2][1] * v.z,
+              A.m[0][2] * v.x + A.m[1][2] * v.y + A.m[2][2] * v.z);
+}
+CPI_HD M3 mm(const M3 &A, const M3 &B) {  // A B
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            r.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+    return r;
+}
+CPI_HD M3 mTm(const M3 &A, const M3 &B) {  // A^T B
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            r.m[i][j] = A.m[0][i] * B.m[0][j] + A.m[1][i] * B.m[1][j] + A.m[2][i] * B.m[2][j];
+    return r;
+}
+CPI_HD M3 madd(const M3 &A, const M3 &B) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = A.m[i][j] + B.m[i][j];
+    return r;
+}
+CPI_HD M3 maxpy(double s, const M3 &A, const M3 &B) {  // s A + B
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = fma(s, A.m[i][j], B.m[i][j]);
+    return r;
+}
+CPI_HD V3 col(const M3 &A, int j) { return mk(A.m[0][j], A.m[1][j], A.m[2][j]); }
+CPI_HD void addcol(M3 &A, int j, V3 v) { A.m[0][j] += v.x; A.m[1][j] += v.y; A.m[2][j] += v.z; }
+// skew_x(w) (quat_ops.h:92-98): skew(w) u = w x u
+CPI_HD M3 skew(V3 w) {
+    M3 r;
+    r.m[0][0] = 0;    r.m[0][1] = -w.z; r.m[0][2] = w.y;
+    r.m[1][0] = w.z;  r.m[1][1] = 0;    r.m[1][2] = -w.x;
+    r.m[2][0] = -w.y; r.m[2][1] = w.x;  r.m[2][2] = 0;
+    return r;
+}
+// c0*I + c1*[w]x + c2*[w]x^2, with [w]x^2 entries formed exactly as the matrix product w_x*w_x
+CPI_HD M3 poly_wx(V3 w, double c0, double c1, double c2) {
+    const double xx = w.x * w.x, yy = w.y * w.y, zz = w.z * w.z;
+    const double xy = w.x * w.y, xz = w.x * w.z, yz = w.y * w.z;
+    M3 r;
+    r.m[0][0] = fma(c2, -(yy + zz), c0);
+    r.m[1][1] = fma(c2, -(xx + zz), c0);
+    r.m[2][2] = fma(c2, -(xx + yy), c0);
+    r.m[0][1] = fma(c2, xy, -c1 * w.z); r.m[1][0] = fma(c2, xy, c1 * w.z);
+    r.m[0][2] = fma(c2, xz, c1 * w.y);  r.m[2][0] = fma(c2, xz, -c1 * w.y);
+    r.m[1][2] = fma(c2, yz, -c1 * w.x); r.m[2][1] = fma(c2, yz, c1 * w.x);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// sin/cos.  IMU angles |w|*dt are tiny (<= a few 0.1 rad even over dropped samples), so a
+// range-reduction-free Taylor/Horner kernel (truncation < 3e-19 on |x| <= 1) replaces the
+// general-purpose libm path; larger arguments take the library route.
+CPI_HD void sincos_fast(double x, double &s, double &c) {
+    if (fabs(x) <= 1.0) {
+        const double z = x * x;
+        double ps = -1.0 / 121645100408832000.0;              // x^19
+        ps = fma(ps, z, 1.0 / 355687428096000.0);            // x^17
+        ps = fma(ps, z, -1.0 / 1307674368000.0);             // x^15
+        ps = fma(ps, z, 1.0 / 6227020800.0);                 // x^13
+        ps = fma(ps, z, -1.0 / 39916800.0);                  // x^11
+        ps = fma(ps, z, 1.0 / 362880.0);                     // x^9
+        ps = fma(ps, z, -1.0 / 5040.0);                      // x^7
+        ps = fma(ps, z, 1.0 / 120.0);                        // x^5
+        ps = fma(ps, z, -1.0 / 6.0);                         // x^3
+        s = fma(x * z, ps, x);
+        double pc = -1.0 / 6402373705728000.0;                // x^18
+        pc = fma(pc, z, 1.0 / 20922789888000.0);             // x^16
+        pc = fma(pc, z, -1.0 / 87178291200.0);               // x^14
+        pc = fma(pc, z, 1.0 / 479001600.0);                  // x^12
+        pc = fma(pc, z, -1.0 / 3628800.0);                   // x^10
+        pc = fma(pc, z, 1.0 / 40320.0);                      // x^8
+        pc = fma(pc, z, -1.0 / 720.0);                       // x^6
+        pc = fma(pc, z, 1.0 / 24.0);                         // x^4
+        pc = fma(pc, z, -0.5);                               // x^2
+        c = fma(z, pc, 1.0);
+    } else {
+        s = sin(x);
+        c = cos(x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// quaternion helpers (quat_ops.h)
+CPI_HD Q4 rot_2_quat(const M3 &R) {  // quat_ops.h:45-86
+    const double r00 = R.m[0][0], r11 = R.m[1][1], r22 = R.m[2][2];
+    const double T = r00 + r11 + r22;
+    Q4 q;
+    if ((r00 >= T) && (r00 >= r11) && (r00 >= r22)) {
+        q.x = sqrt((1 + (2 * r00) - T) / 4);
+        const double k = 1 / (4 * q.x);
+        q.y = k * (R.m[0][1] + R.m[1][0]); q.z = k * (R.m[0][2] + R.m[2][0]); q.w = k * (R.m[1][2] - R.m[2][1]);
+    } else if ((r11 >= T) && (r11 >= r00) && (r11 >= r22)) {
+        q.y = sqrt((1 + (2 * r11) - T) / 4);
+        const double k = 1 / (4 * q.y);
+        q.x = k * (R.m[0][1] + R.m[1][0]); q.z = k * (R.m[1][2] + R.m[2][1]); q.w = k * (R.m[2][0] - R.m[0][2]);
+    } else if ((r22 >= T) && (r22 >= r00) && (r22 >= r11)) {
+        q.z = sqrt((1 + (2 * r22) - T) / 4);
+        const double k = 1 / (4 * q.z);
+        q.x = k * (R.m[0][2] + R.m[2][0]); q.y = k * (R.m[1][2] + R.m[2][1]); q.w = k * (R.m[0][1] - R.m[1][0]);
+    } else {
+        q.w = sqrt((1 + T) / 4);
+        const double k = 1 / (4 * q.w);
+        q.x = k * (R.m[1][2] - R.m[2][1]); q.y = k * (R.m[2][0] - R.m[0][2]); q.z = k * (R.m[0][1] - R.m[1][0]);
+    }
+    if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+    return q;
+}
+CPI_HD M3 quat_2_Rot(Q4 q) {  // quat_ops.h:104-109
+    const V3 v = mk(q.x, q.y, q.z);
+    const double c = 2 * q.w * q.w - 1;
+    const M3 S = skew(v);
+    M3 R;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            R.m[i][j] = c * (i == j ? 1.0 : 0.0) - 2 * q.w * S.m[i][j] + 2 * get(v, i) * get(v, j);
+    return R;
+}
+CPI_HD Q4 quat_multiply(Q4 q, Q4 p) {  // quat_ops.h:115-128
+    const V3 qv = mk(q.x, q.y, q.z), pv = mk(p.x, p.y, p.z);
+    const V3 c = cross(qv, pv);
+    Q4 r;
+    r.x = q.w * p.x - c.x + q.x * p.w;
+    r.y = q.w * p.y - c.y + q.y * p.w;
+    r.z = q.w * p.z - c.z + q.z * p.w;
+    r.w = q.w * p.w - dot(qv, pv);
+    if (r.w < 0) { r.x = -r.x; r.y = -r.y; r.z = -r.z; r.w = -r.w; }
+    const double n = sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+    r.x /= n; r.y /= n; r.z /= n; r.w /= n;
+    return r;
+}
+CPI_HD Q4 quat_inv(Q4 q) { Q4 r; r.x = -q.x; r.y = -q.y; r.z = -q.z; r.w = q.w; return r; }
+CPI_HD M3 Exp_so3(V3 w) {  // quat_ops.h:145-162
+    const double theta = sqrt(dot(w, w));
+    if (theta == 0) return eye();
+    double s, c;
+    sincos_fast(theta, s, c);
+    return poly_wx(w, 1.0, s / theta, (1 - c) / (theta * theta));
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-interval closed-form coefficients (CpiV1.h:97-142, identical in CpiV2.h:118-176).
+struct StepCoef {
+    double dt, mag, wdt, sn, cs;
+    double s1, s2;          // R_tau2tau1 = I - s1 [w]x + s2 [w]x^2
+    double f1, f2, f3, f4;  // alpha_arg = dt^2/2 I + f1 [w]x + f2 [w]x^2 ; Beta_arg = dt I + f3 [w]x + f4 [w]x^2
+    bool small;
+};
+CPI_HD StepCoef step_coef(V3 w, double dt) {
+    StepCoef k;
+    k.dt = dt;
+    k.mag = sqrt(dot(w, w));
+    k.wdt = k.mag * dt;
+    k.small = (k.mag < 0.008726646);  // threshold on the rate, CpiV1.h:101
+    sincos_fast(k.wdt, k.sn, k.cs);
+    if (k.small) {
+        k.s1 = dt; k.s2 = dt * dt / 2;
+        k.f1 = -(dt * dt * dt / 3);
+        k.f2 = (dt * dt * dt * dt / 8);
+        k.f3 = -(dt * dt / 2);
+        k.f4 = (dt * dt * dt / 6);
+    } else {
+        const double im = 1.0 / k.mag, im2 = im * im, im3 = im2 * im, im4 = im2 * im2;
+        k.s1 = k.sn * im;
+        k.s2 = (1.0 - k.cs) * im2;
+        k.f1 = (k.wdt * k.cs - k.sn) * im3;
+        k.f2 = (k.wdt * k.wdt - 2 * k.cs - 2 * k.wdt * k.sn + 2) * (0.5 * im4);
+        k.f3 = -(1 - k.cs) * im2;
+        k.f4 = (k.wdt - k.sn) * im3;
+    }
+    return k;
+}
+CPI_HD M3 R_step_of(V3 w, const StepCoef &k) { return poly_wx(w, 1.0, -k.s1, k.s2); }
+// rotation over the first half of the interval (CpiV1.h:267-268 / CpiV2.h:315-322)
+CPI_HD M3 R_half_of(V3 w, const StepCoef &k) {
+    const double h = 0.5 * k.dt;
+    if (k.small) return poly_wx(w, 1.0, -h, h * h / 2);
+    double s, c;
+    sincos_fast(k.mag * h, s, c);
+    const double im = 1.0 / k.mag;
+    return poly_wx(w, 1.0, -s * im, (1.0 - c) * im * im);
+}
+// ua = alpha_arg * a, ub = Beta_arg * a in vector form ([w]x^2 a = w x (w x a))
+CPI_HD void arg_times(V3 w, V3 a, const StepCoef &k, V3 &ua, V3 &ub) {
+    const V3 wa = cross(w, a), wwa = cross(w, wa);
+    ua = axpy(k.f2, wwa, axpy(k.f1, wa, (0.5 * k.dt * k.dt) * a));
+    ub = axpy(k.f4, wwa, axpy(k.f3, wa, k.dt * a));
+}
+
+// ------------------------------------------------------------------------------------------
+// Sequential mean (+ analytic Jacobian) recursion of one lane (kernel "cpi_mean").
+template <bool JAC>
+struct MeanState {
+    M3 R;
+    V3 alpha, beta;
+    double DT;
+    M3 Jq, Ja, Jb, Ha, Hb, Oa, Ob;  // only touched when JAC
+};
+template <bool JAC>
+CPI_HD void mean_init(MeanState<JAC> &s) {
+    s.R = eye();
+    s.alpha = mk(0, 0, 0); s.beta = mk(0, 0, 0); s.DT = 0;
+    if (JAC) { s.Jq = zero3(); s.Ja = zero3(); s.Jb = zero3(); s.Ha = zero3(); s.Hb = zero3(); s.Oa = zero3(); s.Ob = zero3(); }
+}
+
+// One feed_IMU.  MODEL 1: CpiV1.h:62-154(+161-259 if JAC).  MODEL 2: CpiV2.h:84-186(+187-305 if JAC,
+// i.e. the analytic Jacobians incl. O_a/O_b used when state_transition_jacobians == false).
+// w0/a0/w1/a1 are RAW readings; bw/ba the linearisation biases; gk = R(q_k_lin)*grav (model 2).
+template <int MODEL, bool JAC, bool AVG>
+CPI_HD void mean_step(MeanState<JAC> &s, double t0, double t1, V3 w0, V3 a0, V3 w1, V3 a1, V3 bw, V3 ba, V3 gk) {
+    const double dt = t1 - t0;
+    if (!(dt > 0)) return;  // dt == 0: feed_IMU returns early (CpiV1.h:72); dt < 0: caller skips (GraphSolver_IMU.cpp:52)
+    s.DT += dt;
+    V3 w = w0 - bw;
+    V3 a = a0 - ba;
+    V3 gtau = mk(0, 0, 0);
+    if (MODEL == 2) { gtau = mul(s.R, gk); a = a - gtau; }
+    if (AVG) {
+        w = 0.5 * (w + (w1 - bw));
+        if (MODEL == 1) a = 0.5 * (a + (a1 - ba));
+    }
+    const StepCoef k = step_coef(w, dt);
+    const M3 Rs = R_step_of(w, k);
+    const M3 Rn = mm(Rs, s.R);
+    if (MODEL == 2 && AVG) a = 0.5 * (a + (a1 - ba - mul(Rn, gk)));
+    V3 ua, ub;
+    arg_times(w, a, k, ua, ub);
+    const V3 da = mulT(Rn, ua), db = mulT(Rn, ub);
+    s.alpha = s.alpha + (dt * s.beta + da);  // uses the not-yet-updated beta (CpiV1.h:153)
+    s.beta = s.beta + db;
+
+    if (JAC) {
+        // right Jacobian times dt (CpiV1.h:162-167)
+        double c1, c2;
+        if (k.small) { c1 = 0.5; c2 = 1.0 / 6.0; }
+        else { const double iw = 1.0 / k.wdt; c1 = (1 - k.cs) * iw * iw; c2 = (k.wdt - k.sn) * iw * iw * iw; }
+        const M3 Jr_dt = poly_wx(w, dt, -c1 * dt * dt, c2 * dt * dt * dt);
+        const M3 Jsave = s.Jq;
+        s.Jq = madd(mm(Rs, s.Jq), Jr_dt);
+        // accel-bias Jacobians (CpiV1.h:170-172)
+        const M3 alpha_arg = poly_wx(w, 0.5 * dt * dt, k.f1, k.f2);
+        const M3 Beta_arg = poly_wx(w, dt, k.f3, k.f4);
+        const M3 Hal = mTm(Rn, alpha_arg), Hbe = mTm(Rn, Beta_arg);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+            s.Ha.m[i][j] = (s.Ha.m[i][j] - Hal.m[i][j]) + dt * s.Hb.m[i][j];
+            s.Hb.m[i][j] -= Hbe.m[i][j];
+        }
+        if (MODEL == 2) {  // CpiV2.h:201-205
+            const M3 Sg = skew(gk);
+            const M3 RS = mm(s.R, Sg);
+            const M3 Ta = mm(Hal, RS), Tb = mm(Hbe, RS);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                s.Oa.m[i][j] = (s.Oa.m[i][j] + dt * s.Ob.m[i][j]) - Ta.m[i][j];
+                s.Ob.m[i][j] -= Tb.m[i][j];
+            }
+        }
+        // d f_k / d|w| (CpiV1.h:196-238)
+        double d1, d2, d3, d4;
+        if (k.small) {
+            const double t2 = dt * dt, t4 = t2 * t2;
+            d1 = -(t4 * dt / 15); d2 = (t4 * t2 / 72); d3 = -(t4 / 12); d4 = (t4 * dt / 60);
+        } else {
+            const double im = 1.0 / k.mag, im2 = im * im, im4 = im2 * im2, im5 = im4 * im, im6 = im4 * im2;
+            const double x = k.wdt, x2 = x * x;
+            d1 = (x2 * k.sn - 3 * k.sn + 3 * x * k.cs) * im5;
+            d2 = (x2 - 4 * k.cs - 4 * x * k.sn + x2 * k.cs + 4) * im6;
+            d3 = (2 * (k.cs - 1) + x * k.sn) * im4;
+            d4 = (2 * x + x * k.cs - 3 * k.sn) * im5;
+        }
+        // gyro-bias Jacobians, column by column (CpiV1.h:241-259):
+        //   (d_R_bw_i*arg + R^T*G_i) a = R^T ( G_i a - (J_q e_i) x (arg a) )
+        const V3 wa = cross(w, a), wwa = cross(w, wa);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) s.Ja.m[i][j] += s.Jb.m[i][j] * dt;  // old J_b
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const V3 e = unit(c);
+            const double wc = get(w, c);
+            const V3 ea = cross(e, a);
+            const V3 sym = cross(e, wa) + cross(w, ea);  // (e_x w_x + w_x e_x) a
+            const V3 Ga = axpy(wc * d1, wa, axpy(wc * d2, wwa, -(k.f1 * ea) - (k.f2 * sym)));
+            const V3 Gb = axpy(wc * d3, wa, axpy(wc * d4, wwa, -(k.f3 * ea) - (k.f4 * sym)));
+            const V3 jq = col(s.Jq, c);  // updated J_q (CpiV1.h:175-177)
+            V3 ca = mulT(Rn, Ga - cross(jq, ua));
+            V3 cb = mulT(Rn, Gb - cross(jq, ub));
+            if (MODEL == 2) {  // CpiV2.h:282-305 (the J_b column-0 term carries the reference's double minus)
+                const V3 t = cross(col(Jsave, c), gtau);
+                const V3 ga = mul(Hal, t), gb = mul(Hbe, t);
+                ca = ca - ga;
+                cb = (c == 0) ? cb + gb : cb - gb;
+            }
+            addcol(s.Ja, c, ca);
+            addcol(s.Jb, c, cb);
+        }
+    }
+    s.R = Rn;
+}
+
+// Order-preserving composition of two consecutive segments A (earlier) then B (later), each
+// integrated from identity/zero (model 1): R_AB = R_B R_A, beta = beta_A + R_A^T beta_B,
+// alpha = alpha_A + beta_A DT_B + R_A^T alpha_B, and for the analytic Jacobians
+//   J_q = R_B J_q^A + J_q^B,  H_b = H_b^A + R_A^T H_b^B,  H_a = H_a^A + H_b^A DT_B + R_A^T H_a^B,
+//   J_b = J_b^A + R_A^T (J_b^B + [beta_B]x J_q^A),  J_a = J_a^A + J_b^A DT_B + R_A^T (J_a^B + [alpha_B]x J_q^A).
+template <bool JAC>
+CPI_HD void mean_combine(MeanState<JAC> &A, const MeanState<JAC> &B) {
+    if (JAC) {
+        const M3 SbJ = mm(skew(B.beta), A.Jq), SaJ = mm(skew(B.alpha), A.Jq);
+        const M3 nJb = mTm(A.R, madd(B.Jb, SbJ));
+        const M3 nJa = mTm(A.R, madd(B.Ja, SaJ));
+        const M3 nHb = mTm(A.R, B.Hb), nHa = mTm(A.R, B.Ha);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+            A.Ja.m[i][j] = (A.Ja.m[i][j] + A.Jb.m[i][j] * B.DT) + nJa.m[i][j];
+            A.Jb.m[i][j] += nJb.m[i][j];
+            A.Ha.m[i][j] = (A.Ha.m[i][j] + A.Hb.m[i][j] * B.DT) + nHa.m[i][j];
+            A.Hb.m[i][j] += nHb.m[i][j];
+        }
+        A.Jq = madd(mm(B.R, A.Jq), B.Jq);
+    }
+    A.alpha = A.alpha + (B.DT * A.beta + mulT(A.R, B.alpha));
+    A.beta = A.beta + mulT(A.R, B.beta);
+    A.R = mm(B.R, A.R);
+    A.DT += B.DT;
+}
+
+// ------------------------------------------------------------------------------------------
+// Covariance / state-transition column recursion (kernel "cpi_cov").
+//
+// One lane owns ONE COLUMN x of the (symmetric) covariance -- or, for model 2, one column of the
+// compounded state-transition matrix Discrete_J_b -- as a vector over the error state
+//   [theta(0:3) b_w(3:6) v(6:9) b_a(9:12) p(12:15) | theta_clone(15:18) | theta_klin(18:21)].
+// With F's block structure (CpiV1.h:276-281, CpiV2.h:331-338) the product F x is lane-local:
+//   (F x)_theta = -w x x_theta - x_bw
+//   (F x)_v     = -Rs^T ( a x x_theta + x_ba + g_tau x x_clone + R_old (g_k x x_klin) )
+//   (F x)_p     = x_v                                  (all other rows are zero)
+// and P F^T is its transpose, which the kernel obtains through a 9-row LDS exchange.
+// Classic RK4 with stage rotations (R_old, R_mid, R_mid, R_new), exactly as the reference.
+
+// Per-sample broadcast record produced lane-parallel by phase A of the kernel.
+struct SampleRec {
+    double dt;
+    V3 w, a0, a1;       // w_hat; a0 = a_m_0 - b_a (model-1 averaging already applied); a1 = a_m_1 - b_a (model 2 + avg)
+    double f1, f2, f3, f4;
+    M3 Rstep, Rhalf;
+};
+static const int SAMPLE_REC_DOUBLES = 1 + 9 + 4 + 18;  // 32
+
+template <int MODEL, bool AVG>
+CPI_HD SampleRec make_sample_rec(double t0, double t1, V3 w0, V3 a0, V3 w1, V3 a1, V3 bw, V3 ba) {
+    SampleRec r;
+    double dt = t1 - t0;
+    if (!(dt > 0)) dt = 0;  // a dt == 0 step is an exact no-op of the recursion below
+    r.dt = dt;
+    V3 w = w0 - bw;
+    r.a0 = a0 - ba;
+    r.a1 = a1 - ba;
+    if (AVG) {
+        w = 0.5 * (w + (w1 - bw));
+        if (MODEL == 1) r.a0 = 0.5 * (r.a0 + r.a1);
+    }
+    r.w = w;
+    const StepCoef k = step_coef(w, dt);
+    r.f1 = k.f1; r.f2 = k.f2; r.f3 = k.f3; r.f4 = k.f4;
+    r.Rstep = R_step_of(w, k);
+    r.Rhalf = R_half_of(w, k);
+    return r;
+}
+
+template <int MODEL>
+struct CovDims {
+    static const int NR = (MODEL == 1) ? 15 : 18;    // dynamic rows carried per column
+    static const int NPCOL = NR;                     // covariance columns (lanes)
+    static const int NDCOL = (MODEL == 1) ? 0 : 9;   // state-transition columns: b_w(3), b_a(3), theta_klin(3)
+    static const int NCOL = NPCOL + NDCOL;
+    static const int GROUP = (MODEL == 1) ? 16 : 32; // lanes per window
+};
+
+template <int MODEL>
+struct CovLane {
+    double P0[CovDims<MODEL>::NR];   // column at the start of the interval
+    double X[CovDims<MODEL>::NR];    // RK4 stage value
+    double acc[CovDims<MODEL>::NR];  // running RK4 sum
+    V3 xl;                           // theta_klin part of the column (constant; non-zero only for 3 D-columns)
+    // shared per-window running state, replicated in every lane of the group
+    M3 R;                            // R_k2tau
+    V3 alpha, beta;
+    double DT;
+    // per-interval scratch
+    M3 Rn, Rm;
+    V3 w, a, gtau, h;
+    double dt;
+};
+
+// j = column index inside the window's lane group: [0,NPCOL) covariance, [NPCOL,NCOL) transition.
+template <int MODEL>
+CPI_HD void cov_init(CovLane<MODEL> &L, int j) {
+    typedef CovDims<MODEL> D;
+#pragma unroll
+    for (int i = 0; i < D::NR; i++) { L.P0[i] = 0; L.X[i] = 0; L.acc[i] = 0; }
+    L.xl = mk(0, 0, 0);
+    if (MODEL == 2 && j >= D::NPCOL) {
+        // Discrete_J_b starts at identity (CpiV2.h:49): columns b_w (rows 3:6), b_a (9:12), theta_klin (18:21)
+        const int d = j - D::NPCOL;  // runtime per lane: selects only, no dynamically indexed registers
+        const int hot = (d < 3) ? 3 + d : ((d < 6) ? 9 + (d - 3) : -1);
+#pragma unroll
+        for (int i = 0; i < D::NR; i++) L.P0[i] = (i == hot) ? 1.0 : 0.0;
+        if (d >= 6) L.xl = unit(d - 6);
+    }
+    L.R = eye();
+    L.alpha = mk(0, 0, 0); L.beta = mk(0, 0, 0); L.DT = 0;
+}
+
+// Start of an interval: rotations, gravity terms, means (CpiV1.h:123-154 / CpiV2.h:99,141-186).
+template <int MODEL, bool AVG>
+CPI_HD void cov_begin(CovLane<MODEL> &L, const SampleRec &r, V3 gk) {
+    typedef CovDims<MODEL> D;
+    L.dt = r.dt;
+    L.w = r.w;
+    L.Rn = mm(r.Rstep, L.R);
+    L.Rm = mm(r.Rhalf, L.R);
+    V3 a = r.a0;
+    if (MODEL == 2) {
+        L.gtau = mul(L.R, gk);
+        L.h = mul(L.R, cross(gk, L.xl));
+        a = a - L.gtau;
+        if (AVG) a = 0.5 * (a + (r.a1 - mul(L.Rn, gk)));
+    } else {
+        L.gtau = mk(0, 0, 0); L.h = mk(0, 0, 0);
+    }
+    L.a = a;
+    StepCoef k;
+    k.dt = r.dt; k.f1 = r.f1; k.f2 = r.f2; k.f3 = r.f3; k.f4 = r.f4;
+    V3 ua, ub;
+    arg_times(r.w, a, k, ua, ub);
+    L.alpha = L.alpha + (r.dt * L.beta + mulT(L.Rn, ua));
+    L.beta = L.beta + mulT(L.Rn, ub);
+    L.DT += r.dt;
+#pragma unroll
+    for (int i = 0; i < D::NR; i++) { L.X[i] = L.P0[i]; L.acc[i] = L.P0[i]; }
+}
+
+// Stage s in {0,1,2,3}: M = rows (theta, v, p) of F x for this lane's column.
+template <int MODEL>
+CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, double M[9]) {
+    const M3 &Rs = (s == 0) ? L.R : ((s == 3) ? L.Rn : L.Rm);
+    const V3 xt = mk(L.X[0], L.X[1], L.X[2]);
+    const V3 xbw = mk(L.X[3], L.X[4], L.X[5]);
+    const V3 xba = mk(L.X[9], L.X[10], L.X[11]);
+    const V3 mt = -(cross(L.w, xt)) - xbw;
+    V3 y = cross(L.a, xt) + xba;
+    if (MODEL == 2) {
+        const V3 xc = mk(L.X[15], L.X[16], L.X[17]);
+        y = y + cross(L.gtau, xc) + L.h;
+    }
+    const V3 mv = -(mulT(Rs, y));
+    M[0] = mt.x; M[1] = mt.y; M[2] = mt.z;
+    M[3] = mv.x; M[4] = mv.y; M[5] = mv.z;
+    M[6] = L.X[6]; M[7] = L.X[7]; M[8] = L.X[8];
+}
+
+// Row index (0..8 in the exchange buffer) of the F-row that a covariance column j transposes, or -1.
+CPI_HD int cov_exch_row(int j) {
+    return (j < 3) ? j : ((j >= 6 && j < 9) ? j - 3 : ((j >= 12 && j < 15) ? j - 6 : -1));
+}
+
+// Finish stage s: k = M (rows theta,v,p) + Mt (the transposed row, covariance columns only) + G Q G^T
+// column, then X <- P0 + c k and acc += wgt k.  Mt[i] = (F X)[row j][col i] read from the exchange
+// buffer (ignored when is_pcol is false or the column's row of F is zero).
+template <int MODEL>
+CPI_HD void cov_stage_finish(CovLane<MODEL> &L, int s, const double M[9], const double *Mt, int j,
+                             const double q4[4]) {
+    typedef CovDims<MODEL> D;
+    const double dt = L.dt;
+    const double c = (s == 2) ? dt : 0.5 * dt;               // X for the next stage
+    const double wgt = (s == 0 || s == 3) ? dt / 6.0 : dt / 3.0;
+    const bool is_p = (j < D::NPCOL);
+    const bool has_t = is_p && (cov_exch_row(j) >= 0);
+#pragma unroll
+    for (int i = 0; i < D::NR; i++) {
+        double k = 0.0;
+        if (i < 3) k = M[i];
+        else if (i >= 6 && i < 9) k = M[i - 3];
+        else if (i >= 12 && i < 15) k = M[i - 6];
+        if (has_t) k += Mt[i];
+        if (is_p && i == j && i < 12) k += q4[i / 3];          // G Qc G^T = blkdiag(s_w^2, s_wb^2, s_a^2, s_ab^2, 0) (x) I
+        L.acc[i] = fma(wgt, k, L.acc[i]);
+        if (s < 3) L.X[i] = fma(c, k, L.P0[i]);
+    }
+}
+
+// End of interval: commit; model 2 row-clone theta -> theta_clone (B_k of CpiV2.h:436-443).
+// The column clone (columns 15:18 := columns 0:3) is a cross-lane copy done by the kernel.
+template <int MODEL>
+CPI_HD void cov_end(CovLane<MODEL> &L) {
+    typedef CovDims<MODEL> D;
+#pragma unroll
+    for (int i = 0; i < D::NR; i++) L.P0[i] = L.acc[i];
+    if (MODEL == 2) { L.P0[15] = L.P0[0]; L.P0[16] = L.P0[1]; L.P0[17] = L.P0[2]; }
+    L.R = L.Rn;
+}
+
+// ------------------------------------------------------------------------------------------
+// evaluateError (ImuFactorCPIv1.cpp:37-208 / ImuFactorCPIv2.cpp:38-212).
+struct FactorMeas {          // what the factor constructors copy (ImuFactorCPIv1.h:78-100)
+    V3 alpha, beta; Q4 q_KtoK1;
+    V3 ba_lin, bg_lin;
+    M3 J_q, J_beta, J_alpha, H_beta, H_alpha, O_beta, O_alpha;
+    double dt; V3 grav; Q4 q_K_lin;
+};
+struct NavState { Q4 q; V3 bg, v, ba, p; };  // JPLNavState.h:62-66
+struct FactorBlocks {
+    double err[15];
+    M3 H1_tt, H1_vt, H1_pt, H1_tg;  // state-dependent 3x3 blocks of H1: (0,0) (6,0) (12,0) (0,3)
+    M3 Rk;                          // quat_2_Rot(q_GtoK): H1 (6,6)=-Rk (12,6)=-dt Rk (12,12)=-Rk ; H2 (6,6)=(12,12)=Rk
+    M3 H2_tt;                       // H2 (0,0)
+};
+CPI_HD M3 qLmat(Q4 q, double sgn) {  // q_w I + sgn [q_v]x
+    const M3 S = skew(mk(q.x, q.y, q.z));
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = q.w * (i == j ? 1.0 : 0.0) + sgn * S.m[i][j];
+    return r;
+}
+template <int MODEL>
+CPI_HD void factor_eval(const FactorMeas &f, const NavState &xi, const NavState &xj, FactorBlocks &o) {
+    const V3 dbg = xi.bg - f.bg_lin, dba = xi.ba - f.ba_lin;
+    const Q4 q_b = rot_2_quat(Exp_so3(-(mul(f.J_q, dbg))));
+    const Q4 q_n = quat_multiply(xj.q, quat_inv(xi.q));
+    const Q4 q_rminus = quat_multiply(q_n, quat_inv(f.q_KtoK1));
+    const Q4 q_r = quat_multiply(q_rminus, q_b);
+    const Q4 q_m = quat_multiply(quat_inv(q_b), f.q_KtoK1);
+    Q4 q_kR; q_kR.x = 0; q_kR.y = 0; q_kR.z = 0; q_kR.w = 1;
+    V3 dthk = mk(0, 0, 0);
+    if (MODEL == 2) {
+        q_kR = quat_multiply(xi.q, quat_inv(f.q_K_lin));
+        dthk = mk(2 * q_kR.x, 2 * q_kR.y, 2 * q_kR.z);
+    }
+    o.Rk = quat_2_Rot(xi.q);
+    V3 pa, pb;
+    if (MODEL == 1) {
+        pa = (xj.p - xi.p) - f.dt * xi.v + (0.5 * f.dt * f.dt) * f.grav;
+        pb = (xj.v - xi.v) + f.dt * f.grav;
+    } else {
+        pa = (xj.p - xi.p) - f.dt * xi.v;
+        pb = xj.v - xi.v;
+    }
+    const V3 Ra = mul(o.Rk, pa), Rb = mul(o.Rk, pb);
+    V3 alphahat = Ra - mul(f.J_alpha, dbg) - mul(f.H_alpha, dba);
+    V3 betahat = Rb - mul(f.J_beta, dbg) - mul(f.H_beta, dba);
+    if (MODEL == 2) { alphahat = alphahat - mul(f.O_alpha, dthk); betahat = betahat - mul(f.O_beta, dthk); }
+    const V3 e0 = mk(2 * q_r.x, 2 * q_r.y, 2 * q_r.z), e1 = xj.bg - xi.bg, e2 = betahat - f.beta,
+             e3 = xj.ba - xi.ba, e4 = alphahat - f.alpha;
+    o.err[0] = e0.x; o.err[1] = e0.y; o.err[2] = e0.z;
+    o.err[3] = e1.x; o.err[4] = e1.y; o.err[5] = e1.z;
+    o.err[6] = e2.x; o.err[7] = e2.y; o.err[8] = e2.z;
+    o.err[9] = e3.x; o.err[10] = e3.y; o.err[11] = e3.z;
+    o.err[12] = e4.x; o.err[13] = e4.y; o.err[14] = e4.z;
+    // H1 (0,0)
+    const M3 AB = mm(qLmat(q_n, -1.0), qLmat(q_m, -1.0));
+    const V3 qnv = mk(q_n.x, q_n.y, q_n.z), qmv = mk(q_m.x, q_m.y, q_m.z);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) o.H1_tt.m[i][j] = -(AB.m[i][j] + get(qnv, i) * get(qmv, j));
+    o.H1_vt = skew(Rb);
+    o.H1_pt = skew(Ra);
+    if (MODEL == 2) {
+        const M3 L = qLmat(q_kR, +1.0);
+        const M3 Tb = mm(f.O_beta, L), Ta = mm(f.O_alpha, L);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) { o.H1_vt.m[i][j] -= Tb.m[i][j]; o.H1_pt.m[i][j] -= Ta.m[i][j]; }
+    }
+    o.H1_tg = mm(qLmat(q_rminus, -1.0), f.J_q);
+    o.H2_tt = qLmat(q_r, +1.0);
+}
+// Column c (0..14) of the dense 15x15 H1 / H2, assembled from the blocks with selects only
+// (c is a per-lane runtime value in the kernel: no dynamically indexed register arrays).
+CPI_HD double sel3(double a, double b, double c, int k) { return k == 0 ? a : (k == 1 ? b : c); }
+CPI_HD V3 colsel(const M3 &A, int cc) {
+    double a0 = A.m[0][0], a1 = A.m[0][1], a2 = A.m[0][2], b0 = A.m[1][0], b1 = A.m[1][1], b2 = A.m[1][2],
+           c0 = A.m[2][0], c1 = A.m[2][1], c2 = A.m[2][2];
+    CPI_REG(a0); CPI_REG(a1); CPI_REG(a2); CPI_REG(b0); CPI_REG(b1); CPI_REG(b2); CPI_REG(c0); CPI_REG(c1); CPI_REG(c2);
+    return mk(sel3(a0, a1, a2, cc), sel3(b0, b1, b2, cc), sel3(c0, c1, c2, cc));
+}
+CPI_HD void put3(double *o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+// H1 blocks (ImuFactorCPIv1.cpp:109-143): column-block 0 (theta): (0,0) (6,0) (12,0); 1 (b_g): (0,3) -I -J_beta
+// -J_alpha; 2 (v): -Rk, -dt Rk; 3 (b_a): -H_beta -I -H_alpha; 4 (p): -Rk.
+CPI_HD void factor_H1_col(const FactorBlocks &o, const FactorMeas &f, int c, double out[15]) {
+    const int bc = c / 3, cc = c - 3 * bc;
+    const V3 z = mk(0, 0, 0);
+    const V3 e = mk(cc == 0 ? -1.0 : 0.0, cc == 1 ? -1.0 : 0.0, cc == 2 ? -1.0 : 0.0);
+    const V3 rk = colsel(o.Rk, cc);
+    const V3 b0 = (bc == 0) ? colsel(o.H1_tt, cc) : ((bc == 1) ? colsel(o.H1_tg, cc) : z);
+    const V3 b1 = (bc == 1) ? e : z;
+    const V3 b2 = (bc == 0) ? colsel(o.H1_vt, cc)
+                : (bc == 1) ? -colsel(f.J_beta, cc)
+                : (bc == 2) ? -rk
+                : (bc == 3) ? -colsel(f.H_beta, cc) : z;
+    const V3 b3 = (bc == 3) ? e : z;
+    const V3 b4 = (bc == 0) ? colsel(o.H1_pt, cc)
+                : (bc == 1) ? -colsel(f.J_alpha, cc)
+                : (bc == 2) ? -(f.dt * rk)
+                : (bc == 3) ? -colsel(f.H_alpha, cc) : -rk;
+    put3(out, b0); put3(out + 3, b1); put3(out + 6, b2); put3(out + 9, b3); put3(out + 12, b4);
+}
+// H2 blocks (ImuFactorCPIv1.cpp:169-185): block diagonal (0,0)=q_r,w I + [q_r,v]x, I, Rk, I, Rk.
+CPI_HD void factor_H2_col(const FactorBlocks &o, int c, double out[15]) {
+    const int bc = c / 3, cc = c - 3 * bc;
+    const V3 z = mk(0, 0, 0);
+    const V3 e = mk(cc == 0 ? 1.0 : 0.0, cc == 1 ? 1.0 : 0.0, cc == 2 ? 1.0 : 0.0);
+    const V3 rk = colsel(o.Rk, cc);
+    put3(out, (bc == 0) ? colsel(o.H2_tt, cc) : z);
+    put3(out + 3, (bc == 1) ? e : z);
+    put3(out + 6, (bc == 2) ? rk : z);
+    put3(out + 9, (bc == 3) ? e : z);
+    put3(out + 12, (bc == 4) ? rk : z);
+}
+CPI_HD double pick15(const double *e, int c) {
+    double r = e[0];
+    CPI_REG(r);
+#pragma unroll
+    for (int i = 1; i < 15; i++) { double t = e[i]; CPI_REG(t); r = (c == i) ? t : r; }
+    return r;
+}
+// State prediction (GraphSolver_IMU.cpp:263-281 / 289-307).
+template <int MODEL>
+CPI_HD NavState predict_state(const NavState &xi, V3 alpha, V3 beta, Q4 q_KtoK1, double dt, V3 grav) {
+    NavState o;
+    o.q = quat_multiply(q_KtoK1, xi.q);
+    const M3 Rinv = quat_2_Rot(quat_inv(xi.q));
+    const V3 rb = mul(Rinv, beta), ra = mul(Rinv, alpha);
+    o.bg = xi.bg; o.ba = xi.ba;
+    if (MODEL == 1) {
+        o.v = (xi.v - dt * grav) + rb;
+        o.p = ((xi.p + dt * xi.v) - (0.5 * dt * dt) * grav) + ra;
+    } else {
+        o.v = xi.v + rb;
+        o.p = (xi.p + dt * xi.v) + ra;
+    }
+    return o;
+}
+
+}  // namespace cpi

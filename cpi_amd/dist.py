@@ -1,0 +1,43 @@
+"""Multi-GPU sharding of a batch of preintegration windows (one process per GPU).
+
+Windows (and factors) are independent units: rank r owns the contiguous block
+[r*ceil(W/n), (r+1)*ceil(W/n)) and runs the kernels on it with no data-path collective.  The only
+exchange step is the FINAL gather of the equal-sized per-rank output slabs (RCCL all_gather over
+xGMI when the backend is "nccl"; "gloo" in the CPU tests).  Nothing like this exists in the
+reference (single-threaded CPU program); SURVEY.md section 8(e).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(W, rank, world):
+    """Contiguous block partition with equal padded block size."""
+    per = (W + world - 1) // world
+    lo = min(W, rank * per)
+    hi = min(W, lo + per)
+    return lo, hi, per
+
+
+def gather_outputs(local, W_total, group=None, dst=None):
+    """local: dict name -> tensor [w_local, ...] (this rank's block, in shard_bounds order).
+    Returns dict name -> tensor [W_total, ...] on every rank (dst=None, all_gather) or only on `dst`
+    (others get None).  Slabs are padded to the common block size so one collective per field moves
+    equal counts."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi, per = shard_bounds(W_total, rank, world)
+    out = {}
+    for name in sorted(local):
+        t = local[name]
+        assert t.shape[0] == hi - lo, (name, t.shape, lo, hi)
+        pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: hi - lo] = t
+        full = torch.empty((world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if dst is None:
+            dist.all_gather_into_tensor(full, pad, group=group)
+            out[name] = full[:W_total]
+        else:
+            parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+            dist.gather(pad, parts, dst=dst, group=group)
+            out[name] = torch.cat(parts, dim=0)[:W_total] if rank == dst else None
+    return out

@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference's preintegrator / factor interface over the C-ABI.
+
+    Engine                 one (device, stream) context; batched device-resident entry points
+    CpiV1 / CpiV2          same constructor, setLinearizationPoints(), feed_IMU() and public result
+                           fields as the reference classes (cpi_compare/src/cpi/CpiBase.h:40-145,
+                           CpiV1.h:62, CpiV2.h:84); the recursion runs on the GPU when a result is read
+    ImuFactorCPIv1 / v2    constructor argument order of ImuFactorCPIv1.h:78-81 / ImuFactorCPIv2.h:82-85
+                           and evaluateError(state_i, state_j) -> (error, H1, H2)
+
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import OUT_FIELDS, CpiError, CpiOutputs, CpiParams
+
+DEFAULT_SIGMAS = (0.005, 4e-6, 0.01, 2e-4)   # ADIS16448, cpi_compare/launch/synthetic_test.launch:13-17
+DEFAULT_GRAV = (0.0, 0.0, 9.8)
+MEAN_FIELDS = ("DT", "alpha", "beta", "q")
+JAC_FIELDS = ("J_q", "J_a", "J_b", "H_a", "H_b", "O_a", "O_b")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    def __init__(self, device=None, stream=None):
+        self.lib = _lib.load()
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        ctx = C.c_void_p()
+        if stream is None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(self.device)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        rc = self.lib.cpi_ctx_create(self.device.index or 0, sptr, C.byref(ctx))
+        if rc != 0:
+            raise CpiError(rc, (self.lib.cpi_last_error(None) or b"").decode())
+        self.ctx = ctx
+        self.stream = stream
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.cpi_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CpiError(rc, (self.lib.cpi_last_error(self.ctx) or b"").decode())
+
+    def synchronize(self):
+        self._check(self.lib.cpi_ctx_synchronize(self.ctx))
+
+    # ------------------------------------------------------------------ preintegration
+    @staticmethod
+    def make_params(model=1, imu_avg=False, state_transition_jacobians=True, sigmas=DEFAULT_SIGMAS,
+                    grav=DEFAULT_GRAV, lanes_per_window=0):
+        p = CpiParams()
+        p.sigma_w, p.sigma_wb, p.sigma_a, p.sigma_ab = sigmas
+        p.grav[:] = grav
+        p.model, p.imu_avg = int(model), int(bool(imu_avg))
+        p.state_transition_jacobians = int(bool(state_transition_jacobians))
+        p.lanes_per_window = int(lanes_per_window)
+        return p
+
+    def alloc_outputs(self, W, want=("mean", "jac", "cov"), model=1):
+        out = {}
+        for name, n in OUT_FIELDS:
+            grp = "mean" if name in MEAN_FIELDS else ("cov" if name == "P" else "jac")
+            if grp not in want:
+                continue
+            if model == 1 and name in ("O_a", "O_b"):
+                continue
+            shape = (W,) if n == 1 else (W, n)
+            out[name] = torch.empty(shape, dtype=torch.float64, device=self.device)
+        return out
+
+    @staticmethod
+    def _outputs_struct(out):
+        o = CpiOutputs()
+        for name, _ in OUT_FIELDS:
+            t = out.get(name)
+            setattr(o, name, t.data_ptr() if t is not None else None)
+        return o
+
+    def preintegrate(self, knots, lin, q_k_lin=None, params=None, want=("mean", "jac", "cov"), first=None,
+                     count=None, N=None, out=None):
+        """knots [W,N+1,7] (dense) or [K,7] with first[W] (int64) / count[W] (int32); lin [W,6];
+        q_k_lin [W,4].  All CUDA float64 tensors.  Returns a dict of device tensors (matrices flat,
+        column-major).  Asynchronous on the engine's stream."""
+        params = params or self.make_params()
+        if first is None:
+            W, n1, seven = knots.shape
+            N = n1 - 1
+        else:
+            W = first.shape[0]
+            assert N is not None, "ragged layout needs N = max intervals per window"
+        for t in (knots, lin, q_k_lin, first, count):
+            assert t is None or (t.is_cuda and t.is_contiguous()), "inputs must be contiguous CUDA tensors"
+        assert knots.dtype == torch.float64 and lin.dtype == torch.float64
+        if out is None:
+            out = self.alloc_outputs(W, want, params.model)
+        o = self._outputs_struct(out)
+        self._check(self.lib.cpi_preintegrate_batch(self.ctx, C.byref(params), W, N, _ptr(knots), _ptr(first), _ptr(count),
+                                                    _ptr(lin), _ptr(q_k_lin), C.byref(o)))
+        return out
+
+    # ------------------------------------------------------------------ factors
+    def factor_eval(self, model, meas, lin, q_k_lin, states, idx_i=None, idx_j=None, want_H=True, grav=DEFAULT_GRAV,
+                    out=None):
+        F = lin.shape[0]
+        if out is None:
+            out = {"err": torch.empty((F, 15), dtype=torch.float64, device=self.device)}
+            if want_H:
+                out["H1"] = torch.empty((F, 225), dtype=torch.float64, device=self.device)
+                out["H2"] = torch.empty((F, 225), dtype=torch.float64, device=self.device)
+        m = self._outputs_struct(meas)
+        g = (C.c_double * 3)(*grav)
+        self._check(self.lib.cpi_factor_eval_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin),
+                                                   _ptr(states), _ptr(idx_i), _ptr(idx_j), _ptr(out["err"]),
+                                                   _ptr(out.get("H1")), _ptr(out.get("H2"))))
+        return out
+
+    def predict(self, model, meas, states_i, idx_i=None, grav=DEFAULT_GRAV):
+        F = meas["DT"].shape[0]
+        xj = torch.empty((F, 16), dtype=torch.float64, device=self.device)
+        m = self._outputs_struct(meas)
+        g = (C.c_double * 3)(*grav)
+        self._check(self.lib.cpi_predict_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(states_i), _ptr(idx_i), _ptr(xj)))
+        return xj
+
+
+_default_engine = None
+
+
+def default_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine()
+    return _default_engine
+
+
+# ---------------------------------------------------------------------- reference-shaped classes
+class _CpiBase:
+    """Mirror of CpiBase (CpiBase.h:40-145).  feed_IMU() records the interval; reading any result
+    field runs the whole window through cpi_preintegrate_batch on the GPU (one window = one batch)."""
+    _model = 0
+
+    def __init__(self, sigma_w, sigma_wb, sigma_a, sigma_ab, imu_avg_=False, engine=None):
+        self._sig = (sigma_w, sigma_wb, sigma_a, sigma_ab)
+        self.imu_avg = bool(imu_avg_)
+        self.state_transition_jacobians = True
+        self.b_w_lin = np.zeros(3); self.b_a_lin = np.zeros(3)
+        self.q_k_lin = np.zeros(4); self.grav = np.zeros(3)
+        self._iv = []      # (t0, t1, w0, a0, w1, a1)
+        self._res = None
+        self._engine = engine
+
+    def setLinearizationPoints(self, b_w_lin_, b_a_lin_, q_k_lin_=None, grav_=None):
+        self.b_w_lin = np.asarray(b_w_lin_, dtype=np.float64).reshape(3)
+        self.b_a_lin = np.asarray(b_a_lin_, dtype=np.float64).reshape(3)
+        self.q_k_lin = np.zeros(4) if q_k_lin_ is None else np.asarray(q_k_lin_, dtype=np.float64).reshape(4)
+        self.grav = np.zeros(3) if grav_ is None else np.asarray(grav_, dtype=np.float64).reshape(3)
+        self._res = None
+
+    def feed_IMU(self, t_0, t_1, w_m_0, a_m_0, w_m_1=None, a_m_1=None):
+        z = np.zeros(3)
+        self._iv.append((float(t_0), float(t_1), np.asarray(w_m_0, float).reshape(3), np.asarray(a_m_0, float).reshape(3),
+                         z if w_m_1 is None else np.asarray(w_m_1, float).reshape(3),
+                         z if a_m_1 is None else np.asarray(a_m_1, float).reshape(3)))
+        self._res = None
+
+    def _knots(self):
+        """Intervals -> knot records.  Consecutive intervals that chain (t1 == next t0 and the next
+        reading equals this interval's w1/a1) share a knot; otherwise each interval is fed as its own
+        2-knot window segment separated by a zero-length gap knot pair (dt == 0 is skipped)."""
+        rows = []
+        for (t0, t1, w0, a0, w1, a1) in self._iv:
+            if rows and rows[-1][0] == t0 and np.array_equal(rows[-1][1:4], w0) and np.array_equal(rows[-1][4:7], a0):
+                pass
+            else:
+                if rows:
+                    # re-anchor: repeat the time of the previous knot with the new reading (dt == 0 no-op step)
+                    if t0 != rows[-1][0]:
+                        raise ValueError("feed_IMU intervals must be contiguous in time")
+                    rows.append(np.concatenate([[t0], w0, a0]))
+                else:
+                    rows.append(np.concatenate([[t0], w0, a0]))
+            rows.append(np.concatenate([[t1], w1, a1]))
+        return np.stack(rows) if rows else np.zeros((1, 7))
+
+    def _run(self):
+        if self._res is not None:
+            return self._res
+        eng = self._engine or default_engine()
+        kn = self._knots()
+        dev = eng.device
+        knots = torch.from_numpy(kn[None]).to(dev)
+        lin = torch.from_numpy(np.concatenate([self.b_w_lin, self.b_a_lin])[None]).to(dev)
+        q = torch.from_numpy(self.q_k_lin[None]).to(dev)
+        prm = eng.make_params(self._model, self.imu_avg, self.state_transition_jacobians, self._sig, tuple(self.grav))
+        out = eng.preintegrate(knots, lin, q, prm)
+        eng.synchronize()
+        self._res = {k: v.cpu().numpy()[0] for k, v in out.items()}
+        return self._res
+
+    def _m3(self, name):
+        return self._run()[name].reshape(3, 3).T  # column-major -> [row][col]
+
+    DT = property(lambda s: float(s._run()["DT"]))
+    alpha_tau = property(lambda s: s._run()["alpha"])
+    beta_tau = property(lambda s: s._run()["beta"])
+    q_k2tau = property(lambda s: s._run()["q"])
+    J_q = property(lambda s: s._m3("J_q"))
+    J_a = property(lambda s: s._m3("J_a"))
+    J_b = property(lambda s: s._m3("J_b"))
+    H_a = property(lambda s: s._m3("H_a"))
+    H_b = property(lambda s: s._m3("H_b"))
+    P_meas = property(lambda s: s._run()["P"].reshape(15, 15).T)
+
+
+class CpiV1(_CpiBase):
+    _model = 1
+
+
+class CpiV2(_CpiBase):
+    _model = 2
+    O_a = property(lambda s: s._m3("O_a"))
+    O_b = property(lambda s: s._m3("O_b"))
+
+
+class _ImuFactorBase:
+    _model = 0
+
+    def _setup(self, covariance, deltatime, grav, alpha, beta, q_KtoK1, ba_lin, bg_lin, J_q, J_beta, J_alpha, H_beta,
+               H_alpha, q_K_lin=None, O_beta=None, O_alpha=None, engine=None):
+        self.covariance = np.asarray(covariance, float)
+        self._grav = tuple(np.asarray(grav, float).reshape(3))
+        cm = lambda M: np.asarray(M, float).reshape(3, 3).T.reshape(9)  # -> column-major flat
+        f = lambda v, n: np.asarray(v, float).reshape(n)
+        self._meas = dict(DT=np.array([float(deltatime)]), alpha=f(alpha, 3)[None], beta=f(beta, 3)[None],
+                          q=f(q_KtoK1, 4)[None], J_q=cm(J_q)[None], J_b=cm(J_beta)[None], J_a=cm(J_alpha)[None],
+                          H_b=cm(H_beta)[None], H_a=cm(H_alpha)[None])
+        if self._model == 2:
+            self._meas["O_b"] = cm(O_beta)[None]; self._meas["O_a"] = cm(O_alpha)[None]
+        self._lin = np.concatenate([f(bg_lin, 3), f(ba_lin, 3)])[None]
+        self._qk = None if q_K_lin is None else f(q_K_lin, 4)[None]
+        self._engine = engine
+
+    def evaluateError(self, state_i, state_j, want_H=True):
+        """state = 16-vector [q(4) bg(3) v(3) ba(3) p(3)].  Returns error[15] (and H1, H2 as 15x15)."""
+        eng = self._engine or default_engine()
+        dev = eng.device
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        meas = {k: T(v) for k, v in self._meas.items()}
+        states = T(np.stack([np.asarray(state_i, float).reshape(16), np.asarray(state_j, float).reshape(16)]))
+        out = eng.factor_eval(self._model, meas, T(self._lin), None if self._qk is None else T(self._qk), states,
+                              want_H=want_H, grav=self._grav)
+        eng.synchronize()
+        e = out["err"].cpu().numpy()[0]
+        if not want_H:
+            return e
+        return e, out["H1"].cpu().numpy()[0].reshape(15, 15).T, out["H2"].cpu().numpy()[0].reshape(15, 15).T
+
+
+class ImuFactorCPIv1(_ImuFactorBase):
+    """Argument order of ImuFactorCPIv1.h:78-81 (keys omitted)."""
+    _model = 1
+
+    def __init__(self, covariance, deltatime, grav, alpha, beta, q_KtoK1, ba_lin, bg_lin, J_q, J_beta, J_alpha, H_beta,
+                 H_alpha, engine=None):
+        self._setup(covariance, deltatime, grav, alpha, beta, q_KtoK1, ba_lin, bg_lin, J_q, J_beta, J_alpha, H_beta,
+                    H_alpha, engine=engine)
+
+
+class ImuFactorCPIv2(_ImuFactorBase):
+    """Argument order of ImuFactorCPIv2.h:82-85 (keys omitted)."""
+    _model = 2
+
+    def __init__(self, covariance, deltatime, grav, alpha, beta, q_KtoK1, q_K_lin, ba_lin, bg_lin, J_q, J_beta, J_alpha,
+                 H_beta, H_alpha, O_beta, O_alpha, engine=None):
+        self._setup(covariance, deltatime, grav, alpha, beta, q_KtoK1, ba_lin, bg_lin, J_q, J_beta, J_alpha, H_beta,
+                    H_alpha, q_K_lin=q_K_lin, O_beta=O_beta, O_alpha=O_alpha, engine=engine)

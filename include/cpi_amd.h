@@ -1,0 +1,135 @@
+/*
+ * cpi_amd.h -- C-ABI of the MI355X-native batched continuous-preintegration engine.
+ *
+ * This is the drop-in boundary for the rpng/cpi hot path.  The reference has no FFI layer: the
+ * boundary there is two C++ class interfaces compiled into the caller,
+ *   - the preintegrator  CpiBase / CpiV1 / CpiV2   (cpi_compare/src/cpi/CpiBase.h:40-145,
+ *     CpiV1.h:62, CpiV2.h:84): ctor(sigmas, imu_avg), setLinearizationPoints(), feed_IMU() called
+ *     once per IMU interval (GraphSolver_IMU.cpp:50-69), results read from public members
+ *     (GraphSolver_IMU.cpp:74-75,129-130);
+ *   - the factor  ImuFactorCPIv1/v2::evaluateError(state_i, state_j, H1, H2)
+ *     (cpi_compare/src/gtsam/ImuFactorCPIv1.h:139 / .cpp:37, ImuFactorCPIv2.h:151 / .cpp:38),
+ *     called by GTSAM once per factor per re-linearisation.
+ * The entry points below are the batched equivalents a binding of those two interfaces would call
+ * (see INTEGRATION.md for the reference-side stub).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - all arithmetic is IEEE double; all pointers are DEVICE pointers unless the name says _host;
+ *   - every 3x3 / 15x15 matrix is COLUMN-MAJOR (Eigen's default, so Eigen::Map works unchanged);
+ *   - quaternions are JPL [x y z w] with w >= 0 (quat_ops.h:80-82);
+ *   - error-state / tangent order is [theta b_g v b_a p] (ImuFactorCPIv1.cpp:80);
+ *   - JPLNavState is 16 doubles [q(4) b_g(3) v(3) b_a(3) p(3)] (JPLNavState.h:62-66);
+ *   - calls on one cpi_ctx are ordered on its HIP stream and return without synchronising;
+ *     distinct contexts (one per GPU / per stream) are independent.  No global state.
+ */
+#ifndef CPI_AMD_H
+#define CPI_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPI_ABI_VERSION 1
+
+enum { CPI_OK = 0, CPI_ERR_INVALID = 1, CPI_ERR_HIP = 2, CPI_ERR_NO_DEVICE = 3 };
+enum { CPI_MODEL_V1 = 1, CPI_MODEL_V2 = 2 };
+
+typedef struct cpi_ctx cpi_ctx;
+
+/* Replaces: CpiBase ctor arguments (CpiBase.h:52), the imu_avg flag (CpiBase.h:95), the
+ * state_transition_jacobians flag (CpiV2.h:58) and the gravity passed to setLinearizationPoints
+ * (CpiBase.h:73-80; one global gravity per batch, as in Config.h / GraphSolver_IMU.cpp:44). */
+typedef struct {
+    double sigma_w, sigma_wb, sigma_a, sigma_ab;
+    double grav[3];
+    int32_t model;                       /* CPI_MODEL_V1 | CPI_MODEL_V2 */
+    int32_t imu_avg;                     /* 0 / 1 */
+    int32_t state_transition_jacobians;  /* model 2 only; reference default 1 */
+    int32_t lanes_per_window;            /* mean kernel: 0 = auto, else 1,2,4,...,64 (tuning knob) */
+} cpi_params;
+
+/* Replaces: the public result members of CpiBase / CpiV2 (CpiBase.h:99-124, CpiV2.h:62-63).
+ * Structure-of-arrays over the W windows of a batch; any pointer may be NULL = "not wanted":
+ *   DT, alpha, beta, q all NULL      -> means are not written
+ *   J_q ... O_b all NULL             -> bias / orientation Jacobians are not computed
+ *   P NULL                           -> the covariance recursion is skipped (mean-only kernel) */
+typedef struct {
+    double *DT;     /* [W]       CpiBase::DT        */
+    double *alpha;  /* [W][3]    alpha_tau          */
+    double *beta;   /* [W][3]    beta_tau           */
+    double *q;      /* [W][4]    q_k2tau            */
+    double *J_q;    /* [W][9]    orientation wrt b_w */
+    double *J_a;    /* [W][9]    alpha wrt b_w      */
+    double *J_b;    /* [W][9]    beta wrt b_w       */
+    double *H_a;    /* [W][9]    alpha wrt b_a      */
+    double *H_b;    /* [W][9]    beta wrt b_a       */
+    double *O_a;    /* [W][9]    alpha wrt q_k_lin (model 2) */
+    double *O_b;    /* [W][9]    beta wrt q_k_lin  (model 2) */
+    double *P;      /* [W][225]  P_meas             */
+} cpi_outputs;
+
+/* device < 0: use the current HIP device.  stream: a hipStream_t (NULL = the default stream). */
+int cpi_ctx_create(int device, void *stream, cpi_ctx **out);
+void cpi_ctx_destroy(cpi_ctx *ctx);
+const char *cpi_last_error(const cpi_ctx *ctx); /* ctx may be NULL: last error of a failed create */
+int cpi_abi_version(void);
+int cpi_ctx_synchronize(cpi_ctx *ctx);
+
+/* Replaces: the per-window loop  CpiV{1,2} cpi(...); cpi.setLinearizationPoints(...);
+ *           while (...) cpi.feed_IMU(t0,t1,w0,a0,w1,a1);   (GraphSolver_IMU.cpp:43-69, 97-124).
+ *
+ * knots   IMU knot records {t, w[3], a[3]} (7 doubles).  Interval i of a window is
+ *         feed_IMU(t_i, t_{i+1}, w_i, a_i, w_{i+1}, a_{i+1}); intervals with t_{i+1}-t_i <= 0 are
+ *         skipped exactly like the reference (dt==0: CpiV1.h:72; dt<0: GraphSolver_IMU.cpp:52).
+ *         A tail interval [t_last, updatetime] is expressed by a final knot
+ *         {updatetime, w_last, a_last} (GraphSolver_IMU.cpp:64-69).
+ * first   [W] index of each window's first knot, or NULL for the dense layout knots[W][N+1][7].
+ * count   [W] number of intervals of each window (<= N), or NULL = every window has N.
+ *         Windows may share knots (consecutive windows cut from one stream).
+ * N       maximum number of intervals per window.
+ * lin     [W][6]  {b_w_lin[3], b_a_lin[3]}  (CpiBase.h:113-114)
+ * q_k_lin [W][4]  JPL q_GtoK linearisation orientation (CpiBase.h:115); required for model 2.
+ * Zero-length windows produce the identity / zero state.  W == 0 is a no-op. */
+int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
+                           const double *knots, const int64_t *first, const int32_t *count,
+                           const double *lin, const double *q_k_lin, const cpi_outputs *out);
+
+/* Replaces: ImuFactorCPIv1::evaluateError / ImuFactorCPIv2::evaluateError, one call per factor
+ * (ImuFactorCPIv1.cpp:37-208, ImuFactorCPIv2.cpp:38-212), as driven by GTSAM's linearize loop.
+ *
+ * Factor f reads its measurement from the preintegration outputs of window f (field -> ctor
+ * mapping of GraphSolver_IMU.cpp:74-75,129-130: J_b->J_beta, J_a->J_alpha, H_b->H_beta,
+ * H_a->H_alpha, O_b->O_beta, O_a->O_alpha), its linearisation biases from lin[f] and, for
+ * model 2, q_K_lin from q_k_lin[f].
+ * states  [S][16] JPLNavState array; idx_i/idx_j [F] select state_i/state_j (NULL: f and f+1).
+ * err     [F][15] unwhitened residual; H1, H2 [F][225] dense column-major Jacobians wrt the two
+ *         states' tangent vectors; H1/H2 may be NULL (the boost::optional<Matrix&> = none case). */
+int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                          const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                          const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                          double *err, double *H1, double *H2);
+
+/* Replaces: GraphSolver::getpredictedstate_v1 / _v2 (GraphSolver_IMU.cpp:263-281, 289-307):
+ * states_j[f] = prediction of X(k+1) from states_i[idx_i[f]] and measurement f. */
+int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                      const cpi_outputs *meas, const double *states_i, const int32_t *idx_i,
+                      double *states_j);
+
+/* Convenience for single-window / small host-side callers (the CpiV1-shaped C++ facade in
+ * cpi_amd/csrc/cpi_host.hpp): same as cpi_preintegrate_batch but every pointer is a HOST pointer;
+ * stages through device memory and synchronises.  PCIe-inclusive, not the benchmarked path. */
+int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
+                                const double *knots, const int64_t *first, const int32_t *count,
+                                int64_t n_knots, const double *lin, const double *q_k_lin,
+                                const cpi_outputs *out);
+int cpi_factor_eval_batch_host(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                               const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                               const double *states, int64_t S, const int32_t *idx_i,
+                               const int32_t *idx_j, double *err, double *H1, double *H2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPI_AMD_H */

@@ -1,0 +1,155 @@
+// hostsim.cpp -- lane-by-lane HOST emulation of the HIP kernels' arithmetic (cpi_math.hpp).
+// TEST INFRASTRUCTURE ONLY: lets the CPU test-suite validate the kernel mathematics (segment
+// composition, column-lane covariance recursion with its transpose exchange, factor blocks)
+// against the oracle where no GPU exists.  Not linked into, or reachable from, libcpi_amd.so.
+#include "../../cpi_amd/csrc/cpi_math.hpp"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+using namespace cpi;
+
+namespace {
+const int OUTD = 308;  // DT1 alpha3 beta3 q4 R9 Jq9 Ja9 Jb9 Ha9 Hb9 Oa9 Ob9 P225
+void put_cm(double *dst, const M3 &A) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) dst[j * 3 + i] = A.m[i][j]; }
+V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+M3 ld_cm(const double *p) { M3 A; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A.m[i][j] = p[j * 3 + i]; return A; }
+Q4 ldq(const double *p) { Q4 q; q.x = p[0]; q.y = p[1]; q.z = p[2]; q.w = p[3]; return q; }
+
+template <int MODEL, bool JAC, bool AVG>
+void mean_window(int L, int n, const double *kn, const double *lin, const double *qk, const double *grav, double *o) {
+    const V3 bw = ld3(lin), ba = ld3(lin + 3);
+    V3 gk = mk(0, 0, 0);
+    if (MODEL == 2) gk = mul(quat_2_Rot(ldq(qk)), ld3(grav));
+    const int per = (n + L - 1) / L;
+    std::vector<MeanState<JAC>> seg(L);
+    for (int l = 0; l < L; l++) {
+        mean_init(seg[l]);
+        const int s0 = std::min(n, l * per), s1 = std::min(n, s0 + per);
+        for (int s = s0; s < s1; s++) {
+            const double *k0 = kn + 7 * s, *k1 = kn + 7 * (s + 1);
+            mean_step<MODEL, JAC, AVG>(seg[l], k0[0], k1[0], ld3(k0 + 1), ld3(k0 + 4), ld3(k1 + 1), ld3(k1 + 4), bw, ba, gk);
+        }
+    }
+    // order-preserving tree (as the shuffle tree in the kernel): stride doubles
+    for (int st = 1; st < L; st *= 2)
+        for (int l = 0; l + st < L; l += 2 * st) mean_combine(seg[l], seg[l + st]);
+    const MeanState<JAC> &s = seg[0];
+    o[0] = s.DT;
+    o[1] = s.alpha.x; o[2] = s.alpha.y; o[3] = s.alpha.z;
+    o[4] = s.beta.x; o[5] = s.beta.y; o[6] = s.beta.z;
+    const Q4 q = rot_2_quat(s.R);
+    o[7] = q.x; o[8] = q.y; o[9] = q.z; o[10] = q.w;
+    put_cm(o + 11, s.R);
+    if (JAC) {
+        put_cm(o + 20, s.Jq); put_cm(o + 29, s.Ja); put_cm(o + 38, s.Jb); put_cm(o + 47, s.Ha); put_cm(o + 56, s.Hb);
+        put_cm(o + 65, s.Oa); put_cm(o + 74, s.Ob);
+    }
+}
+
+template <int MODEL, bool AVG>
+void cov_window(int n, const double *kn, const double *lin, const double *qk, const double *sig, const double *grav, double *o) {
+    typedef CovDims<MODEL> D;
+    const V3 bw = ld3(lin), ba = ld3(lin + 3);
+    V3 gk = mk(0, 0, 0);
+    if (MODEL == 2) gk = mul(quat_2_Rot(ldq(qk)), ld3(grav));
+    const double q4[4] = { sig[0] * sig[0], sig[1] * sig[1], sig[2] * sig[2], sig[3] * sig[3] };
+    std::vector<CovLane<MODEL>> lane(D::NCOL);
+    for (int j = 0; j < D::NCOL; j++) cov_init(lane[j], j);
+    double exch[9][32];
+    for (int s = 0; s < n; s++) {
+        const double *k0 = kn + 7 * s, *k1 = kn + 7 * (s + 1);
+        const SampleRec r = make_sample_rec<MODEL, AVG>(k0[0], k1[0], ld3(k0 + 1), ld3(k0 + 4), ld3(k1 + 1), ld3(k1 + 4), bw, ba);
+        for (int j = 0; j < D::NCOL; j++) cov_begin<MODEL, AVG>(lane[j], r, gk);
+        for (int st = 0; st < 4; st++) {
+            double M[32][9];
+            for (int j = 0; j < D::NCOL; j++) {
+                cov_stage_M(lane[j], st, M[j]);
+                for (int rr = 0; rr < 9; rr++) exch[rr][j] = M[j][rr];
+            }
+            for (int j = 0; j < D::NCOL; j++) {
+                const int er = cov_exch_row(j);
+                cov_stage_finish(lane[j], st, M[j], exch[er < 0 ? 0 : er], j, q4);
+            }
+        }
+        for (int j = 0; j < D::NCOL; j++) cov_end(lane[j]);
+        if (MODEL == 2)
+            for (int b = 0; b < 3; b++) for (int i = 0; i < D::NR; i++) lane[15 + b].P0[i] = lane[b].P0[i];
+    }
+    const CovLane<MODEL> &z = lane[0];
+    o[0] = z.DT;
+    o[1] = z.alpha.x; o[2] = z.alpha.y; o[3] = z.alpha.z;
+    o[4] = z.beta.x; o[5] = z.beta.y; o[6] = z.beta.z;
+    const Q4 q = rot_2_quat(z.R);
+    o[7] = q.x; o[8] = q.y; o[9] = q.z; o[10] = q.w;
+    put_cm(o + 11, z.R);
+    for (int j = 0; j < 15; j++) for (int i = 0; i < 15; i++) o[83 + j * 15 + i] = lane[j].P0[i];
+    if (MODEL == 2) {
+        for (int c = 0; c < 3; c++) {
+            const CovLane<MODEL> &g = lane[D::NPCOL + c], &a = lane[D::NPCOL + 3 + c], &l = lane[D::NPCOL + 6 + c];
+            for (int i = 0; i < 3; i++) {
+                o[20 + c * 3 + i] = -g.P0[0 + i];   // J_q = -D(0:3, 3:6)
+                o[29 + c * 3 + i] = g.P0[12 + i];   // J_a = D(12:15, 3:6)
+                o[38 + c * 3 + i] = g.P0[6 + i];    // J_b = D(6:9, 3:6)
+                o[47 + c * 3 + i] = a.P0[12 + i];   // H_a = D(12:15, 9:12)
+                o[56 + c * 3 + i] = a.P0[6 + i];    // H_b = D(6:9, 9:12)
+                o[65 + c * 3 + i] = l.P0[12 + i];   // O_a = D(12:15, 18:21)
+                o[74 + c * 3 + i] = l.P0[6 + i];    // O_b = D(6:9, 18:21)
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" void hs_mean(int model, int jac, int avg, int L, long W, int n, const double *kn, const double *lin,
+                        const double *qk, const double *grav, double *out) {
+    for (long w = 0; w < W; w++) {
+        const double *k = kn + (size_t)w * (n + 1) * 7, *l = lin + w * 6, *q = qk ? qk + w * 4 : nullptr;
+        double *o = out + w * OUTD;
+#define GO(M, J, A) mean_window<M, J, A>(L, n, k, l, q, grav, o)
+        if (model == 1) { if (jac) { if (avg) GO(1, true, true); else GO(1, true, false); } else { if (avg) GO(1, false, true); else GO(1, false, false); } }
+        else            { if (jac) { if (avg) GO(2, true, true); else GO(2, true, false); } else { if (avg) GO(2, false, true); else GO(2, false, false); } }
+#undef GO
+    }
+}
+extern "C" void hs_cov(int model, int avg, long W, int n, const double *kn, const double *lin, const double *qk,
+                       const double *sig, const double *grav, double *out) {
+    for (long w = 0; w < W; w++) {
+        const double *k = kn + (size_t)w * (n + 1) * 7, *l = lin + w * 6, *q = qk ? qk + w * 4 : nullptr;
+        double *o = out + w * OUTD;
+        if (model == 1) { if (avg) cov_window<1, true>(n, k, l, q, sig, grav, o); else cov_window<1, false>(n, k, l, q, sig, grav, o); }
+        else            { if (avg) cov_window<2, true>(n, k, l, q, sig, grav, o); else cov_window<2, false>(n, k, l, q, sig, grav, o); }
+    }
+}
+// rec: 87 doubles in the order of oracle_py.FACTOR_FIELDS
+extern "C" void hs_factor(int model, long F, const double *rec, const double *xi, const double *xj, double *err,
+                          double *H1, double *H2) {
+    for (long k = 0; k < F; k++) {
+        const double *r = rec + k * 87;
+        FactorMeas f;
+        f.alpha = ld3(r); f.beta = ld3(r + 3); f.q_KtoK1 = ldq(r + 6); f.ba_lin = ld3(r + 10); f.bg_lin = ld3(r + 13);
+        f.J_q = ld_cm(r + 16); f.J_beta = ld_cm(r + 25); f.J_alpha = ld_cm(r + 34); f.H_beta = ld_cm(r + 43); f.H_alpha = ld_cm(r + 52);
+        f.dt = r[61]; f.grav = ld3(r + 62); f.q_K_lin = ldq(r + 65); f.O_beta = ld_cm(r + 69); f.O_alpha = ld_cm(r + 78);
+        NavState a, b;
+        const double *p = xi + k * 16; a.q = ldq(p); a.bg = ld3(p + 4); a.v = ld3(p + 7); a.ba = ld3(p + 10); a.p = ld3(p + 13);
+        p = xj + k * 16; b.q = ldq(p); b.bg = ld3(p + 4); b.v = ld3(p + 7); b.ba = ld3(p + 10); b.p = ld3(p + 13);
+        FactorBlocks o;
+        if (model == 1) factor_eval<1>(f, a, b, o); else factor_eval<2>(f, a, b, o);
+        for (int i = 0; i < 15; i++) err[k * 15 + i] = pick15(o.err, i);
+        for (int c = 0; c < 15; c++) {
+            factor_H1_col(o, f, c, H1 + k * 225 + c * 15);
+            factor_H2_col(o, c, H2 + k * 225 + c * 15);
+        }
+    }
+}
+extern "C" void hs_predict(int model, long F, const double *rec, const double *xi, double *xj) {
+    for (long k = 0; k < F; k++) {
+        const double *r = rec + k * 87, *p = xi + k * 16;
+        NavState a; a.q = ldq(p); a.bg = ld3(p + 4); a.v = ld3(p + 7); a.ba = ld3(p + 10); a.p = ld3(p + 13);
+        NavState o = (model == 1) ? predict_state<1>(a, ld3(r), ld3(r + 3), ldq(r + 6), r[61], ld3(r + 62))
+                                  : predict_state<2>(a, ld3(r), ld3(r + 3), ldq(r + 6), r[61], ld3(r + 62));
+        double *d = xj + k * 16;
+        d[0] = o.q.x; d[1] = o.q.y; d[2] = o.q.z; d[3] = o.q.w;
+        d[4] = o.bg.x; d[5] = o.bg.y; d[6] = o.bg.z; d[7] = o.v.x; d[8] = o.v.y; d[9] = o.v.z;
+        d[10] = o.ba.x; d[11] = o.ba.y; d[12] = o.ba.z; d[13] = o.p.x; d[14] = o.p.y; d[15] = o.p.z;
+    }
+}

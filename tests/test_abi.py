@@ -1,0 +1,57 @@
+"""CPU-only: the C-ABI shared library builds for gfx950, loads, and exports every symbol that
+include/cpi_amd.h declares.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "cpi_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cpi_[a-z_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from cpi_amd import _lib
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 9
+    for s in syms:
+        assert hasattr(lib, s), "libcpi_amd.so does not export %s" % s
+    assert lib.cpi_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from cpi_amd._lib import CpiOutputs, CpiParams
+    assert C.sizeof(CpiParams) == 7 * 8 + 4 * 4
+    assert C.sizeof(CpiOutputs) == 12 * 8
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the context constructor must fail loudly (CPI_ERR_NO_DEVICE), never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cpi_amd import _lib
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    rc = lib.cpi_ctx_create(0, None, C.byref(ctx))
+    assert rc == _lib.CPI_ERR_NO_DEVICE
+    assert b"no HIP device" in lib.cpi_last_error(None)
+    import cpi_amd
+    with pytest.raises(cpi_amd.CpiError):
+        cpi_amd.Engine()
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reference the oracle (test infrastructure)."""
+    pkg = os.path.join(ROOT, "cpi_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_py" not in txt and "liboracle" not in txt and "cpi_oracle" not in txt, f

@@ -1,0 +1,314 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against
+  (1) the golden vectors the compiled reference produced (tests/golden/),
+  (2) the CPU oracle on fresh seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Gates (tests/tol.py): 1e-9 on DT/alpha/beta/q, 1e-6 * sqrt(P_ii P_jj) on the covariance,
+1e-8 on the bias Jacobians, 1e-9 on evaluateError."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cpi_amd import synth
+from tests.tol import TOL_FACTOR, TOL_MEAN, check_pre, cov_rel_err
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(1, 0, 1), (1, 1, 1), (2, 0, 1), (2, 1, 1), (2, 0, 0), (2, 1, 0)]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import cpi_amd
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return cpi_amd.Engine()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle_py as op
+    return op
+
+
+def _dev(a, eng):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+
+
+def _host(out):
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _mode_out(d, m):
+    key = "m%d_avg%d_stj%d__" % m
+    return {k[len(key):]: v for k, v in d.items() if k.startswith(key)}
+
+
+def _run(eng, m, kn, lin, q, want=("mean", "jac", "cov"), lanes=0, **kw):
+    prm = eng.make_params(m[0], m[1], m[2], lanes_per_window=lanes)
+    return _host(eng.preintegrate(_dev(kn, eng), _dev(lin, eng), _dev(q, eng), prm, want=want, **kw))
+
+
+# --------------------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("fname", ["pre_cfg1.npz", "pre_w48.npz"])
+@pytest.mark.parametrize("mode", MODES)
+def test_full_outputs_vs_reference_golden(eng, golden_dir, fname, mode):
+    d = dict(np.load(os.path.join(golden_dir, fname)))
+    out = _run(eng, mode, d["knots"], d["lin"], d["q_k_lin"])
+    check_pre(out, _mode_out(d, mode), v2=(mode[0] == 2), label="%s %s" % (fname, mode))
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize("avg", [0, 1])
+def test_mean_only_vs_reference_golden_all_lane_splits(eng, golden_dir, lanes, avg):
+    d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
+    out = _run(eng, (1, avg, 1), d["knots"], d["lin"], d["q_k_lin"], want=("mean",), lanes=lanes)
+    assert set(out) == {"DT", "alpha", "beta", "q"}
+    check_pre(out, _mode_out(d, (1, avg, 1)), what=("mean",))
+    out = _run(eng, (1, avg, 1), d["knots"], d["lin"], d["q_k_lin"], want=("mean", "jac"), lanes=lanes)
+    check_pre(out, _mode_out(d, (1, avg, 1)), what=("mean", "jac"))
+
+
+def test_mean_only_model2_vs_golden(eng, golden_dir):
+    d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
+    for avg in (0, 1):
+        out = _run(eng, (2, avg, 1), d["knots"], d["lin"], d["q_k_lin"], want=("mean",))
+        check_pre(out, _mode_out(d, (2, avg, 1)), what=("mean",))
+
+
+def test_cov_only_and_jac_only_requests(eng, golden_dir):
+    d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
+    for m in [(1, 0, 1), (2, 0, 1), (2, 0, 0)]:
+        ref = _mode_out(d, m)
+        out = _run(eng, m, d["knots"], d["lin"], d["q_k_lin"], want=("cov",))
+        assert set(out) == {"P"}
+        check_pre(out, ref, what=("cov",))
+        out = _run(eng, m, d["knots"], d["lin"], d["q_k_lin"], want=("jac",))
+        check_pre(out, ref, what=("jac",), v2=(m[0] == 2))
+
+
+# --------------------------------------------------------------------------- vs oracle, seeded
+@pytest.mark.parametrize("mode", MODES)
+def test_vs_oracle_seeded(eng, orc, mode):
+    W = 1500 if mode[0] == 1 else 700
+    kn, lin, q = synth.make_windows(W, 50, seed=777 + 10 * mode[0] + mode[1])
+    kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
+    ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=os.cpu_count() or 1)
+    out = _run(eng, mode, kn, lin, q)
+    check_pre(out, ref, v2=(mode[0] == 2), label=str(mode))
+
+
+def test_window_of_100_samples(eng, orc):
+    kn, lin, q = synth.make_windows(333, 100, seed=5)     # W not a multiple of any group size
+    kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
+    for mode in [(1, 0, 1), (2, 0, 1)]:
+        ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=os.cpu_count() or 1)
+        check_pre(_run(eng, mode, kn, lin, q), ref, v2=(mode[0] == 2))
+
+
+# --------------------------------------------------------------------------- ragged / shared-knot windows
+def test_ragged_windows_cut_from_one_stream(eng, orc):
+    """Windows cut from ONE IMU stream at irregular update times (GraphSolver_IMU.cpp:50-69):
+    first[]/count[] index a shared knot array; lengths 0..73 incl. empty and single-interval windows."""
+    rng = np.random.default_rng(3)
+    lens = np.concatenate([[0, 1, 2, 73, 16, 17, 31, 32, 33, 64], rng.integers(1, 70, 150)]).astype(np.int32)
+    K = int(lens.sum()) + 1
+    kn1, _, _ = synth.make_windows(1, K - 1, seed=11, edge_cases=False)
+    stream = kn1.numpy()[0]                                  # [K,7]
+    first = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    W = len(lens)
+    _, lin, q = synth.make_windows(W, 4, seed=12)
+    lin, q = lin.numpy(), q.numpy()
+    N = int(lens.max())
+    for mode in [(1, 0, 1), (1, 1, 1), (2, 0, 1), (2, 1, 0)]:
+        prm = eng.make_params(*mode)
+        out = _host(eng.preintegrate(_dev(stream, eng), _dev(lin, eng), _dev(q, eng), prm, first=_dev(first, eng),
+                                     count=_dev(lens, eng), N=N))
+        # oracle window by window (zero-length windows: identity state)
+        ref = {k: np.zeros_like(v) for k, v in out.items()}
+        oprm = orc.make_params(*mode)
+        for w in range(W):
+            n = int(lens[w])
+            kn_w = stream[first[w]:first[w] + n + 1][None]
+            r = orc.oracle().run(oprm, kn_w, lin[w:w + 1], q[w:w + 1])
+            for k in ref:
+                ref[k][w] = r[k][0]
+        check_pre(out, ref, v2=(mode[0] == 2), label="ragged %s" % (mode,))
+        assert out["DT"][0] == 0.0 and np.array_equal(out["q"][0], [0, 0, 0, 1]) and np.all(out["P"][0] == 0)
+        # mean-only kernel on the same ragged layout, several lane splits
+        if mode[0] == 1:
+            for lanes in (1, 4, 64):
+                prm = eng.make_params(*mode, lanes_per_window=lanes)
+                o2 = _host(eng.preintegrate(_dev(stream, eng), _dev(lin, eng), _dev(q, eng), prm, want=("mean",),
+                                            first=_dev(first, eng), count=_dev(lens, eng), N=N))
+                check_pre(o2, ref, what=("mean",))
+
+
+def test_empty_batch_and_bad_arguments(eng):
+    import cpi_amd
+    z = torch.zeros((0, 51, 7), dtype=torch.float64, device=eng.device)
+    out = eng.preintegrate(z, torch.zeros((0, 6), dtype=torch.float64, device=eng.device))
+    assert out["alpha"].shape == (0, 3)
+    kn, lin, q = synth.make_windows(4, 10, seed=1, device=eng.device)
+    with pytest.raises(cpi_amd.CpiError):                    # model 2 without q_k_lin
+        eng.preintegrate(kn, lin, None, eng.make_params(2))
+    with pytest.raises(cpi_amd.CpiError):
+        eng.preintegrate(kn, lin, q, eng.make_params(3))
+    with pytest.raises(cpi_amd.CpiError):
+        eng.preintegrate(kn, lin, q, eng.make_params(1, lanes_per_window=3))
+
+
+# --------------------------------------------------------------------------- factors
+@pytest.mark.parametrize("model", [1, 2])
+def test_factor_eval_vs_golden_and_oracle(eng, orc, golden_dir, model):
+    d = dict(np.load(os.path.join(golden_dir, "factor_256.npz")))
+    rec, xi, xj = d["v%d_rec" % model], d["v%d_xi" % model], d["v%d_xj" % model]
+    F = rec.shape[0]
+    cols, o = {}, 0
+    for name, n in orc.FACTOR_FIELDS:
+        cols[name] = rec[:, o:o + n]; o += n
+    meas = dict(DT=cols["deltatime"][:, 0], alpha=cols["alpha"], beta=cols["beta"], q=cols["q_KtoK1"], J_q=cols["J_q"],
+                J_b=cols["J_beta"], J_a=cols["J_alpha"], H_b=cols["H_beta"], H_a=cols["H_alpha"], O_b=cols["O_beta"],
+                O_a=cols["O_alpha"])
+    meas = {k: _dev(v, eng) for k, v in meas.items()}
+    lin = np.concatenate([cols["bg_lin"], cols["ba_lin"]], axis=1)
+    states = np.concatenate([xi, xj], axis=0)
+    idx_i = np.arange(F, dtype=np.int32); idx_j = (np.arange(F) + F).astype(np.int32)
+    out = eng.factor_eval(model, meas, _dev(lin, eng), _dev(cols["q_K_lin"], eng), _dev(states, eng), _dev(idx_i, eng),
+                          _dev(idx_j, eng))
+    out = _host(out)
+    assert np.abs(out["err"] - d["v%d_err" % model]).max() <= TOL_FACTOR
+    assert np.abs(out["H1"] - d["v%d_H1" % model]).max() <= TOL_FACTOR
+    assert np.abs(out["H2"] - d["v%d_H2" % model]).max() <= TOL_FACTOR
+    # error-only call (boost::optional none)
+    o2 = _host(eng.factor_eval(model, meas, _dev(lin, eng), _dev(cols["q_K_lin"], eng), _dev(states, eng),
+                               _dev(idx_i, eng), _dev(idx_j, eng), want_H=False))
+    assert set(o2) == {"err"} and np.array_equal(o2["err"], out["err"])
+    # prediction
+    xjp = eng.predict(model, meas, _dev(xi, eng)); torch.cuda.synchronize()
+    assert np.abs(xjp.cpu().numpy() - orc.oracle().predict(model, rec, xi)).max() <= TOL_FACTOR
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_factor_chain_sweep_vs_oracle(eng, orc, model):
+    """cfg-4 shape at oracle-checkable size: F chained factors over F+1 states (idx NULL -> f, f+1),
+    measurements straight from the GPU preintegration outputs."""
+    F = 3001
+    kn, lin, q = synth.make_windows(F, 50, seed=21, device=eng.device)
+    meas = eng.preintegrate(kn, lin, q, eng.make_params(model))
+    torch.cuda.synchronize()
+    xi, xj = synth.make_states(meas["alpha"], meas["beta"], meas["q"], meas["DT"], lin, model, device=eng.device)
+    states = torch.cat([xi, xj[-1:]], dim=0).contiguous()    # chained: state f+1 is the next factor's state_i
+    out = _host(eng.factor_eval(model, meas, lin, q if model == 2 else None, states))
+    m = _host(meas)
+    rec = orc.factor_records(m, lin.cpu().numpy(), q.cpu().numpy() if model == 2 else None)
+    st = states.cpu().numpy()
+    err, H1, H2 = orc.oracle().factor(model, rec, st[:-1], st[1:])
+    assert np.abs(out["err"] - err).max() <= TOL_FACTOR * max(1.0, np.abs(err).max())
+    assert np.abs(out["H1"] - H1).max() <= TOL_FACTOR * max(1.0, np.abs(H1).max())
+    assert np.abs(out["H2"] - H2).max() <= TOL_FACTOR
+
+
+# --------------------------------------------------------------------------- reference-shaped classes
+def test_reference_shaped_classes_config1(eng, golden_dir):
+    """BASELINE.json configs[0]: 1 window x 100 samples @200 Hz driven exactly like
+    GraphSolver_IMU.cpp:43-75 drives the reference class."""
+    import cpi_amd
+    d = dict(np.load(os.path.join(golden_dir, "pre_cfg1.npz")))
+    kn, lin, q = d["knots"][0], d["lin"][0], d["q_k_lin"][0]
+    for cls, mode in ((cpi_amd.CpiV1, (1, 0, 1)), (cpi_amd.CpiV2, (2, 0, 1))):
+        cpi = cls(0.005, 4e-6, 0.01, 2e-4, engine=eng)
+        cpi.setLinearizationPoints(lin[0:3], lin[3:6], q, [0, 0, 9.8])
+        cpi.imu_avg = False
+        for i in range(kn.shape[0] - 1):
+            cpi.feed_IMU(kn[i, 0], kn[i + 1, 0], kn[i, 1:4], kn[i, 4:7], kn[i + 1, 1:4], kn[i + 1, 4:7])
+        ref = _mode_out(d, mode)
+        assert abs(cpi.DT - ref["DT"][0]) <= TOL_MEAN
+        assert np.abs(cpi.alpha_tau - ref["alpha"][0]).max() <= TOL_MEAN
+        assert np.abs(cpi.beta_tau - ref["beta"][0]).max() <= TOL_MEAN
+        assert np.abs(cpi.q_k2tau - ref["q"][0]).max() <= TOL_MEAN
+        assert np.abs(cpi.J_a - ref["J_a"][0].reshape(3, 3).T).max() <= 1e-8
+        assert cov_rel_err(cpi.P_meas.T.reshape(1, 225), ref["P"]) <= 1e-6
+        # factor built with the reference's argument order (GraphSolver_IMU.cpp:74-75 / 129-130)
+        if mode[0] == 1:
+            fac = cpi_amd.ImuFactorCPIv1(cpi.P_meas, cpi.DT, cpi.grav, cpi.alpha_tau, cpi.beta_tau, cpi.q_k2tau,
+                                         cpi.b_a_lin, cpi.b_w_lin, cpi.J_q, cpi.J_b, cpi.J_a, cpi.H_b, cpi.H_a, engine=eng)
+        else:
+            fac = cpi_amd.ImuFactorCPIv2(cpi.P_meas, cpi.DT, cpi.grav, cpi.alpha_tau, cpi.beta_tau, cpi.q_k2tau,
+                                         cpi.q_k_lin, cpi.b_a_lin, cpi.b_w_lin, cpi.J_q, cpi.J_b, cpi.J_a, cpi.H_b,
+                                         cpi.H_a, cpi.O_b, cpi.O_a, engine=eng)
+        xi = np.concatenate([q, lin[0:3], [0.3, -0.2, 0.1], lin[3:6], [1.0, 2.0, 3.0]])
+        e, H1, H2 = fac.evaluateError(xi, xi)
+        assert e.shape == (15,) and H1.shape == (15, 15) and np.all(np.isfinite(H1))
+        assert np.abs(e[3:6]).max() == 0 and np.abs(e[9:12]).max() == 0
+
+
+# --------------------------------------------------------------------------- full-size properties
+def test_config2_size_composition_property(eng):
+    """BASELINE configs[1] (10k x 50, model-1 mean-only): halves composed == whole,
+    R_AB = R_B R_A, beta = beta_A + R_A^T beta_B, alpha = alpha_A + beta_A DT_B + R_A^T alpha_B."""
+    kn, lin, q = synth.make_windows(10000, 50, seed=31, device=eng.device)
+    prm = eng.make_params(1)
+    whole = eng.preintegrate(kn, lin, q, prm, want=("mean",))
+    A = eng.preintegrate(kn[:, :26].contiguous(), lin, q, prm, want=("mean",))
+    B = eng.preintegrate(kn[:, 25:].contiguous(), lin, q, prm, want=("mean",))
+    torch.cuda.synchronize()
+
+    def R_of(qt):  # quat_2_Rot, batched
+        x, y, z, w = qt[:, 0], qt[:, 1], qt[:, 2], qt[:, 3]
+        v = qt[:, :3]
+        S = torch.zeros((qt.shape[0], 3, 3), dtype=qt.dtype, device=qt.device)
+        S[:, 0, 1], S[:, 0, 2], S[:, 1, 0], S[:, 1, 2], S[:, 2, 0], S[:, 2, 1] = -z, y, z, -x, -y, x
+        return (2 * w * w - 1)[:, None, None] * torch.eye(3, dtype=qt.dtype, device=qt.device) - 2 * w[:, None, None] * S \
+            + 2 * v[:, :, None] * v[:, None, :]
+    RA, RB, RW = R_of(A["q"]), R_of(B["q"]), R_of(whole["q"])
+    assert (torch.bmm(RB, RA) - RW).abs().max().item() < 1e-12
+    beta = A["beta"] + torch.bmm(RA.transpose(1, 2), B["beta"].unsqueeze(-1)).squeeze(-1)
+    alpha = A["alpha"] + A["beta"] * B["DT"][:, None] + torch.bmm(RA.transpose(1, 2), B["alpha"].unsqueeze(-1)).squeeze(-1)
+    assert (beta - whole["beta"]).abs().max().item() < 1e-12
+    assert (alpha - whole["alpha"]).abs().max().item() < 1e-12
+    assert (A["DT"] + B["DT"] - whole["DT"]).abs().max().item() < 1e-13
+    # every lane split gives the same answer to round-off; launches are deterministic
+    ref = whole
+    for lanes in (1, 8, 64):
+        o = eng.preintegrate(kn, lin, q, eng.make_params(1, lanes_per_window=lanes), want=("mean",))
+        assert (o["alpha"] - ref["alpha"]).abs().max().item() < 1e-12
+        assert (o["q"] - ref["q"]).abs().max().item() < 1e-13
+    again = eng.preintegrate(kn, lin, q, prm, want=("mean",))
+    for k in ref:
+        assert torch.equal(again[k], ref[k])
+
+
+def test_config3_size_structure_properties(eng):
+    """BASELINE configs[2] (100k x 50, model 2, covariance + bias Jacobians): structural invariants of
+    the reference (P symmetric PSD, theta/b_a and b_w/b_a blocks exactly zero, b_w and b_a blocks
+    sigma^2 * DT * I), agreement of the covariance kernel's means with the mean kernel, determinism."""
+    W = 100000
+    kn, lin, q = synth.make_windows(W, 50, seed=41, device=eng.device)
+    prm = eng.make_params(2)
+    out = eng.preintegrate(kn, lin, q, prm)
+    m = eng.preintegrate(kn, lin, q, prm, want=("mean",))
+    torch.cuda.synchronize()
+    for k in ("DT", "alpha", "beta", "q"):
+        assert (out[k] - m[k]).abs().max().item() < 1e-12, k
+    P = out["P"].reshape(W, 15, 15)
+    assert torch.equal(P, P.transpose(1, 2))
+    assert P[:, 0:3, 9:12].abs().max().item() == 0.0 and P[:, 3:6, 9:12].abs().max().item() == 0.0
+    eye = torch.eye(3, dtype=torch.float64, device=eng.device)
+    DT = out["DT"][:, None, None]
+    assert (P[:, 3:6, 3:6] - (4e-6) ** 2 * DT * eye).abs().max().item() < 1e-24
+    assert (P[:, 9:12, 9:12] - (2e-4) ** 2 * DT * eye).abs().max().item() < 1e-20
+    ev = torch.linalg.eigvalsh(P[:2000])
+    assert ev.min().item() > -1e-18
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    # H_b = d beta / d b_a is -int R^T: its scale is DT; J_q ~ DT
+    assert (out["H_b"].abs().max(dim=1).values <= out["DT"] * 1.0001 + 1e-12).all()
+    again = eng.preintegrate(kn, lin, q, prm)
+    torch.cuda.synchronize()
+    for k in out:
+        assert torch.equal(again[k], out[k]), k
+    # model 1 on the same windows: identical rotation, covariance of the same magnitude
+    o1 = eng.preintegrate(kn, lin, q, eng.make_params(1), want=("mean", "cov"))
+    assert (o1["q"] - out["q"]).abs().max().item() < 1e-12

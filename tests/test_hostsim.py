@@ -1,0 +1,53 @@
+"""CPU-only: the kernels' arithmetic (cpi_amd/csrc/cpi_math.hpp compiled for the host, driven
+lane-by-lane exactly as the HIP kernels drive it) against the golden vectors from the compiled
+reference.  This validates the kernel DESIGN where no GPU exists: the order-preserving segment
+composition of the mean kernel (any lanes-per-window L), the column-lane covariance recursion with
+its transpose exchange, the state-transition columns of model 2 and the factor blocks.
+The GPU tests (-m gpu) then validate the actual HIP launch path through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as op
+from tests import hostsim_py as hs
+from tests.tol import check_pre
+
+
+def _gold(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _mode_out(d, m):
+    key = "m%d_avg%d_stj%d__" % m
+    return {k[len(key):]: v for k, v in d.items() if k.startswith(key)}
+
+
+@pytest.mark.parametrize("fname", ["pre_cfg1.npz", "pre_w48.npz"])
+@pytest.mark.parametrize("model,avg,jac,L", [(1, 0, 0, 1), (1, 0, 0, 16), (1, 1, 0, 64), (1, 0, 1, 1), (1, 0, 1, 8),
+                                              (1, 1, 1, 32), (2, 0, 0, 1), (2, 1, 0, 1), (2, 0, 1, 1), (2, 1, 1, 1)])
+def test_mean_kernel_math(golden_dir, fname, model, avg, jac, L):
+    d = _gold(golden_dir, fname)
+    out = op.split_out(hs.mean(model, jac, avg, L, d["knots"], d["lin"], d["q_k_lin"]))
+    ref = _mode_out(d, (model, avg, 0 if (model == 2 and jac) else 1))
+    check_pre(out, ref, what=("mean", "jac") if jac else ("mean",), v2=(model == 2))
+
+
+@pytest.mark.parametrize("fname", ["pre_cfg1.npz", "pre_w48.npz"])
+@pytest.mark.parametrize("model,avg", [(1, 0), (1, 1), (2, 0), (2, 1)])
+def test_cov_kernel_math(golden_dir, fname, model, avg):
+    d = _gold(golden_dir, fname)
+    out = op.split_out(hs.cov(model, avg, d["knots"], d["lin"], d["q_k_lin"]))
+    ref = _mode_out(d, (model, avg, 1))
+    check_pre(out, ref, what=("mean", "cov", "jac") if model == 2 else ("mean", "cov"), v2=(model == 2))
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_factor_kernel_math(golden_dir, model):
+    d = _gold(golden_dir, "factor_256.npz")
+    err, H1, H2 = hs.factor(model, d["v%d_rec" % model], d["v%d_xi" % model], d["v%d_xj" % model])
+    assert np.abs(err - d["v%d_err" % model]).max() < 1e-12
+    assert np.abs(H1 - d["v%d_H1" % model]).max() < 1e-12
+    assert np.abs(H2 - d["v%d_H2" % model]).max() < 1e-12
+    xj = hs.predict(model, d["v%d_rec" % model], d["v%d_xi" % model])
+    assert np.abs(xj - op.oracle().predict(model, d["v%d_rec" % model], d["v%d_xi" % model])).max() < 1e-12
