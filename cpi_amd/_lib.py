@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpi_amd.so")
+LIB_PATH = os.environ.get("CPI_AMD_LIB") or os.path.join(_HERE, "libcpi_amd.so")  # env override: kernel-variant A/B runs
 
 CPI_OK, CPI_ERR_INVALID, CPI_ERR_HIP, CPI_ERR_NO_DEVICE = 0, 1, 2, 3
 OUT_FIELDS = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9),

@@ -1,0 +1,204 @@
+// cpi_host.hpp -- C++ host facade above the C-ABI (include/cpi_amd.h), shaped like the reference's
+// classes so caller code written like GraphSolver_IMU.cpp:43-75 / 97-130 keeps its structure:
+//
+//   cpi_host::CpiV1 cpi(sigma_g, sigma_wg, sigma_a, sigma_wa);          // CpiV1.h:55
+//   cpi.setLinearizationPoints(bg_K, ba_K, q_K, gravity);               // CpiBase.h:73
+//   while (...) cpi.feed_IMU(t0, t1, w0, a0, w1, a1);                   // CpiBase.h:86
+//   use cpi.DT, cpi.alpha_tau, cpi.beta_tau, cpi.q_k2tau, cpi.J_q ... cpi.P_meas   // CpiBase.h:99-124
+//
+// Differences forced by the device boundary: feed_IMU() only records the interval; the recursion
+// runs on the GPU when finalize() is called (or through CpiBatch, which flushes many windows in one
+// launch -- the intended use).  Matrices are plain column-major arrays (Eigen::Map them if needed).
+// Header-only; link with -lcpi_amd.  No CPU fallback: errors throw std::runtime_error.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/cpi_amd.h"
+
+namespace cpi_host {
+
+typedef std::array<double, 3> Vec3;
+typedef std::array<double, 4> Vec4;
+typedef std::array<double, 9> Mat3;      // column-major
+typedef std::array<double, 225> Mat15;   // column-major
+
+class Context {
+public:
+    explicit Context(int device = -1, void *stream = nullptr) {
+        if (cpi_ctx_create(device, stream, &ctx_) != CPI_OK) throw std::runtime_error(cpi_last_error(nullptr));
+    }
+    ~Context() { cpi_ctx_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    cpi_ctx *get() const { return ctx_; }
+    void check(int rc) const { if (rc != CPI_OK) throw std::runtime_error(cpi_last_error(ctx_)); }
+private:
+    cpi_ctx *ctx_ = nullptr;
+};
+
+// Results of one window: the public members of CpiBase / CpiV2.
+struct CpiResult {
+    double DT = 0;
+    Vec3 alpha_tau{}, beta_tau{};
+    Vec4 q_k2tau{{0, 0, 0, 1}};
+    Mat3 J_q{}, J_a{}, J_b{}, H_a{}, H_b{}, O_a{}, O_b{};
+    Mat15 P_meas{};
+};
+
+class CpiBase : public CpiResult {
+public:
+    CpiBase(int model, double sigma_w, double sigma_wb, double sigma_a, double sigma_ab, bool imu_avg_ = false)
+        : imu_avg(imu_avg_), model_(model) { sig_[0] = sigma_w; sig_[1] = sigma_wb; sig_[2] = sigma_a; sig_[3] = sigma_ab; }
+    void setLinearizationPoints(const Vec3 &b_w_lin_, const Vec3 &b_a_lin_, const Vec4 &q_k_lin_ = Vec4{{0, 0, 0, 0}},
+                                const Vec3 &grav_ = Vec3{{0, 0, 0}}) {
+        b_w_lin = b_w_lin_; b_a_lin = b_a_lin_; q_k_lin = q_k_lin_; grav = grav_;
+    }
+    // Records interval [t_0, t_1] with readings (w_m_0, a_m_0) at t_0 and (w_m_1, a_m_1) at t_1.
+    void feed_IMU(double t_0, double t_1, const Vec3 &w_m_0, const Vec3 &a_m_0, const Vec3 &w_m_1 = Vec3{{0, 0, 0}},
+                  const Vec3 &a_m_1 = Vec3{{0, 0, 0}}) {
+        const size_t n = knots_.size() / 7;
+        bool chained = false;
+        if (n) {
+            const double *k = &knots_[(n - 1) * 7];
+            chained = k[0] == t_0 && k[1] == w_m_0[0] && k[2] == w_m_0[1] && k[3] == w_m_0[2] && k[4] == a_m_0[0] &&
+                      k[5] == a_m_0[1] && k[6] == a_m_0[2];
+        }
+        if (!chained) {
+            // The reference's feed_IMU only ever uses t_1 - t_0, so intervals need not chain.  A knot whose
+            // time is NaN is a separator: both intervals touching it have a NaN dt and are skipped by the kernels.
+            if (n) push(std::numeric_limits<double>::quiet_NaN(), Vec3{{0, 0, 0}}, Vec3{{0, 0, 0}});
+            push(t_0, w_m_0, a_m_0);
+        }
+        push(t_1, w_m_1, a_m_1);
+    }
+    // Runs this single window on the GPU and fills the result members.
+    void finalize(const Context &ctx) {
+        cpi_params p = params();
+        const double lin[6] = { b_w_lin[0], b_w_lin[1], b_w_lin[2], b_a_lin[0], b_a_lin[1], b_a_lin[2] };
+        cpi_outputs o = outputs_of(*this);
+        const int32_t n = knots_.empty() ? 0 : (int32_t)(knots_.size() / 7 - 1);
+        static const double zero_knot[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        ctx.check(cpi_preintegrate_batch_host(ctx.get(), &p, 1, n, knots_.empty() ? zero_knot : knots_.data(), nullptr, nullptr,
+                                              n + 1, lin, q_k_lin.data(), &o));
+    }
+    cpi_params params() const {
+        cpi_params p{};
+        p.sigma_w = sig_[0]; p.sigma_wb = sig_[1]; p.sigma_a = sig_[2]; p.sigma_ab = sig_[3];
+        for (int i = 0; i < 3; i++) p.grav[i] = grav[i];
+        p.model = model_; p.imu_avg = imu_avg ? 1 : 0;
+        p.state_transition_jacobians = state_transition_jacobians ? 1 : 0;
+        p.lanes_per_window = 0;
+        return p;
+    }
+    static cpi_outputs outputs_of(CpiResult &r) {
+        cpi_outputs o{};
+        o.DT = &r.DT; o.alpha = r.alpha_tau.data(); o.beta = r.beta_tau.data(); o.q = r.q_k2tau.data();
+        o.J_q = r.J_q.data(); o.J_a = r.J_a.data(); o.J_b = r.J_b.data(); o.H_a = r.H_a.data(); o.H_b = r.H_b.data();
+        o.O_a = r.O_a.data(); o.O_b = r.O_b.data(); o.P = r.P_meas.data();
+        return o;
+    }
+    const std::vector<double> &knots() const { return knots_; }
+    int model() const { return model_; }
+
+    bool imu_avg = false;
+    bool state_transition_jacobians = true;  // CpiV2.h:58
+    Vec3 b_w_lin{}, b_a_lin{};
+    Vec4 q_k_lin{};
+    Vec3 grav{};
+
+private:
+    void push(double t, const Vec3 &w, const Vec3 &a) {
+        knots_.push_back(t);
+        for (int i = 0; i < 3; i++) knots_.push_back(w[i]);
+        for (int i = 0; i < 3; i++) knots_.push_back(a[i]);
+    }
+    int model_;
+    double sig_[4];
+    std::vector<double> knots_;
+};
+
+class CpiV1 : public CpiBase {
+public:
+    CpiV1(double sigma_w, double sigma_wb, double sigma_a, double sigma_ab, bool imu_avg_ = false)
+        : CpiBase(CPI_MODEL_V1, sigma_w, sigma_wb, sigma_a, sigma_ab, imu_avg_) {}
+};
+class CpiV2 : public CpiBase {
+public:
+    CpiV2(double sigma_w, double sigma_wb, double sigma_a, double sigma_ab, bool imu_avg_ = false)
+        : CpiBase(CPI_MODEL_V2, sigma_w, sigma_wb, sigma_a, sigma_ab, imu_avg_) {}
+};
+
+// Collects many recorded windows (same model / flags / gravity) and runs them in ONE launch.
+class CpiBatch {
+public:
+    void add(CpiBase *w) { win_.push_back(w); }
+    void flush(const Context &ctx) {
+        if (win_.empty()) return;
+        const int64_t W = (int64_t)win_.size();
+        std::vector<double> knots, lin(W * 6), qk(W * 4);
+        std::vector<int64_t> first(W);
+        std::vector<int32_t> count(W);
+        int32_t N = 0;
+        for (int64_t w = 0; w < W; w++) {
+            const std::vector<double> &k = win_[w]->knots();
+            first[w] = (int64_t)(knots.size() / 7);
+            count[w] = k.empty() ? 0 : (int32_t)(k.size() / 7 - 1);
+            if (count[w] > N) N = count[w];
+            if (k.empty()) knots.insert(knots.end(), 7, 0.0); else knots.insert(knots.end(), k.begin(), k.end());
+            for (int i = 0; i < 3; i++) { lin[w * 6 + i] = win_[w]->b_w_lin[i]; lin[w * 6 + 3 + i] = win_[w]->b_a_lin[i]; }
+            for (int i = 0; i < 4; i++) qk[w * 4 + i] = win_[w]->q_k_lin[i];
+        }
+        cpi_params p = win_[0]->params();
+        std::vector<double> DT(W), al(W * 3), be(W * 3), q(W * 4), Jq(W * 9), Ja(W * 9), Jb(W * 9), Ha(W * 9), Hb(W * 9),
+            Oa(W * 9), Ob(W * 9), P(W * 225);
+        cpi_outputs o{ DT.data(), al.data(), be.data(), q.data(), Jq.data(), Ja.data(), Jb.data(), Ha.data(), Hb.data(),
+                       Oa.data(), Ob.data(), P.data() };
+        ctx.check(cpi_preintegrate_batch_host(ctx.get(), &p, W, N, knots.data(), first.data(), count.data(),
+                                              (int64_t)(knots.size() / 7), lin.data(), qk.data(), &o));
+        for (int64_t w = 0; w < W; w++) {
+            CpiResult &r = *win_[w];
+            r.DT = DT[w];
+            for (int i = 0; i < 3; i++) { r.alpha_tau[i] = al[w * 3 + i]; r.beta_tau[i] = be[w * 3 + i]; }
+            for (int i = 0; i < 4; i++) r.q_k2tau[i] = q[w * 4 + i];
+            for (int i = 0; i < 9; i++) {
+                r.J_q[i] = Jq[w * 9 + i]; r.J_a[i] = Ja[w * 9 + i]; r.J_b[i] = Jb[w * 9 + i]; r.H_a[i] = Ha[w * 9 + i];
+                r.H_b[i] = Hb[w * 9 + i]; r.O_a[i] = Oa[w * 9 + i]; r.O_b[i] = Ob[w * 9 + i];
+            }
+            for (int i = 0; i < 225; i++) r.P_meas[i] = P[w * 225 + i];
+        }
+        win_.clear();
+    }
+private:
+    std::vector<CpiBase *> win_;
+};
+
+// evaluateError-shaped evaluator (ImuFactorCPIv1.h:139 / ImuFactorCPIv2.h:151).  state = 16 doubles
+// [q(4) bg(3) v(3) ba(3) p(3)]; error[15]; H1/H2 column-major 15x15, may be nullptr.
+class ImuFactorCPI {
+public:
+    // built straight from a finished preintegrator, with the field->ctor mapping of GraphSolver_IMU.cpp:74-75,129-130
+    explicit ImuFactorCPI(const CpiBase &cpi) : model_(cpi.model()), m_(cpi), grav_(cpi.grav), qk_(cpi.q_k_lin) {
+        for (int i = 0; i < 3; i++) { lin_[i] = cpi.b_w_lin[i]; lin_[3 + i] = cpi.b_a_lin[i]; }
+    }
+    void evaluateError(const Context &ctx, const double *state_i, const double *state_j, double *error, double *H1 = nullptr,
+                       double *H2 = nullptr) {
+        double states[32];
+        for (int i = 0; i < 16; i++) { states[i] = state_i[i]; states[16 + i] = state_j[i]; }
+        cpi_outputs o = CpiBase::outputs_of(m_);
+        ctx.check(cpi_factor_eval_batch_host(ctx.get(), model_, grav_.data(), 1, &o, lin_, qk_.data(), states, 2, nullptr, nullptr,
+                                             error, H1, H2));
+    }
+private:
+    int model_;
+    CpiResult m_;
+    Vec3 grav_;
+    Vec4 qk_;
+    double lin_[6];
+};
+
+}  // namespace cpi_host

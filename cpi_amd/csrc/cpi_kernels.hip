@@ -25,6 +25,13 @@
 
 using namespace cpi;
 
+#ifndef CPI_MEAN_PREFETCH
+#define CPI_MEAN_PREFETCH 1
+#endif
+#ifndef CPI_MEAN_UNROLL
+#define CPI_MEAN_UNROLL 0
+#endif
+
 // ============================================================================================
 // device helpers
 // ============================================================================================
@@ -97,15 +104,19 @@ struct PreArgs {
 // ============================================================================================
 // mean (+ analytic Jacobian) kernel
 // ============================================================================================
+#ifndef CPI_MEAN_WPS
+#define CPI_MEAN_WPS 1
+#endif
 template <int MODEL, bool JAC, bool AVG, int L>
-__global__ __launch_bounds__(64) void cpi_mean_kernel(PreArgs A) {
+__global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     constexpr int WPB = 64 / L;       // windows per wavefront
-    constexpr int C = 4;              // knots staged per lane per chunk
+    // knots staged per lane per chunk: measured on MI355X -- 1 is best when a wave is latency-bound (few
+    // intervals per lane, small batches), 2 when the launch is throughput-bound (one window per lane)
+    constexpr int C = (L == 1 && !JAC) ? 2 : 1;
     constexpr int SEGD = 7 * C;       // doubles per lane per chunk
     constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
     __shared__ double tile[64 * PITCH];
-    __shared__ long long segbase[64];
-    __shared__ int seglen[64];
+    __shared__ unsigned long long segdesc[64];  // per lane-segment: (first double of the segment << 16) | intervals
 
     const int lane = threadIdx.x;
     const int l = lane % L;
@@ -119,8 +130,7 @@ __global__ __launch_bounds__(64) void cpi_mean_kernel(PreArgs A) {
     const int len = s1 - s0;
     const int maxlen = wave_max(len);
 
-    segbase[lane] = (k0 + s0) * 7;
-    seglen[lane] = len;
+    segdesc[lane] = ((unsigned long long)((k0 + s0) * 7) << 16) | (unsigned long long)(unsigned)len;
 
     const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
     V3 gk = mk(0, 0, 0);
@@ -130,39 +140,83 @@ __global__ __launch_bounds__(64) void cpi_mean_kernel(PreArgs A) {
     {
         const double *kb = A.knots + (k0 + s0) * 7;
 #pragma unroll
-        for (int i = 0; i < 7; i++) pk[i] = (len > 0) ? kb[i] : 0.0;
+        for (int i = 0; i < 7; i++) pk[i] = kb[i];  // knot s0 always exists (a window owns count+1 knots)
     }
     MeanState<JAC> st;
     mean_init(st);
     __syncthreads();
 
-    const int nchunks = (maxlen + C - 1) / C;
-    for (int it = 0; it < nchunks; ++it) {
-        // cooperative, coalesced copy of 64 segments x C knots: element idx of the tile belongs to
-        // segment idx / SEGD; consecutive lanes read consecutive doubles of (mostly) one segment.
-#pragma unroll 4
+    // Tile element idx = e*64 + lane belongs to segment idx / SEGD at offset idx % SEGD, so consecutive
+    // lanes read consecutive doubles of (mostly) one segment: coalesced.  Everything that does not depend
+    // on the chunk index is hoisted: per staged element a lane keeps one pointer and the last chunk for
+    // which its knot exists (later chunks re-read that knot; the value is never consumed), so the hot loop
+    // spends ~3 VALU per element on addressing and no load is ever out of bounds.
+    double stage[SEGD];
+    const double *sptr[SEGD];
+    int smax[SEGD];
+    int tofs[SEGD];
+    {
+        int seg = lane / SEGD, off = lane - seg * SEGD;
+#pragma unroll
         for (int e = 0; e < SEGD; ++e) {
-            const int idx = e * 64 + lane;
-            const int seg = idx / SEGD, off = idx - seg * SEGD;
-            const int kk = it * C + 1 + off / 7;  // knot index relative to the segment's first knot
-            double v = 0.0;
-            if (kk <= seglen[seg]) v = A.knots[segbase[seg] + (long long)(it * C + 1) * 7 + off];
-            tile[seg * PITCH + off] = v;
+            const unsigned long long d = segdesc[seg];
+            const long long base = (long long)(d >> 16);
+            const int slen = (int)(d & 0xffffULL);
+            const int kn = off / 7;                       // knot (1 + kn) of chunk 0
+            const bool ok = slen >= 1 + kn;
+            sptr[e] = A.knots + base + (ok ? 7 + off : off - 7 * kn);
+            smax[e] = ok ? (slen - 1 - kn) / C : 0;       // never-valid elements keep re-reading knot 0
+            tofs[e] = seg * PITCH + off;
+            off += 64 % SEGD; seg += 64 / SEGD;   // idx advances by 64 per staged element
+            if (off >= SEGD) { off -= SEGD; seg += 1; }
         }
+    }
+    // Dense layout, not one of the last waves: reading a few knots past a short segment's end stays inside
+    // the knot array, so the running pointers advance unconditionally (1 VALU per element per chunk).
+    const bool safe_overread = (A.first == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W);
+    auto issue = [&](int it) {
+        if (safe_overread) {
+#pragma unroll
+            for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += SEGD; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += (it < smax[e]) ? SEGD : 0; }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int e = 0; e < SEGD; ++e) tile[tofs[e]] = stage[e];
+    };
+
+    const int nchunks = (maxlen + C - 1) / C;
+#if CPI_MEAN_PREFETCH
+    if (nchunks > 0) issue(0);
+#endif
+    for (int it = 0; it < nchunks; ++it) {
+#if CPI_MEAN_PREFETCH
+        commit();
         __syncthreads();
+        if (it + 1 < nchunks) issue(it + 1);   // next chunk's HBM round trip overlaps this chunk's FP64 work
+#else
+        issue(it);
+        commit();
+        __syncthreads();
+#endif
+#if CPI_MEAN_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int c = 0; c < C; ++c) {
             const int s = it * C + c;
-            if (s < len) {
-                const double *nk = &tile[lane * PITCH + c * 7];
-                double q[7];
+            const double *nk = &tile[lane * PITCH + c * 7];
+            double q[7];
 #pragma unroll
-                for (int i = 0; i < 7; i++) q[i] = nk[i];
-                mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
-                                           mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk);
+            for (int i = 0; i < 7; i++) q[i] = nk[i];
+            mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                       mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, s < len);
 #pragma unroll
-                for (int i = 0; i < 7; i++) pk[i] = q[i];
-            }
+            for (int i = 0; i < 7; i++) pk[i] = q[i];
         }
         __syncthreads();
     }
@@ -488,9 +542,13 @@ extern "C" int cpi_ctx_synchronize(cpi_ctx *ctx) {
 static int pick_lanes(const cpi_params *prm, int64_t W, int N) {
     if (prm->model == CPI_MODEL_V2) return 1;  // model 2 means depend on the running rotation: sequential per window
     int L = prm->lanes_per_window;
-    if (L <= 0) {  // enough wavefronts to fill 256 CUs x 4 SIMDs a few times over
+    if (L <= 0) {
+        // Tuned on MI355X (1024 SIMDs): a launch wants at least ~1 wavefront per SIMD; beyond that, more lanes
+        // per window only adds composition work.  Small batches are latency-bound per wavefront and prefer
+        // fewer, longer segments than mid-size ones.
+        const int64_t target = (W < 50000) ? 80000 : 160000;
         L = 1;
-        while (L < 64 && W * L < (int64_t)262144 && 2 * L <= N) L *= 2;
+        while (L < 64 && W * L < target && 2 * L <= N) L *= 2;
     }
     return L;
 }
@@ -535,6 +593,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     if (prm->model == CPI_MODEL_V2 && !q_k_lin)
         return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: model 2 needs q_k_lin");
     if (W > ((int64_t)1 << 31) * 4) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: W too large for one launch");
+    if (N > 65535) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: N (intervals per window) must be <= 65535");
     int L = prm->lanes_per_window;
     if (L != 0 && (L < 1 || L > 64 || (L & (L - 1)))) return fail(ctx, CPI_ERR_INVALID, "lanes_per_window must be 0 or a power of two <= 64");
 

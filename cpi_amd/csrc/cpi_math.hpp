@@ -135,36 +135,94 @@ CPI_HD M3 poly_wx(V3 w, double c0, double c1, double c2) {
 }
 
 // ------------------------------------------------------------------------------------------
-// sin/cos.  IMU angles |w|*dt are tiny (<= a few 0.1 rad even over dropped samples), so a
-// range-reduction-free Taylor/Horner kernel (truncation < 3e-19 on |x| <= 1) replaces the
-// general-purpose libm path; larger arguments take the library route.
-CPI_HD void sincos_fast(double x, double &s, double &c) {
-    if (fabs(x) <= 1.0) {
-        const double z = x * x;
-        double ps = -1.0 / 121645100408832000.0;              // x^19
-        ps = fma(ps, z, 1.0 / 355687428096000.0);            // x^17
-        ps = fma(ps, z, -1.0 / 1307674368000.0);             // x^15
-        ps = fma(ps, z, 1.0 / 6227020800.0);                 // x^13
-        ps = fma(ps, z, -1.0 / 39916800.0);                  // x^11
-        ps = fma(ps, z, 1.0 / 362880.0);                     // x^9
-        ps = fma(ps, z, -1.0 / 5040.0);                      // x^7
-        ps = fma(ps, z, 1.0 / 120.0);                        // x^5
-        ps = fma(ps, z, -1.0 / 6.0);                         // x^3
-        s = fma(x * z, ps, x);
-        double pc = -1.0 / 6402373705728000.0;                // x^18
-        pc = fma(pc, z, 1.0 / 20922789888000.0);             // x^16
-        pc = fma(pc, z, -1.0 / 87178291200.0);               // x^14
-        pc = fma(pc, z, 1.0 / 479001600.0);                  // x^12
-        pc = fma(pc, z, -1.0 / 3628800.0);                   // x^10
-        pc = fma(pc, z, 1.0 / 40320.0);                      // x^8
-        pc = fma(pc, z, -1.0 / 720.0);                       // x^6
-        pc = fma(pc, z, 1.0 / 24.0);                         // x^4
-        pc = fma(pc, z, -0.5);                               // x^2
-        c = fma(z, pc, 1.0);
+// sin/cos.  IMU angles |w|*dt are tiny (<= a few 0.1 rad even over dropped samples), so the common
+// path is a range-reduction-free Taylor/Horner kernel (truncation < 3e-19 on |x| <= 1).  Larger
+// arguments are reduced by a three-term Cody-Waite subtraction of k*pi/2 (exact for |k| < 2^20, i.e.
+// |x| < 1.6e6 rad per IMU interval -- far beyond anything physical) onto the same polynomials; there
+// is deliberately no Payne-Hanek path: it would double the kernel's register footprint for inputs
+// that cannot occur.
+// p*z + C as ONE v_fma_f64 on the device.  (Left to itself hipcc turns a Horner step whose addend is a
+// loop-invariant constant into v_mov_b64 + v_fmac_f64, i.e. two issue slots per coefficient.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CPI_HORNER(p, z, C)                                                          \
+    do {                                                                             \
+        double c__ = (C);                                                            \
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(z), "v"(c__));        \
+    } while (0)
+#else
+#define CPI_HORNER(p, z, C) p = fma(p, z, (C))
+#endif
+// Taylor/Horner kernels.  SHORT (|x| <= 0.25, truncation < 3e-18 relative) is what every physical IMU
+// interval needs; LONG covers |x| <= 1.
+template <bool LONG>
+CPI_HD void sincos_poly(double x, double &s, double &c) {
+    const double z = x * x;
+    double ps, pc;
+    if (LONG) {
+        ps = -1.0 / 121645100408832000.0;                 // x^19
+        CPI_HORNER(ps, z, 1.0 / 355687428096000.0);      // x^17
+        CPI_HORNER(ps, z, -1.0 / 1307674368000.0);       // x^15
+        CPI_HORNER(ps, z, 1.0 / 6227020800.0);           // x^13
+        CPI_HORNER(ps, z, -1.0 / 39916800.0);            // x^11
+        pc = -1.0 / 6402373705728000.0;                   // x^18
+        CPI_HORNER(pc, z, 1.0 / 20922789888000.0);       // x^16
+        CPI_HORNER(pc, z, -1.0 / 87178291200.0);         // x^14
+        CPI_HORNER(pc, z, 1.0 / 479001600.0);            // x^12
     } else {
-        s = sin(x);
-        c = cos(x);
+        ps = 1.0 / 6227020800.0;                          // x^13
+        CPI_HORNER(ps, z, -1.0 / 39916800.0);            // x^11
+        pc = -1.0 / 87178291200.0;                        // x^14
+        CPI_HORNER(pc, z, 1.0 / 479001600.0);            // x^12
     }
+    CPI_HORNER(ps, z, 1.0 / 362880.0);                   // x^9
+    CPI_HORNER(ps, z, -1.0 / 5040.0);                    // x^7
+    CPI_HORNER(ps, z, 1.0 / 120.0);                      // x^5
+    CPI_HORNER(ps, z, -1.0 / 6.0);                       // x^3
+    s = fma(x * z, ps, x);
+    CPI_HORNER(pc, z, -1.0 / 3628800.0);                 // x^10
+    CPI_HORNER(pc, z, 1.0 / 40320.0);                    // x^8
+    CPI_HORNER(pc, z, -1.0 / 720.0);                     // x^6
+    CPI_HORNER(pc, z, 1.0 / 24.0);                       // x^4
+    CPI_HORNER(pc, z, -0.5);                             // x^2
+    c = fma(z, pc, 1.0);
+}
+CPI_HD void sincos_fast(double x, double &s, double &c) {
+    const double ax = fabs(x);
+    if (ax <= 0.25) { sincos_poly<false>(x, s, c); return; }   // every lane of a wave, for any physical input
+    if (ax <= 1.0) { sincos_poly<true>(x, s, c); return; }
+    // pi/2 split into three parts with trailing zero bits (the classic fdlibm constants)
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    r = fma(-k, 2.02226624879595063154e-21, r);
+    double sr, cr;
+    sincos_poly<true>(r, sr, cr);
+    const int q = ((int)(long long)k) & 3;
+    s = (q == 0) ? sr : ((q == 1) ? cr : ((q == 2) ? -sr : -cr));
+    c = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
+}
+// |w| and 1/|w| from ONE reciprocal-square-root seed + Newton (device); sqrt + divide on the host.
+// m2 == 0 (or denormal) returns mag = 0, im = 0: such a rate is far below the Taylor threshold, whose
+// branch never uses im.
+CPI_HD void mag_and_inverse(double m2, double &mag, double &im) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool tiny = !(m2 > 1e-280);
+    const double a = tiny ? 1.0 : m2;
+    double y = __builtin_amdgcn_rsq(a);          // ~2^-26 relative
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);          // ~2^-50
+    double d = fma(-g, g, a);
+    g = fma(d, h, g);                            // sqrt(a), <= 1 ulp
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);                            // 1/(2 sqrt(a)), <= 1 ulp
+    mag = tiny ? 0.0 : g;
+    im = tiny ? 0.0 : 2.0 * h;
+#else
+    mag = sqrt(m2);
+    im = (m2 > 1e-280) ? 1.0 / mag : 0.0;
+    if (!(m2 > 1e-280)) mag = 0.0;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -232,7 +290,7 @@ CPI_HD M3 Exp_so3(V3 w) {  // quat_ops.h:145-162
 // ------------------------------------------------------------------------------------------
 // Per-interval closed-form coefficients (CpiV1.h:97-142, identical in CpiV2.h:118-176).
 struct StepCoef {
-    double dt, mag, wdt, sn, cs;
+    double dt, mag, im, wdt, sn, cs;
     double s1, s2;          // R_tau2tau1 = I - s1 [w]x + s2 [w]x^2
     double f1, f2, f3, f4;  // alpha_arg = dt^2/2 I + f1 [w]x + f2 [w]x^2 ; Beta_arg = dt I + f3 [w]x + f4 [w]x^2
     bool small;
@@ -240,25 +298,23 @@ struct StepCoef {
 CPI_HD StepCoef step_coef(V3 w, double dt) {
     StepCoef k;
     k.dt = dt;
-    k.mag = sqrt(dot(w, w));
+    mag_and_inverse(dot(w, w), k.mag, k.im);
+    const double im = k.im;
     k.wdt = k.mag * dt;
     k.small = (k.mag < 0.008726646);  // threshold on the rate, CpiV1.h:101
     sincos_fast(k.wdt, k.sn, k.cs);
-    if (k.small) {
-        k.s1 = dt; k.s2 = dt * dt / 2;
-        k.f1 = -(dt * dt * dt / 3);
-        k.f2 = (dt * dt * dt * dt / 8);
-        k.f3 = -(dt * dt / 2);
-        k.f4 = (dt * dt * dt / 6);
-    } else {
-        const double im = 1.0 / k.mag, im2 = im * im, im3 = im2 * im, im4 = im2 * im2;
-        k.s1 = k.sn * im;
-        k.s2 = (1.0 - k.cs) * im2;
-        k.f1 = (k.wdt * k.cs - k.sn) * im3;
-        k.f2 = (k.wdt * k.wdt - 2 * k.cs - 2 * k.wdt * k.sn + 2) * (0.5 * im4);
-        k.f3 = -(1 - k.cs) * im2;
-        k.f4 = (k.wdt - k.sn) * im3;
-    }
+    // Both forms are evaluated and selected (no branch): the Taylor side is a handful of multiplies.
+    // (1/3, 1/6 as constants: <= 1 ulp from the reference's divisions.)
+    const double t2 = dt * dt, t3 = t2 * dt;
+    const double im2 = im * im, im3 = im2 * im, im4 = im2 * im2;
+    const double omc = 1.0 - k.cs;
+    const bool sm = k.small;
+    k.s1 = sm ? dt : k.sn * im;
+    k.s2 = sm ? 0.5 * t2 : omc * im2;
+    k.f1 = sm ? -(t3 * (1.0 / 3.0)) : (k.wdt * k.cs - k.sn) * im3;
+    k.f2 = sm ? (t2 * t2 * 0.125) : (k.wdt * k.wdt - 2 * k.cs - 2 * k.wdt * k.sn + 2) * (0.5 * im4);
+    k.f3 = sm ? -(0.5 * t2) : -omc * im2;
+    k.f4 = sm ? (t3 * (1.0 / 6.0)) : (k.wdt - k.sn) * im3;
     return k;
 }
 CPI_HD M3 R_step_of(V3 w, const StepCoef &k) { return poly_wx(w, 1.0, -k.s1, k.s2); }
@@ -268,7 +324,7 @@ CPI_HD M3 R_half_of(V3 w, const StepCoef &k) {
     if (k.small) return poly_wx(w, 1.0, -h, h * h / 2);
     double s, c;
     sincos_fast(k.mag * h, s, c);
-    const double im = 1.0 / k.mag;
+    const double im = k.im;
     return poly_wx(w, 1.0, -s * im, (1.0 - c) * im * im);
 }
 // ua = alpha_arg * a, ub = Beta_arg * a in vector form ([w]x^2 a = w x (w x a))
@@ -298,9 +354,15 @@ CPI_HD void mean_init(MeanState<JAC> &s) {
 // i.e. the analytic Jacobians incl. O_a/O_b used when state_transition_jacobians == false).
 // w0/a0/w1/a1 are RAW readings; bw/ba the linearisation biases; gk = R(q_k_lin)*grav (model 2).
 template <int MODEL, bool JAC, bool AVG>
-CPI_HD void mean_step(MeanState<JAC> &s, double t0, double t1, V3 w0, V3 a0, V3 w1, V3 a1, V3 bw, V3 ba, V3 gk) {
-    const double dt = t1 - t0;
-    if (!(dt > 0)) return;  // dt == 0: feed_IMU returns early (CpiV1.h:72); dt < 0: caller skips (GraphSolver_IMU.cpp:52)
+CPI_HD void mean_step(MeanState<JAC> &s, double t0, double t1, V3 w0, V3 a0, V3 w1, V3 a1, V3 bw, V3 ba, V3 gk,
+                      bool active = true) {
+    double dt = t1 - t0;
+    // dt == 0: feed_IMU returns early (CpiV1.h:72); dt < 0: caller skips (GraphSolver_IMU.cpp:52); NaN: separator.
+    // Mean-only path: a dt == 0 step is an exact no-op of the arithmetic below (every increment is a product
+    // with 0), so inactive / skipped intervals run branch-free with dt forced to 0 -- no divergence, no
+    // exec-mask bookkeeping, no register copies at control-flow joins.
+    if (!JAC) { if (!(active && dt > 0)) dt = 0; }
+    else if (!(active && dt > 0)) return;
     s.DT += dt;
     V3 w = w0 - bw;
     V3 a = a0 - ba;
@@ -311,6 +373,23 @@ CPI_HD void mean_step(MeanState<JAC> &s, double t0, double t1, V3 w0, V3 a0, V3 
         if (MODEL == 1) a = 0.5 * (a + (a1 - ba));
     }
     const StepCoef k = step_coef(w, dt);
+    if (!JAC) {
+        // Mean-only: rotate the columns of R in place, R'[:,c] = r - s1 (w x r) + s2 (w x (w x r)),
+        // instead of forming R_tau2tau1 and a 3x3 product -- same arithmetic, half the live registers.
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const V3 r = col(s.R, c);
+            const V3 wr = cross(w, r), wwr = cross(w, wr);
+            const V3 rn = axpy(k.s2, wwr, axpy(-k.s1, wr, r));
+            s.R.m[0][c] = rn.x; s.R.m[1][c] = rn.y; s.R.m[2][c] = rn.z;
+        }
+        if (MODEL == 2 && AVG) a = 0.5 * (a + (a1 - ba - mul(s.R, gk)));
+        V3 ua, ub;
+        arg_times(w, a, k, ua, ub);
+        s.alpha = s.alpha + (dt * s.beta + mulT(s.R, ua));  // uses the not-yet-updated beta (CpiV1.h:153)
+        s.beta = s.beta + mulT(s.R, ub);
+        return;
+    }
     const M3 Rs = R_step_of(w, k);
     const M3 Rn = mm(Rs, s.R);
     if (MODEL == 2 && AVG) a = 0.5 * (a + (a1 - ba - mul(Rn, gk)));
@@ -357,7 +436,7 @@ CPI_HD void mean_step(MeanState<JAC> &s, double t0, double t1, V3 w0, V3 a0, V3 
             const double t2 = dt * dt, t4 = t2 * t2;
             d1 = -(t4 * dt / 15); d2 = (t4 * t2 / 72); d3 = -(t4 / 12); d4 = (t4 * dt / 60);
         } else {
-            const double im = 1.0 / k.mag, im2 = im * im, im4 = im2 * im2, im5 = im4 * im, im6 = im4 * im2;
+            const double im = k.im, im2 = im * im, im4 = im2 * im2, im5 = im4 * im, im6 = im4 * im2;
             const double x = k.wdt, x2 = x * x;
             d1 = (x2 * k.sn - 3 * k.sn + 3 * x * k.cs) * im5;
             d2 = (x2 - 4 * k.cs - 4 * x * k.sn + x2 * k.cs + 4) * im6;

@@ -182,20 +182,16 @@ class _CpiBase:
 
     def _knots(self):
         """Intervals -> knot records.  Consecutive intervals that chain (t1 == next t0 and the next
-        reading equals this interval's w1/a1) share a knot; otherwise each interval is fed as its own
-        2-knot window segment separated by a zero-length gap knot pair (dt == 0 is skipped)."""
+        reading equals this interval's w1/a1) share a knot.  The reference's feed_IMU only ever uses
+        t1 - t0, so intervals need not chain: a knot whose time is NaN acts as a separator (both
+        intervals touching it have a NaN dt and are skipped by the kernels)."""
         rows = []
         for (t0, t1, w0, a0, w1, a1) in self._iv:
-            if rows and rows[-1][0] == t0 and np.array_equal(rows[-1][1:4], w0) and np.array_equal(rows[-1][4:7], a0):
-                pass
-            else:
+            chained = bool(rows) and rows[-1][0] == t0 and np.array_equal(rows[-1][1:4], w0) and np.array_equal(rows[-1][4:7], a0)
+            if not chained:
                 if rows:
-                    # re-anchor: repeat the time of the previous knot with the new reading (dt == 0 no-op step)
-                    if t0 != rows[-1][0]:
-                        raise ValueError("feed_IMU intervals must be contiguous in time")
-                    rows.append(np.concatenate([[t0], w0, a0]))
-                else:
-                    rows.append(np.concatenate([[t0], w0, a0]))
+                    rows.append(np.concatenate([[np.nan], np.zeros(6)]))
+                rows.append(np.concatenate([[t0], w0, a0]))
             rows.append(np.concatenate([[t1], w1, a1]))
         return np.stack(rows) if rows else np.zeros((1, 7))
 

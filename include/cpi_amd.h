@@ -84,7 +84,9 @@ int cpi_ctx_synchronize(cpi_ctx *ctx);
  *         feed_IMU(t_i, t_{i+1}, w_i, a_i, w_{i+1}, a_{i+1}); intervals with t_{i+1}-t_i <= 0 are
  *         skipped exactly like the reference (dt==0: CpiV1.h:72; dt<0: GraphSolver_IMU.cpp:52).
  *         A tail interval [t_last, updatetime] is expressed by a final knot
- *         {updatetime, w_last, a_last} (GraphSolver_IMU.cpp:64-69).
+ *         {updatetime, w_last, a_last} (GraphSolver_IMU.cpp:64-69).  A knot whose t is NaN is a
+ *         separator: both intervals touching it are skipped, so non-chained feed_IMU calls
+ *         (the reference only ever uses t_1 - t_0) can be expressed in one window.
  * first   [W] index of each window's first knot, or NULL for the dense layout knots[W][N+1][7].
  * count   [W] number of intervals of each window (<= N), or NULL = every window has N.
  *         Windows may share knots (consecutive windows cut from one stream).

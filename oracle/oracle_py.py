@@ -186,5 +186,6 @@ def factor_records(out, lin, q_k_lin, grav=DEFAULT_GRAV):
         rec[:, cols["q_K_lin"]] = q_k_lin
     else:
         rec[:, cols["q_K_lin"]] = np.array([0, 0, 0, 1.0])
-    rec[:, cols["O_beta"]] = out["O_b"]; rec[:, cols["O_alpha"]] = out["O_a"]
+    if "O_b" in out:
+        rec[:, cols["O_beta"]] = out["O_b"]; rec[:, cols["O_alpha"]] = out["O_a"]
     return rec

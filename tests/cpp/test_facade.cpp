@@ -1,0 +1,72 @@
+// test_facade.cpp -- drives the C++ facade (cpi_host.hpp) exactly like GraphSolver_IMU.cpp:43-75
+// drives the reference: read a dumped window, feed_IMU it, print the results for the Python test
+// (tests/test_gpu_cpp_facade.py) to compare with the golden vectors.  GPU only.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../cpi_amd/csrc/cpi_host.hpp"
+
+using namespace cpi_host;
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s <input.bin> <model>\n", argv[0]); return 2; }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    double hdr[2];
+    if (fread(hdr, 8, 2, f) != 2) return 2;
+    const int W = (int)hdr[0], n = (int)hdr[1];
+    std::vector<double> kn((size_t)W * (n + 1) * 7), lin((size_t)W * 6), q((size_t)W * 4);
+    if (fread(kn.data(), 8, kn.size(), f) != kn.size() || fread(lin.data(), 8, lin.size(), f) != lin.size() ||
+        fread(q.data(), 8, q.size(), f) != q.size()) return 2;
+    fclose(f);
+    const int model = atoi(argv[2]);
+    try {
+        Context ctx;
+        std::vector<CpiBase *> wins;
+        CpiBatch batch;
+        for (int w = 0; w < W; w++) {
+            CpiBase *cpi = (model == 1) ? (CpiBase *)new CpiV1(0.005, 4e-6, 0.01, 2e-4) : (CpiBase *)new CpiV2(0.005, 4e-6, 0.01, 2e-4);
+            const double *l = &lin[w * 6], *qq = &q[w * 4];
+            cpi->setLinearizationPoints({{l[0], l[1], l[2]}}, {{l[3], l[4], l[5]}}, {{qq[0], qq[1], qq[2], qq[3]}}, {{0, 0, 9.8}});
+            cpi->imu_avg = false;
+            const double *k = &kn[(size_t)w * (n + 1) * 7];
+            for (int i = 0; i < n; i++) {
+                const double *a = k + 7 * i, *b = k + 7 * (i + 1);
+                if (b[0] - a[0] >= 0)  // GraphSolver_IMU.cpp:52
+                    cpi->feed_IMU(a[0], b[0], {{a[1], a[2], a[3]}}, {{a[4], a[5], a[6]}}, {{b[1], b[2], b[3]}}, {{b[4], b[5], b[6]}});
+            }
+            wins.push_back(cpi);
+            if (w == 0) cpi->finalize(ctx); else batch.add(cpi);   // both paths: single-window and batched
+        }
+        batch.flush(ctx);
+        for (int w = 0; w < W; w++) {
+            const CpiBase &c = *wins[w];
+            printf("%.17g", c.DT);
+            for (double v : c.alpha_tau) printf(" %.17g", v);
+            for (double v : c.beta_tau) printf(" %.17g", v);
+            for (double v : c.q_k2tau) printf(" %.17g", v);
+            for (double v : c.J_q) printf(" %.17g", v);
+            for (double v : c.J_a) printf(" %.17g", v);
+            for (double v : c.J_b) printf(" %.17g", v);
+            for (double v : c.H_a) printf(" %.17g", v);
+            for (double v : c.H_b) printf(" %.17g", v);
+            for (double v : c.O_a) printf(" %.17g", v);
+            for (double v : c.O_b) printf(" %.17g", v);
+            for (double v : c.P_meas) printf(" %.17g", v);
+            printf("\n");
+        }
+        // one evaluateError at the predicted-like state pair (state_i == state_j): bias rows must vanish
+        ImuFactorCPI fac(*wins[0]);
+        double xi[16] = { q[0], q[1], q[2], q[3], lin[0], lin[1], lin[2], 0.3, -0.2, 0.1, lin[3], lin[4], lin[5], 1, 2, 3 };
+        double err[15], H1[225], H2[225];
+        fac.evaluateError(ctx, xi, xi, err, H1, H2);
+        printf("ERR");
+        for (double v : err) printf(" %.17g", v);
+        printf("\n");
+    } catch (const std::exception &e) {
+        fprintf(stderr, "cpi_host error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,51 @@
+"""GPU: the C++ host facade (cpi_amd/csrc/cpi_host.hpp) -- CpiV1/CpiV2-shaped classes, CpiBatch and the
+evaluateError-shaped evaluator -- compiled with g++ against libcpi_amd.so and compared with the
+golden vectors of the compiled reference."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests.tol import check_pre
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe():
+    from cpi_amd import _lib
+    _lib.load()
+    out = os.path.join(tempfile.mkdtemp(), "test_facade")
+    libdir = os.path.join(ROOT, "cpi_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_facade.cpp"), "-o", out,
+                           "-L" + libdir, "-lcpi_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_cpp_facade_vs_golden(exe, golden_dir, model):
+    d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
+    kn, lin, q = d["knots"], d["lin"], d["q_k_lin"]
+    W, n1, _ = kn.shape
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        np.array([W, n1 - 1], dtype=np.float64).tofile(f)
+        kn.tofile(f); lin.tofile(f); q.tofile(f)
+        path = f.name
+    p = subprocess.run([exe, path, str(model)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().split("\n")
+    rows = np.array([[float(x) for x in ln.split()] for ln in lines[:W]])
+    names = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9), ("H_a", 9), ("H_b", 9),
+             ("O_a", 9), ("O_b", 9), ("P", 225)]
+    out, o = {}, 0
+    for name, n in names:
+        out[name] = rows[:, o] if n == 1 else rows[:, o:o + n]
+        o += n
+    key = "m%d_avg0_stj1__" % model
+    ref = {k[len(key):]: v for k, v in d.items() if k.startswith(key)}
+    check_pre(out, ref, v2=(model == 2), label="c++ facade m%d" % model)
+    err = np.array([float(x) for x in lines[W].split()[1:]])
+    assert err.shape == (15,) and np.abs(err[3:6]).max() == 0 and np.abs(err[9:12]).max() == 0

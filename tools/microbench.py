@@ -1,0 +1,35 @@
+"""Kernel A/B harness (development tool): time several (workload, windows, lanes) configs in one process.
+   CPI_AMD_LIB=build/exp/variant.so python tools/microbench.py v1_mean:10000:8 v1_mean:1000000:1 ...
+Prints launch microseconds (HIP events over `steps` back-to-back launches on a >256 MiB batch pool)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import cpi_amd  # noqa: E402
+
+
+def main():
+    eng = cpi_amd.Engine(device=0)
+    tag = os.path.basename(os.environ.get("CPI_AMD_LIB", "default"))
+    for spec in sys.argv[1:]:
+        name, W, lanes = spec.split(":")[:3]
+        W, lanes = int(W), int(lanes)
+        steps = int(spec.split(":")[3]) if spec.count(":") >= 3 else (200 if W <= 20000 else 10)
+        wl = bench.Workload(eng, name, W, 50, seed=1234, lanes=lanes)
+        best = 1e30
+        for rep in range(3):
+            wall, k_ms = bench.time_steps(wl, steps, 5)
+            best = min(best, k_ms * 1e3 / steps)
+        gbs = bench.BYTES[name] * W / (best * 1e-6) / 1e9
+        print("%-18s %-10s W=%-8d L=%-3d launch_us=%10.2f  units/s=%.4g  GB/s=%.1f  frac=%.3f" % (
+            tag, name, W, lanes, best, W / (best * 1e-6), gbs, gbs / 8000.0), flush=True)
+        del wl
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
