@@ -256,16 +256,19 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
 // ============================================================================================
 // covariance (+ state transition) kernel
 // ============================================================================================
+#ifndef CPI_COV_WPS
+#define CPI_COV_WPS 1
+#endif
 template <int MODEL, bool AVG>
-__global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
+__global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     typedef CovDims<MODEL> D;
     constexpr int GROUP = D::GROUP;   // lanes per window
     constexpr int G = 64 / GROUP;     // windows per wavefront
     constexpr int CH = GROUP;         // intervals per window processed by one phase-A pass
     constexpr int RD = SAMPLE_REC_DOUBLES;
-    constexpr int EP = 18;            // exchange row pitch (doubles): 16-B aligned rows, distinct bank slots
+    constexpr int EP = EXCH_PITCH;
     __shared__ __attribute__((aligned(16))) double recs[64 * RD];
-    __shared__ __attribute__((aligned(16))) double exch[G * 9 * EP];
+    __shared__ __attribute__((aligned(16))) double exch[G * EXCH_ROWS * EP];
 
     const int lane = threadIdx.x;
     const int g = lane / GROUP, j = lane % GROUP;
@@ -283,16 +286,17 @@ __global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
 
     const int jj = min(j, (int)D::NCOL);  // idle lanes (j >= NCOL) run as a harmless zero transition column
     CovLane<MODEL> Ln;
-    cov_init(Ln, jj);
-    const int er = cov_exch_row(jj);
-    double *ex_g = exch + g * 9 * EP;
-    const double *ex_row = ex_g + (er < 0 ? 0 : er) * EP;
+    cov_init(Ln, jj, q4);
+    double *ex_g = exch + g * EXCH_ROWS * EP;
+    const double *ex_row = ex_g + cov_read_row<MODEL>(jj) * EP;
+    for (int i = lane; i < G * EXCH_ROWS * EP; i += 64) exch[i] = 0.0;
+    __syncthreads();
+    cov_exch_init<MODEL>(ex_g, jj, q4);
 
     for (int base = 0; base < nmax; base += CH) {
         // ---- phase A: lane (g, j) evaluates the closed forms of interval base + j of its window
         {
             const int s = base + j;
-            double *rp = recs + (g * CH + j) * RD;
             SampleRec r;
             if (s < n) {
                 const double *ka = A.knots + (k0 + s) * 7;
@@ -305,13 +309,7 @@ __global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
                 r.dt = 0; r.w = mk(0, 0, 0); r.a0 = mk(0, 0, 0); r.a1 = mk(0, 0, 0);
                 r.f1 = r.f2 = r.f3 = r.f4 = 0; r.Rstep = eye(); r.Rhalf = eye();
             }
-            rp[0] = r.dt;
-            stv3(rp + 1, r.w); stv3(rp + 4, r.a0); stv3(rp + 7, r.a1);
-            rp[10] = r.f1; rp[11] = r.f2; rp[12] = r.f3; rp[13] = r.f4;
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int k = 0; k < 3; k++) { rp[14 + i * 3 + k] = r.Rstep.m[i][k]; rp[23 + i * 3 + k] = r.Rhalf.m[i][k]; }
+            rec_store(recs + (g * CH + j) * RD, r);
         }
         __syncthreads();
 
@@ -319,31 +317,25 @@ __global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
         const int cnt = min(CH, nmax - base);
         for (int sl = 0; sl < cnt; ++sl) {
             const double *rp = recs + (g * CH + sl) * RD;  // group-uniform address: LDS broadcast
-            SampleRec r;
-            r.dt = rp[0];
-            r.w = ldv3(rp + 1); r.a0 = ldv3(rp + 4); r.a1 = ldv3(rp + 7);
-            r.f1 = rp[10]; r.f2 = rp[11]; r.f3 = rp[12]; r.f4 = rp[13];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int k = 0; k < 3; k++) { r.Rstep.m[i][k] = rp[14 + i * 3 + k]; r.Rhalf.m[i][k] = rp[23 + i * 3 + k]; }
-            cov_begin<MODEL, AVG>(Ln, r, gk);
+            cov_begin<MODEL, AVG>(Ln, rp, gk);
 #pragma unroll
             for (int stg = 0; stg < 4; ++stg) {
+                cov_stage_rot(Ln, stg, rp);
                 double M[9];
                 cov_stage_M(Ln, stg, M);
                 if (j < D::NPCOL) {
 #pragma unroll
                     for (int rr = 0; rr < 9; rr++) ex_g[rr * EP + j] = M[rr];
                 }
-                __syncthreads();
-                double Mt[D::NR];
-#pragma unroll
-                for (int i = 0; i < D::NR; i++) Mt[i] = ex_row[i];
-                cov_stage_finish(Ln, stg, M, Mt, jj, q4);
-                __syncthreads();
+                // The exchange is private to this wavefront and a wave's DS instructions execute in issue
+                // order, so the row reads below see the writes above without draining lgkmcnt; only the
+                // COMPILER must not reorder them (no instruction is emitted here).
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                cov_stage_finish(Ln, stg, M, ex_row);
             }
-            cov_end(Ln);
+            cov_end(Ln, rp);
             if (MODEL == 2) {  // column clone: columns 15:18 := columns 0:3 (CpiV2.h:436-441)
                 const int src = (j >= 15 && j < 18) ? lane - 15 : lane;
 #pragma unroll

@@ -555,25 +555,78 @@ struct CovDims {
     static const int GROUP = (MODEL == 1) ? 16 : 32; // lanes per window
 };
 
+// Record layout (doubles) of SampleRec as staged in LDS by the kernel / in memory by the host emulator.
+static const int REC_DT = 0, REC_W = 1, REC_A0 = 4, REC_A1 = 7, REC_F = 10, REC_RSTEP = 14, REC_RHALF = 23;
+CPI_HD void rec_store(double *rp, const SampleRec &r) {
+    rp[REC_DT] = r.dt;
+    rp[REC_W] = r.w.x; rp[REC_W + 1] = r.w.y; rp[REC_W + 2] = r.w.z;
+    rp[REC_A0] = r.a0.x; rp[REC_A0 + 1] = r.a0.y; rp[REC_A0 + 2] = r.a0.z;
+    rp[REC_A1] = r.a1.x; rp[REC_A1 + 1] = r.a1.y; rp[REC_A1 + 2] = r.a1.z;
+    rp[REC_F] = r.f1; rp[REC_F + 1] = r.f2; rp[REC_F + 2] = r.f3; rp[REC_F + 3] = r.f4;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { rp[REC_RSTEP + i * 3 + k] = r.Rstep.m[i][k]; rp[REC_RHALF + i * 3 + k] = r.Rhalf.m[i][k]; }
+}
+CPI_HD M3 rec_mat(const double *rp, int at) {
+    M3 A;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) A.m[i][k] = rp[at + i * 3 + k];
+    return A;
+}
+CPI_HD V3 rec_v3(const double *rp, int at) { return mk(rp[at], rp[at + 1], rp[at + 2]); }
+
+// Exchange-buffer rows of one window group: 0..8 = rows (theta,v,p) of F X written every stage;
+// 9..14 = constant rows q_j e_j for the b_w / b_a covariance columns (their only k contribution is the
+// process noise on the diagonal); 15 = zeros (columns with no transposed row: clone and transition lanes).
+static const int EXCH_ROWS = 16;
+static const int EXCH_PITCH = 18;  // doubles: 16-B aligned rows on distinct LDS bank slots
+
 template <int MODEL>
 struct CovLane {
     double P0[CovDims<MODEL>::NR];   // column at the start of the interval
     double X[CovDims<MODEL>::NR];    // RK4 stage value
     double acc[CovDims<MODEL>::NR];  // running RK4 sum
     V3 xl;                           // theta_klin part of the column (constant; non-zero only for 3 D-columns)
+    V3 hqt, hqv;                     // half the process-noise variance on this column's own diagonal row
+                                     // (theta / v columns only): k_jj = (M_jj + q/2) + (M_jj + q/2)
     // shared per-window running state, replicated in every lane of the group
     M3 R;                            // R_k2tau
     V3 alpha, beta;
     double DT;
     // per-interval scratch
-    M3 Rn, Rm;
+    M3 Rs;                           // rotation used by the current RK4 stage (R_old, R_mid, R_mid, R_new)
     V3 w, a, gtau, h;
     double dt;
 };
 
-// j = column index inside the window's lane group: [0,NPCOL) covariance, [NPCOL,NCOL) transition.
+// Which exchange row this column reads as its transposed contribution.
+CPI_HD int cov_exch_row(int j) {
+    return (j < 3) ? j : ((j >= 6 && j < 9) ? j - 3 : ((j >= 12 && j < 15) ? j - 6 : -1));
+}
 template <int MODEL>
-CPI_HD void cov_init(CovLane<MODEL> &L, int j) {
+CPI_HD int cov_read_row(int j) {
+    typedef CovDims<MODEL> D;
+    if (j >= D::NPCOL) return 15;
+    const int er = cov_exch_row(j);
+    if (er >= 0) return er;
+    if (j >= 3 && j < 6) return 9 + (j - 3);
+    if (j >= 9 && j < 12) return 12 + (j - 9);
+    return 15;
+}
+// Initialise the constant rows (9..15) of a window group's exchange buffer.  Called by every lane j of the
+// group for its own column index (idle lanes included); rows 9..15 must have been zeroed before.
+template <int MODEL>
+CPI_HD void cov_exch_init(double *ex_g, int j, const double q4[4]) {
+    if (j >= 3 && j < 6) ex_g[(9 + (j - 3)) * EXCH_PITCH + j] = q4[1];
+    if (j >= 9 && j < 12) ex_g[(12 + (j - 9)) * EXCH_PITCH + j] = q4[3];
+}
+
+// j = column index inside the window's lane group: [0,NPCOL) covariance, [NPCOL,NCOL) transition, NCOL = idle.
+template <int MODEL>
+CPI_HD void cov_init(CovLane<MODEL> &L, int j, const double q4[4]) {
     typedef CovDims<MODEL> D;
 #pragma unroll
     for (int i = 0; i < D::NR; i++) { L.P0[i] = 0; L.X[i] = 0; L.acc[i] = 0; }
@@ -586,97 +639,102 @@ CPI_HD void cov_init(CovLane<MODEL> &L, int j) {
         for (int i = 0; i < D::NR; i++) L.P0[i] = (i == hot) ? 1.0 : 0.0;
         if (d >= 6) L.xl = unit(d - 6);
     }
+    // G Qc G^T = blkdiag(s_w^2, s_wb^2, s_a^2, s_ab^2, 0) (x) I  (CpiV1.h:283-291; Rs^T Rs = I)
+    const double ht = 0.5 * q4[0], hv = 0.5 * q4[2];
+    L.hqt = mk(j == 0 ? ht : 0.0, j == 1 ? ht : 0.0, j == 2 ? ht : 0.0);
+    L.hqv = mk(j == 6 ? hv : 0.0, j == 7 ? hv : 0.0, j == 8 ? hv : 0.0);
     L.R = eye();
     L.alpha = mk(0, 0, 0); L.beta = mk(0, 0, 0); L.DT = 0;
 }
 
-// Start of an interval: rotations, gravity terms, means (CpiV1.h:123-154 / CpiV2.h:99,141-186).
+// Start of an interval (rp = the interval's SampleRec record): specific force, gravity terms, stage-0 rotation.
 template <int MODEL, bool AVG>
-CPI_HD void cov_begin(CovLane<MODEL> &L, const SampleRec &r, V3 gk) {
+CPI_HD void cov_begin(CovLane<MODEL> &L, const double *rp, V3 gk) {
     typedef CovDims<MODEL> D;
-    L.dt = r.dt;
-    L.w = r.w;
-    L.Rn = mm(r.Rstep, L.R);
-    L.Rm = mm(r.Rhalf, L.R);
-    V3 a = r.a0;
+    L.dt = rp[REC_DT];
+    L.w = rec_v3(rp, REC_W);
+    V3 a = rec_v3(rp, REC_A0);
     if (MODEL == 2) {
         L.gtau = mul(L.R, gk);
         L.h = mul(L.R, cross(gk, L.xl));
         a = a - L.gtau;
-        if (AVG) a = 0.5 * (a + (r.a1 - mul(L.Rn, gk)));
+        if (AVG) {  // CpiV2.h:146-149: average the LOCAL acceleration, the second one in the frame after the step
+            const M3 Rn = mm(rec_mat(rp, REC_RSTEP), L.R);
+            a = 0.5 * (a + (rec_v3(rp, REC_A1) - mul(Rn, gk)));
+        }
     } else {
         L.gtau = mk(0, 0, 0); L.h = mk(0, 0, 0);
     }
     L.a = a;
-    StepCoef k;
-    k.dt = r.dt; k.f1 = r.f1; k.f2 = r.f2; k.f3 = r.f3; k.f4 = r.f4;
-    V3 ua, ub;
-    arg_times(r.w, a, k, ua, ub);
-    L.alpha = L.alpha + (r.dt * L.beta + mulT(L.Rn, ua));
-    L.beta = L.beta + mulT(L.Rn, ub);
-    L.DT += r.dt;
-#pragma unroll
-    for (int i = 0; i < D::NR; i++) { L.X[i] = L.P0[i]; L.acc[i] = L.P0[i]; }
+    L.Rs = L.R;
+    (void)sizeof(D);  // stage 0 works on P0 directly: no X / acc initialisation copies
 }
 
-// Stage s in {0,1,2,3}: M = rows (theta, v, p) of F x for this lane's column.
+// Rotation of RK4 stage s (CpiV1.h:267-269,279,300,332): called before cov_stage_M for s = 1 and s = 3.
+template <int MODEL>
+CPI_HD void cov_stage_rot(CovLane<MODEL> &L, int s, const double *rp) {
+    if (s == 1) L.Rs = mm(rec_mat(rp, REC_RHALF), L.R);
+    if (s == 3) L.Rs = mm(rec_mat(rp, REC_RSTEP), L.R);
+}
+
+// Stage s: M = rows (theta, v, p) of F x for this lane's column (+ half its own diagonal process noise).
 template <int MODEL>
 CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, double M[9]) {
-    const M3 &Rs = (s == 0) ? L.R : ((s == 3) ? L.Rn : L.Rm);
-    const V3 xt = mk(L.X[0], L.X[1], L.X[2]);
-    const V3 xbw = mk(L.X[3], L.X[4], L.X[5]);
-    const V3 xba = mk(L.X[9], L.X[10], L.X[11]);
-    const V3 mt = -(cross(L.w, xt)) - xbw;
+    const double *X = (s == 0) ? L.P0 : L.X;   // s is a compile-time constant after unrolling
+    const V3 xt = mk(X[0], X[1], X[2]);
+    const V3 xbw = mk(X[3], X[4], X[5]);
+    const V3 xba = mk(X[9], X[10], X[11]);
+    const V3 mt = (L.hqt - cross(L.w, xt)) - xbw;
     V3 y = cross(L.a, xt) + xba;
     if (MODEL == 2) {
-        const V3 xc = mk(L.X[15], L.X[16], L.X[17]);
+        const V3 xc = mk(X[15], X[16], X[17]);
         y = y + cross(L.gtau, xc) + L.h;
     }
-    const V3 mv = -(mulT(Rs, y));
+    const V3 mv = L.hqv - mulT(L.Rs, y);
     M[0] = mt.x; M[1] = mt.y; M[2] = mt.z;
     M[3] = mv.x; M[4] = mv.y; M[5] = mv.z;
-    M[6] = L.X[6]; M[7] = L.X[7]; M[8] = L.X[8];
+    M[6] = X[6]; M[7] = X[7]; M[8] = X[8];
 }
 
-// Row index (0..8 in the exchange buffer) of the F-row that a covariance column j transposes, or -1.
-CPI_HD int cov_exch_row(int j) {
-    return (j < 3) ? j : ((j >= 6 && j < 9) ? j - 3 : ((j >= 12 && j < 15) ? j - 6 : -1));
-}
-
-// Finish stage s: k = M (rows theta,v,p) + Mt (the transposed row, covariance columns only) + G Q G^T
-// column, then X <- P0 + c k and acc += wgt k.  Mt[i] = (F X)[row j][col i] read from the exchange
-// buffer (ignored when is_pcol is false or the column's row of F is zero).
+// Finish stage s: k = M (rows theta,v,p) + Mt, then X <- P0 + c k and acc += wgt k.  Mt = the row of the
+// exchange buffer selected by cov_read_row (the transposed F X row, a constant noise row, or zeros), so no
+// per-lane condition is left in the arithmetic.
 template <int MODEL>
-CPI_HD void cov_stage_finish(CovLane<MODEL> &L, int s, const double M[9], const double *Mt, int j,
-                             const double q4[4]) {
+CPI_HD void cov_stage_finish(CovLane<MODEL> &L, int s, const double M[9], const double *Mt) {
     typedef CovDims<MODEL> D;
     const double dt = L.dt;
     const double c = (s == 2) ? dt : 0.5 * dt;               // X for the next stage
-    const double wgt = (s == 0 || s == 3) ? dt / 6.0 : dt / 3.0;
-    const bool is_p = (j < D::NPCOL);
-    const bool has_t = is_p && (cov_exch_row(j) >= 0);
+    const double wgt = (s == 0 || s == 3) ? dt * (1.0 / 6.0) : dt * (1.0 / 3.0);
 #pragma unroll
     for (int i = 0; i < D::NR; i++) {
-        double k = 0.0;
-        if (i < 3) k = M[i];
-        else if (i >= 6 && i < 9) k = M[i - 3];
-        else if (i >= 12 && i < 15) k = M[i - 6];
-        if (has_t) k += Mt[i];
-        if (is_p && i == j && i < 12) k += q4[i / 3];          // G Qc G^T = blkdiag(s_w^2, s_wb^2, s_a^2, s_ab^2, 0) (x) I
-        L.acc[i] = fma(wgt, k, L.acc[i]);
+        double k = Mt[i];
+        if (i < 3) k += M[i];
+        else if (i >= 6 && i < 9) k += M[i - 3];
+        else if (i >= 12 && i < 15) k += M[i - 6];
+        // stage 0 starts the running sum from P0; stage 3 writes the finished column straight back into P0
+        if (s == 0) L.acc[i] = fma(wgt, k, L.P0[i]);
+        else if (s < 3) L.acc[i] = fma(wgt, k, L.acc[i]);
         if (s < 3) L.X[i] = fma(c, k, L.P0[i]);
+        else L.P0[i] = fma(wgt, k, L.acc[i]);
     }
 }
 
-// End of interval: commit; model 2 row-clone theta -> theta_clone (B_k of CpiV2.h:436-443).
-// The column clone (columns 15:18 := columns 0:3) is a cross-lane copy done by the kernel.
+// End of interval: means (CpiV1.h:145-154 with R' = the stage-3 rotation), commit; model 2 row-clone
+// theta -> theta_clone (B_k of CpiV2.h:436-443).  The column clone (columns 15:18 := columns 0:3) is a
+// cross-lane copy done by the kernel.
 template <int MODEL>
-CPI_HD void cov_end(CovLane<MODEL> &L) {
+CPI_HD void cov_end(CovLane<MODEL> &L, const double *rp) {
     typedef CovDims<MODEL> D;
-#pragma unroll
-    for (int i = 0; i < D::NR; i++) L.P0[i] = L.acc[i];
+    StepCoef k;
+    k.dt = L.dt; k.f1 = rp[REC_F]; k.f2 = rp[REC_F + 1]; k.f3 = rp[REC_F + 2]; k.f4 = rp[REC_F + 3];
+    V3 ua, ub;
+    arg_times(L.w, L.a, k, ua, ub);
+    L.alpha = L.alpha + (L.dt * L.beta + mulT(L.Rs, ua));
+    L.beta = L.beta + mulT(L.Rs, ub);
+    L.DT += L.dt;
+    (void)sizeof(D);
     if (MODEL == 2) { L.P0[15] = L.P0[0]; L.P0[16] = L.P0[1]; L.P0[17] = L.P0[2]; }
-    L.R = L.Rn;
+    L.R = L.Rs;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -53,25 +53,26 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
     V3 gk = mk(0, 0, 0);
     if (MODEL == 2) gk = mul(quat_2_Rot(ldq(qk)), ld3(grav));
     const double q4[4] = { sig[0] * sig[0], sig[1] * sig[1], sig[2] * sig[2], sig[3] * sig[3] };
-    std::vector<CovLane<MODEL>> lane(D::NCOL);
-    for (int j = 0; j < D::NCOL; j++) cov_init(lane[j], j);
-    double exch[9][32];
+    const int NL = D::GROUP;   // all lanes of the group, idle ones included (as in the kernel)
+    std::vector<CovLane<MODEL>> lane(NL);
+    std::vector<double> exch(EXCH_ROWS * EXCH_PITCH, 0.0);
+    for (int j = 0; j < NL; j++) { const int jj = std::min(j, (int)D::NCOL); cov_init(lane[j], jj, q4); cov_exch_init<MODEL>(exch.data(), jj, q4); }
+    double rec[SAMPLE_REC_DOUBLES];
     for (int s = 0; s < n; s++) {
         const double *k0 = kn + 7 * s, *k1 = kn + 7 * (s + 1);
-        const SampleRec r = make_sample_rec<MODEL, AVG>(k0[0], k1[0], ld3(k0 + 1), ld3(k0 + 4), ld3(k1 + 1), ld3(k1 + 4), bw, ba);
-        for (int j = 0; j < D::NCOL; j++) cov_begin<MODEL, AVG>(lane[j], r, gk);
+        rec_store(rec, make_sample_rec<MODEL, AVG>(k0[0], k1[0], ld3(k0 + 1), ld3(k0 + 4), ld3(k1 + 1), ld3(k1 + 4), bw, ba));
+        for (int j = 0; j < NL; j++) cov_begin<MODEL, AVG>(lane[j], rec, gk);
         for (int st = 0; st < 4; st++) {
             double M[32][9];
-            for (int j = 0; j < D::NCOL; j++) {
+            for (int j = 0; j < NL; j++) {
+                cov_stage_rot(lane[j], st, rec);
                 cov_stage_M(lane[j], st, M[j]);
-                for (int rr = 0; rr < 9; rr++) exch[rr][j] = M[j][rr];
+                if (j < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + j] = M[j][rr];
             }
-            for (int j = 0; j < D::NCOL; j++) {
-                const int er = cov_exch_row(j);
-                cov_stage_finish(lane[j], st, M[j], exch[er < 0 ? 0 : er], j, q4);
-            }
+            for (int j = 0; j < NL; j++)
+                cov_stage_finish(lane[j], st, M[j], exch.data() + cov_read_row<MODEL>(std::min(j, (int)D::NCOL)) * EXCH_PITCH);
         }
-        for (int j = 0; j < D::NCOL; j++) cov_end(lane[j]);
+        for (int j = 0; j < NL; j++) cov_end(lane[j], rec);
         if (MODEL == 2)
             for (int b = 0; b < 3; b++) for (int i = 0; i < D::NR; i++) lane[15 + b].P0[i] = lane[b].P0[i];
     }
