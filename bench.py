@@ -158,7 +158,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or bool(os.environ.get("CPI_BENCH_FORCE_DIST"))  # env: exercise the RCCL path with one rank
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     torch.cuda.set_device(local_rank)

@@ -80,6 +80,13 @@ __device__ __forceinline__ MeanState<JAC> shfl_down(const MeanState<JAC> &s, int
     }
     return r;
 }
+// Orders LDS traffic of a single-wavefront workgroup for the COMPILER only: a wave's DS instructions execute
+// in issue order, so no counter drain (and no s_barrier) is needed between a write and a dependent read.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
@@ -330,9 +337,7 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                 // The exchange is private to this wavefront and a wave's DS instructions execute in issue
                 // order, so the row reads below see the writes above without draining lgkmcnt; only the
                 // COMPILER must not reorder them (no instruction is emitted here).
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                wave_lds_fence();
                 cov_stage_finish(Ln, stg, M, ex_row);
             }
             cov_end(Ln, rp);
@@ -407,54 +412,98 @@ __device__ __forceinline__ NavState ld_state(const double *p) {
     return s;
 }
 
+// 16 lanes per factor, 4 factors per wavefront.  Every lane evaluates the (cheap) shared quaternion algebra;
+// lane c < 15 owns column c of H1 / H2 and err[c].  The sweep is HBM-WRITE bound (3 720 of 4 496 B per factor
+// are the dense 15x15 pair), so the columns are transposed through LDS and leave the wavefront as full,
+// consecutive 16-byte stores: the 4 factors' H1 blocks are one contiguous 7 200-byte span of the output.
+#ifndef CPI_FACTOR_WPS
+#define CPI_FACTOR_WPS 1
+#endif
 template <int MODEL>
-__global__ __launch_bounds__(64) void cpi_factor_kernel(FactorArgs A) {
+__global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
+    constexpr int FPW = 4;                       // factors per wavefront
+    constexpr int HB = FPW * 225;                // doubles of H1 (or H2) per wavefront
+    __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
     const int lane = threadIdx.x;
-    const int c = lane & 15;
-    long long f = (long long)blockIdx.x * 4 + (lane >> 4);
-    const bool valid = f < A.F;
-    if (!valid) f = A.F - 1;
-    FactorMeas m;
-    m.alpha = ldv3(A.meas.alpha + f * 3);
-    m.beta = ldv3(A.meas.beta + f * 3);
-    m.q_KtoK1 = ldq4(A.meas.q + f * 4);
-    m.bg_lin = ldv3(A.lin + f * 6);
-    m.ba_lin = ldv3(A.lin + f * 6 + 3);
-    m.J_q = ldm3_cm(A.meas.J_q + f * 9);
-    m.J_beta = ldm3_cm(A.meas.J_b + f * 9);
-    m.J_alpha = ldm3_cm(A.meas.J_a + f * 9);
-    m.H_beta = ldm3_cm(A.meas.H_b + f * 9);
-    m.H_alpha = ldm3_cm(A.meas.H_a + f * 9);
-    m.dt = A.meas.DT[f];
+    const int c = lane & 15, fl = lane >> 4;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const bool valid = (f0 + fl) < A.F;
+    (void)valid;
+
+    // ---- cooperative, de-duplicated input fetch: every double of the 4 factors' records is loaded from HBM
+    // exactly once per wavefront (consecutive lanes = consecutive doubles of one SoA field) into LDS, from
+    // where the 16 lanes of a factor read it as broadcasts.  The staging area is reused for the outputs.
+    constexpr int O_ALPHA = 0, O_BETA = 3, O_Q = 6, O_LIN = 10, O_JQ = 16, O_JB = 25, O_JA = 34, O_HB = 43, O_HA = 52,
+                  O_DT = 61, O_QK = 62, O_OB = 66, O_OA = 75, O_XI = 84, O_XJ = 100, IN_D = 116;
+    static_assert(FPW * IN_D <= HB, "input staging must fit in the output staging area");
+    double *sIn = sH;
+    {
+        auto fetch = [&](const double *src, int k, int off) {   // field with k doubles per factor
+            if (lane < FPW * k) {
+                const int q = lane / k, e = lane - q * k;
+                const long long ff = min(f0 + q, A.F - 1);
+                sIn[q * IN_D + off + e] = src[ff * k + e];
+            }
+        };
+        fetch(A.meas.alpha, 3, O_ALPHA); fetch(A.meas.beta, 3, O_BETA); fetch(A.meas.q, 4, O_Q);
+        fetch(A.lin, 6, O_LIN); fetch(A.meas.J_q, 9, O_JQ); fetch(A.meas.J_b, 9, O_JB); fetch(A.meas.J_a, 9, O_JA);
+        fetch(A.meas.H_b, 9, O_HB); fetch(A.meas.H_a, 9, O_HA); fetch(A.meas.DT, 1, O_DT);
+        if (MODEL == 2) { fetch(A.qk, 4, O_QK); fetch(A.meas.O_b, 9, O_OB); fetch(A.meas.O_a, 9, O_OA); }
+        const long long ff = min(f0 + fl, A.F - 1);
+        const long long ii = A.idx_i ? A.idx_i[ff] : ff;
+        const long long ij = A.idx_j ? A.idx_j[ff] : ff + 1;
+        sIn[fl * IN_D + O_XI + c] = A.states[ii * 16 + c];
+        sIn[fl * IN_D + O_XJ + c] = A.states[ij * 16 + c];
+    }
+    __syncthreads();
+    const double *in = sIn + fl * IN_D;
+    FactorMeas m;   // every field is read from LDS where it is used
+    m.alpha = in + O_ALPHA; m.beta = in + O_BETA; m.q_KtoK1 = in + O_Q; m.lin = in + O_LIN; m.J_q = in + O_JQ;
+    m.J_beta = in + O_JB; m.J_alpha = in + O_JA; m.H_beta = in + O_HB; m.H_alpha = in + O_HA; m.dt = in + O_DT;
+    m.q_K_lin = in + O_QK; m.O_beta = in + O_OB; m.O_alpha = in + O_OA; m.xi = in + O_XI; m.xj = in + O_XJ;
     m.grav = mk(A.grav[0], A.grav[1], A.grav[2]);
-    if (MODEL == 2) {
-        m.q_K_lin = ldq4(A.qk + f * 4);
-        m.O_beta = ldm3_cm(A.meas.O_b + f * 9);
-        m.O_alpha = ldm3_cm(A.meas.O_a + f * 9);
-    } else {
-        m.q_K_lin.x = 0; m.q_K_lin.y = 0; m.q_K_lin.z = 0; m.q_K_lin.w = 1;
-        m.O_beta = zero3(); m.O_alpha = zero3();
-    }
-    const long long ii = A.idx_i ? A.idx_i[f] : f;
-    const long long ij = A.idx_j ? A.idx_j[f] : f + 1;
-    const NavState xi = ld_state(A.states + ii * 16), xj = ld_state(A.states + ij * 16);
-    FactorBlocks o;
-    factor_eval<MODEL>(m, xi, xj, o);
-    if (!valid || c >= 15) return;
-    A.err[f * 15 + c] = pick15(o.err, c);
-    if (A.H1) {
-        double h[15];
-        factor_H1_col(o, m, c, h);
-        double *p = A.H1 + f * 225 + c * 15;
+    FactorShared S;
+    factor_shared<MODEL>(m, min(c, 14), S);
+    double h1[15];
+    if (A.H1) factor_H1_column<MODEL>(S, m, h1);
+    wave_lds_fence();   // every lane is done reading the input staging area (in-order DS)
+
+    // ---- this lane's column -> LDS (layout identical to the global layout of this wavefront's span) -> HBM,
+    // consecutive lanes = consecutive 16-byte pieces (8-byte pieces for an output pointer that is not
+    // 16-byte aligned).  H1 and H2 take turns in the same staging area to keep LDS per wavefront small.
+    double *s1 = sH, *se = sH + HB;
+    const long long nf = min((long long)FPW, A.F - f0);
+    const int nd = (int)nf * 225, ne = (int)nf * 15;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    auto flush = [&](double *dst, const double *src, int n) {
+        if ((((unsigned long long)dst) & 15ULL) == 0) {
+            const int n2 = n >> 1;
+            for (int i = lane; i < n2; i += 64) ((d2 *)dst)[i] = ((const d2 *)src)[i];
+            if ((n & 1) && lane == 0) dst[n - 1] = src[n - 1];
+        } else {
+            for (int i = lane; i < n; i += 64) dst[i] = src[i];
+        }
+    };
+    if (c < 15) {
+        se[fl * 15 + c] = S.err_c;
+        if (A.H1) {
 #pragma unroll
-        for (int i = 0; i < 15; i++) p[i] = h[i];
+            for (int i = 0; i < 15; i++) s1[fl * 225 + c * 15 + i] = h1[i];
+        }
     }
+    wave_lds_fence();
+    flush(A.err + f0 * 15, se, ne);
+    if (A.H1) flush(A.H1 + f0 * 225, s1, nd);
     if (A.H2) {
-        double h[15];
-        factor_H2_col(o, c, h);
-        double *p = A.H2 + f * 225 + c * 15;
+        wave_lds_fence();   // in-order DS: the H1 reads above complete before these writes land
+        if (c < 15) {
+            double h2[15];
+            factor_H2_column(S, h2);
 #pragma unroll
-        for (int i = 0; i < 15; i++) p[i] = h[i];
+            for (int i = 0; i < 15; i++) s1[fl * 225 + c * 15 + i] = h2[i];
+        }
+        wave_lds_fence();
+        flush(A.H2 + f0 * 225, s1, nd);
     }
 }
 

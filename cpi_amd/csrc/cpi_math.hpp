@@ -25,8 +25,12 @@
 // "select of loads" into "load of a selected address", which would force the whole block to scratch.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CPI_REG(x) asm volatile("" : "+v"(x))
+// Scheduling fence: keeps hipcc from hoisting every operand load of a long straight-line block to its top
+// (which maximises registers, i.e. minimises co-resident wavefronts, in kernels that are latency-bound).
+#define CPI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define CPI_REG(x) ((void)0)
+#define CPI_SCHED_FENCE() ((void)0)
 #endif
 
 namespace cpi {
@@ -687,7 +691,8 @@ CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, double M[9]) {
     const V3 mt = (L.hqt - cross(L.w, xt)) - xbw;
     V3 y = cross(L.a, xt) + xba;
     if (MODEL == 2) {
-        const V3 xc = mk(X[15], X[16], X[17]);
+        constexpr int o = (CovDims<MODEL>::NR >= 18) ? 15 : 0;
+        const V3 xc = mk(X[o], X[o + 1], X[o + 2]);
         y = y + cross(L.gtau, xc) + L.h;
     }
     const V3 mv = L.hqv - mulT(L.Rs, y);
@@ -732,138 +737,150 @@ CPI_HD void cov_end(CovLane<MODEL> &L, const double *rp) {
     L.alpha = L.alpha + (L.dt * L.beta + mulT(L.Rs, ua));
     L.beta = L.beta + mulT(L.Rs, ub);
     L.DT += L.dt;
-    (void)sizeof(D);
-    if (MODEL == 2) { L.P0[15] = L.P0[0]; L.P0[16] = L.P0[1]; L.P0[17] = L.P0[2]; }
+    if (MODEL == 2) {
+        constexpr int o = (D::NR >= 18) ? 15 : 0;   // (model 1 never takes this branch)
+        L.P0[o] = L.P0[0]; L.P0[o + 1] = L.P0[1]; L.P0[o + 2] = L.P0[2];
+    }
     L.R = L.Rs;
 }
 
 // ------------------------------------------------------------------------------------------
 // evaluateError (ImuFactorCPIv1.cpp:37-208 / ImuFactorCPIv2.cpp:38-212).
-struct FactorMeas {          // what the factor constructors copy (ImuFactorCPIv1.h:78-100)
-    V3 alpha, beta; Q4 q_KtoK1;
-    V3 ba_lin, bg_lin;
-    M3 J_q, J_beta, J_alpha, H_beta, H_alpha, O_beta, O_alpha;
-    double dt; V3 grav; Q4 q_K_lin;
+// What the factor constructors copy (ImuFactorCPIv1.h:78-100), by reference: every field stays in memory
+// (LDS in the kernel) and is read where it is used, so nothing is held in registers across the evaluation.
+// Matrices are column-major; lin = {bg_lin[3], ba_lin[3]}; xi/xj = JPLNavState [q(4) bg(3) v(3) ba(3) p(3)].
+struct FactorMeas {
+    const double *alpha, *beta, *q_KtoK1, *lin, *J_q, *J_beta, *J_alpha, *H_beta, *H_alpha, *dt, *q_K_lin, *O_beta, *O_alpha;
+    const double *xi, *xj;
+    V3 grav;
 };
-struct NavState { Q4 q; V3 bg, v, ba, p; };  // JPLNavState.h:62-66
-struct FactorBlocks {
-    double err[15];
-    M3 H1_tt, H1_vt, H1_pt, H1_tg;  // state-dependent 3x3 blocks of H1: (0,0) (6,0) (12,0) (0,3)
-    M3 Rk;                          // quat_2_Rot(q_GtoK): H1 (6,6)=-Rk (12,6)=-dt Rk (12,12)=-Rk ; H2 (6,6)=(12,12)=Rk
-    M3 H2_tt;                       // H2 (0,0)
-};
-CPI_HD M3 qLmat(Q4 q, double sgn) {  // q_w I + sgn [q_v]x
-    const M3 S = skew(mk(q.x, q.y, q.z));
+CPI_HD V3 ldv(const double *p) { return mk(p[0], p[1], p[2]); }
+CPI_HD Q4 ldq(const double *p) { Q4 q; q.x = p[0]; q.y = p[1]; q.z = p[2]; q.w = p[3]; return q; }
+CPI_HD V3 mulcm(const double *A, V3 v) {  // column-major 3x3 in memory times vector
+    return mk(A[0] * v.x + A[3] * v.y + A[6] * v.z, A[1] * v.x + A[4] * v.y + A[7] * v.z, A[2] * v.x + A[5] * v.y + A[8] * v.z);
+}
+CPI_HD V3 colcm(const double *A, int cc) { return mk(A[cc * 3], A[cc * 3 + 1], A[cc * 3 + 2]); }
+CPI_HD M3 ldcm(const double *A) {
     M3 r;
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) r.m[i][j] = q.w * (i == j ? 1.0 : 0.0) + sgn * S.m[i][j];
+        for (int i = 0; i < 3; i++) r.m[i][j] = A[j * 3 + i];
     return r;
 }
-template <int MODEL>
-CPI_HD void factor_eval(const FactorMeas &f, const NavState &xi, const NavState &xj, FactorBlocks &o) {
-    const V3 dbg = xi.bg - f.bg_lin, dba = xi.ba - f.ba_lin;
-    const Q4 q_b = rot_2_quat(Exp_so3(-(mul(f.J_q, dbg))));
-    const Q4 q_n = quat_multiply(xj.q, quat_inv(xi.q));
-    const Q4 q_rminus = quat_multiply(q_n, quat_inv(f.q_KtoK1));
-    const Q4 q_r = quat_multiply(q_rminus, q_b);
-    const Q4 q_m = quat_multiply(quat_inv(q_b), f.q_KtoK1);
-    Q4 q_kR; q_kR.x = 0; q_kR.y = 0; q_kR.z = 0; q_kR.w = 1;
-    V3 dthk = mk(0, 0, 0);
-    if (MODEL == 2) {
-        q_kR = quat_multiply(xi.q, quat_inv(f.q_K_lin));
-        dthk = mk(2 * q_kR.x, 2 * q_kR.y, 2 * q_kR.z);
-    }
-    o.Rk = quat_2_Rot(xi.q);
-    V3 pa, pb;
-    if (MODEL == 1) {
-        pa = (xj.p - xi.p) - f.dt * xi.v + (0.5 * f.dt * f.dt) * f.grav;
-        pb = (xj.v - xi.v) + f.dt * f.grav;
-    } else {
-        pa = (xj.p - xi.p) - f.dt * xi.v;
-        pb = xj.v - xi.v;
-    }
-    const V3 Ra = mul(o.Rk, pa), Rb = mul(o.Rk, pb);
-    V3 alphahat = Ra - mul(f.J_alpha, dbg) - mul(f.H_alpha, dba);
-    V3 betahat = Rb - mul(f.J_beta, dbg) - mul(f.H_beta, dba);
-    if (MODEL == 2) { alphahat = alphahat - mul(f.O_alpha, dthk); betahat = betahat - mul(f.O_beta, dthk); }
-    const V3 e0 = mk(2 * q_r.x, 2 * q_r.y, 2 * q_r.z), e1 = xj.bg - xi.bg, e2 = betahat - f.beta,
-             e3 = xj.ba - xi.ba, e4 = alphahat - f.alpha;
-    o.err[0] = e0.x; o.err[1] = e0.y; o.err[2] = e0.z;
-    o.err[3] = e1.x; o.err[4] = e1.y; o.err[5] = e1.z;
-    o.err[6] = e2.x; o.err[7] = e2.y; o.err[8] = e2.z;
-    o.err[9] = e3.x; o.err[10] = e3.y; o.err[11] = e3.z;
-    o.err[12] = e4.x; o.err[13] = e4.y; o.err[14] = e4.z;
-    // H1 (0,0)
-    const M3 AB = mm(qLmat(q_n, -1.0), qLmat(q_m, -1.0));
-    const V3 qnv = mk(q_n.x, q_n.y, q_n.z), qmv = mk(q_m.x, q_m.y, q_m.z);
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) o.H1_tt.m[i][j] = -(AB.m[i][j] + get(qnv, i) * get(qmv, j));
-    o.H1_vt = skew(Rb);
-    o.H1_pt = skew(Ra);
-    if (MODEL == 2) {
-        const M3 L = qLmat(q_kR, +1.0);
-        const M3 Tb = mm(f.O_beta, L), Ta = mm(f.O_alpha, L);
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) { o.H1_vt.m[i][j] -= Tb.m[i][j]; o.H1_pt.m[i][j] -= Ta.m[i][j]; }
-    }
-    o.H1_tg = mm(qLmat(q_rminus, -1.0), f.J_q);
-    o.H2_tt = qLmat(q_r, +1.0);
-}
-// Column c (0..14) of the dense 15x15 H1 / H2, assembled from the blocks with selects only
-// (c is a per-lane runtime value in the kernel: no dynamically indexed register arrays).
+struct NavState { Q4 q; V3 bg, v, ba, p; };  // JPLNavState.h:62-66 (state prediction output)
+
+
 CPI_HD double sel3(double a, double b, double c, int k) { return k == 0 ? a : (k == 1 ? b : c); }
-CPI_HD V3 colsel(const M3 &A, int cc) {
-    double a0 = A.m[0][0], a1 = A.m[0][1], a2 = A.m[0][2], b0 = A.m[1][0], b1 = A.m[1][1], b2 = A.m[1][2],
-           c0 = A.m[2][0], c1 = A.m[2][1], c2 = A.m[2][2];
-    CPI_REG(a0); CPI_REG(a1); CPI_REG(a2); CPI_REG(b0); CPI_REG(b1); CPI_REG(b2); CPI_REG(c0); CPI_REG(c1); CPI_REG(c2);
-    return mk(sel3(a0, a1, a2, cc), sel3(b0, b1, b2, cc), sel3(c0, c1, c2, cc));
+// quat_2_Rot(q) x without forming the matrix: (2w^2-1) x - 2w (v x x) + 2 v (v.x)   (quat_ops.h:104-109)
+CPI_HD V3 qrot(Q4 q, V3 x) {
+    const V3 v = mk(q.x, q.y, q.z);
+    const double c = 2 * q.w * q.w - 1;
+    return axpy(2 * dot(v, x), v, axpy(-2 * q.w, cross(v, x), c * x));
+}
+// (q_w I + sgn [q_v]x) y
+CPI_HD V3 qLmul(Q4 q, double sgn, V3 y) { return axpy(sgn, cross(mk(q.x, q.y, q.z), y), q.w * y); }
+CPI_HD V3 pick5(V3 a0, V3 a1, V3 a2, V3 a3, V3 a4, int b) {
+    return mk(b == 0 ? a0.x : (b == 1 ? a1.x : (b == 2 ? a2.x : (b == 3 ? a3.x : a4.x))),
+              b == 0 ? a0.y : (b == 1 ? a1.y : (b == 2 ? a2.y : (b == 3 ? a3.y : a4.y))),
+              b == 0 ? a0.z : (b == 1 ? a1.z : (b == 2 ? a2.z : (b == 3 ? a3.z : a4.z))));
 }
 CPI_HD void put3(double *o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
-// H1 blocks (ImuFactorCPIv1.cpp:109-143): column-block 0 (theta): (0,0) (6,0) (12,0); 1 (b_g): (0,3) -I -J_beta
-// -J_alpha; 2 (v): -Rk, -dt Rk; 3 (b_a): -H_beta -I -H_alpha; 4 (p): -Rk.
-CPI_HD void factor_H1_col(const FactorBlocks &o, const FactorMeas &f, int c, double out[15]) {
-    const int bc = c / 3, cc = c - 3 * bc;
-    const V3 z = mk(0, 0, 0);
-    const V3 e = mk(cc == 0 ? -1.0 : 0.0, cc == 1 ? -1.0 : 0.0, cc == 2 ? -1.0 : 0.0);
-    const V3 rk = colsel(o.Rk, cc);
-    const V3 b0 = (bc == 0) ? colsel(o.H1_tt, cc) : ((bc == 1) ? colsel(o.H1_tg, cc) : z);
-    const V3 b1 = (bc == 1) ? e : z;
-    const V3 b2 = (bc == 0) ? colsel(o.H1_vt, cc)
-                : (bc == 1) ? -colsel(f.J_beta, cc)
-                : (bc == 2) ? -rk
-                : (bc == 3) ? -colsel(f.H_beta, cc) : z;
-    const V3 b3 = (bc == 3) ? e : z;
-    const V3 b4 = (bc == 0) ? colsel(o.H1_pt, cc)
-                : (bc == 1) ? -colsel(f.J_alpha, cc)
-                : (bc == 2) ? -(f.dt * rk)
-                : (bc == 3) ? -colsel(f.H_alpha, cc) : -rk;
-    put3(out, b0); put3(out + 3, b1); put3(out + 6, b2); put3(out + 9, b3); put3(out + 12, b4);
+
+// One lane's share of evaluateError: the residual component err[c] and column c (0..14) of the dense
+// 15x15 H1 and H2.  A column of a block is "block times unit vector", so with u = e_(c mod 3) held as a
+// runtime vector everything is 3-vector algebra -- no 3x3 temporaries, no select chains over matrices.
+// Split in three steps (shared quaternions + residual, H1 column, H2 column) so that a kernel can retire
+// each output before computing the next and keep its register footprint small.
+// Block layout: ImuFactorCPIv1.cpp:109-143 (H1), :169-185 (H2); model 2 adds the O_beta / O_alpha terms of
+// ImuFactorCPIv2.cpp:73,75,115-119.
+struct FactorShared {
+    Q4 q_n, q_m, q_rminus, q_r, q_kR;
+    V3 Ra, Rb, rku, u;
+    double err_c;
+    int bc, cc;
+};
+template <int MODEL>
+CPI_HD void factor_shared(const FactorMeas &f, int c, FactorShared &S) {
+    S.bc = c / 3; S.cc = c - 3 * S.bc;
+    S.u = unit(S.cc);
+    const V3 dbg = ldv(f.xi + 4) - ldv(f.lin), dba = ldv(f.xi + 10) - ldv(f.lin + 3);
+    V3 ja = mulcm(f.J_alpha, dbg) + mulcm(f.H_alpha, dba);      // alpha corrections
+    CPI_SCHED_FENCE();
+    V3 jb = mulcm(f.J_beta, dbg) + mulcm(f.H_beta, dba);        // beta corrections
+    CPI_SCHED_FENCE();
+    const Q4 qi = ldq(f.xi);
+    S.q_kR.x = 0; S.q_kR.y = 0; S.q_kR.z = 0; S.q_kR.w = 1;
+    if (MODEL == 2) {
+        S.q_kR = quat_multiply(qi, quat_inv(ldq(f.q_K_lin)));
+        const V3 dthk = mk(2 * S.q_kR.x, 2 * S.q_kR.y, 2 * S.q_kR.z);
+        ja = ja + mulcm(f.O_alpha, dthk);
+        jb = jb + mulcm(f.O_beta, dthk);
+        CPI_SCHED_FENCE();
+    }
+    const double dt = f.dt[0];
+    {
+        const V3 vi = ldv(f.xi + 7);
+        V3 pa = (ldv(f.xj + 13) - ldv(f.xi + 13)) - dt * vi;
+        V3 pb = ldv(f.xj + 7) - vi;
+        if (MODEL == 1) { pa = pa + (0.5 * dt * dt) * f.grav; pb = pb + dt * f.grav; }
+        S.Ra = qrot(qi, pa); S.Rb = qrot(qi, pb);
+    }
+    const V3 e4 = (S.Ra - ja) - ldv(f.alpha);   // alphahat - alpha
+    const V3 e2 = (S.Rb - jb) - ldv(f.beta);    // betahat - beta
+    CPI_SCHED_FENCE();
+    const Q4 q_meas = ldq(f.q_KtoK1);
+    const Q4 q_b = rot_2_quat(Exp_so3(-(mulcm(f.J_q, dbg))));
+    S.q_n = quat_multiply(ldq(f.xj), quat_inv(qi));
+    S.q_rminus = quat_multiply(S.q_n, quat_inv(q_meas));
+    S.q_r = quat_multiply(S.q_rminus, q_b);
+    S.q_m = quat_multiply(quat_inv(q_b), q_meas);
+    // residual [2 q_r,vec ; b_g,K+1 - b_g,K ; betahat - beta ; b_a,K+1 - b_a,K ; alphahat - alpha]
+    const V3 e = pick5(mk(2 * S.q_r.x, 2 * S.q_r.y, 2 * S.q_r.z), ldv(f.xj + 4) - ldv(f.xi + 4), e2,
+                       ldv(f.xj + 10) - ldv(f.xi + 10), e4, S.bc);
+    S.err_c = sel3(e.x, e.y, e.z, S.cc);
+    S.rku = qrot(qi, S.u);  // column cc of quat_2_Rot(q_GtoK)
+    CPI_SCHED_FENCE();
 }
-// H2 blocks (ImuFactorCPIv1.cpp:169-185): block diagonal (0,0)=q_r,w I + [q_r,v]x, I, Rk, I, Rk.
-CPI_HD void factor_H2_col(const FactorBlocks &o, int c, double out[15]) {
-    const int bc = c / 3, cc = c - 3 * bc;
-    const V3 z = mk(0, 0, 0);
-    const V3 e = mk(cc == 0 ? 1.0 : 0.0, cc == 1 ? 1.0 : 0.0, cc == 2 ? 1.0 : 0.0);
-    const V3 rk = colsel(o.Rk, cc);
-    put3(out, (bc == 0) ? colsel(o.H2_tt, cc) : z);
-    put3(out + 3, (bc == 1) ? e : z);
-    put3(out + 6, (bc == 2) ? rk : z);
-    put3(out + 9, (bc == 3) ? e : z);
-    put3(out + 12, (bc == 4) ? rk : z);
+template <int MODEL>
+CPI_HD void factor_H1_column(const FactorShared &S, const FactorMeas &f, double h1[15]) {
+    const V3 u = S.u, z = mk(0, 0, 0);
+    const int bc = S.bc, cc = S.cc;
+    const V3 qnv = mk(S.q_n.x, S.q_n.y, S.q_n.z), qmv = mk(S.q_m.x, S.q_m.y, S.q_m.z);
+    const V3 tt = -(qLmul(S.q_n, -1.0, qLmul(S.q_m, -1.0, u)) + dot(qmv, u) * qnv);         // (0,0)
+    const V3 tg = qLmul(S.q_rminus, -1.0, colcm(f.J_q, cc));                                 // (0,3)
+    V3 vt = cross(S.Rb, u), pt = cross(S.Ra, u);                                             // (6,0) (12,0)
+    if (MODEL == 2) {
+        const V3 Lu = qLmul(S.q_kR, +1.0, u);
+        vt = vt - mulcm(f.O_beta, Lu);
+        pt = pt - mulcm(f.O_alpha, Lu);
+    }
+    const V3 jb = colcm(f.J_beta, cc), ja = colcm(f.J_alpha, cc), hb = colcm(f.H_beta, cc), ha = colcm(f.H_alpha, cc);
+    put3(h1 + 0, pick5(tt, tg, z, z, z, bc));
+    put3(h1 + 3, (bc == 1) ? -u : z);
+    put3(h1 + 6, pick5(vt, -jb, -S.rku, -hb, z, bc));
+    put3(h1 + 9, (bc == 3) ? -u : z);
+    put3(h1 + 12, pick5(pt, -ja, -(f.dt[0] * S.rku), -ha, -S.rku, bc));
 }
-CPI_HD double pick15(const double *e, int c) {
-    double r = e[0];
-    CPI_REG(r);
-#pragma unroll
-    for (int i = 1; i < 15; i++) { double t = e[i]; CPI_REG(t); r = (c == i) ? t : r; }
-    return r;
+// H2, column c: blkdiag(q_r,w I + [q_r,v]x, I, Rk, I, Rk)
+CPI_HD void factor_H2_column(const FactorShared &S, double h2[15]) {
+    const V3 u = S.u, z = mk(0, 0, 0);
+    const int bc = S.bc;
+    put3(h2 + 0, (bc == 0) ? qLmul(S.q_r, +1.0, u) : z);
+    put3(h2 + 3, (bc == 1) ? u : z);
+    put3(h2 + 6, (bc == 2) ? S.rku : z);
+    put3(h2 + 9, (bc == 3) ? u : z);
+    put3(h2 + 12, (bc == 4) ? S.rku : z);
 }
+template <int MODEL>
+CPI_HD void factor_eval_col(const FactorMeas &f, int c, double &err_c, double h1[15], double h2[15]) {
+    FactorShared S;
+    factor_shared<MODEL>(f, c, S);
+    err_c = S.err_c;
+    factor_H1_column<MODEL>(S, f, h1);
+    factor_H2_column(S, h2);
+}
+
 // State prediction (GraphSolver_IMU.cpp:263-281 / 289-307).
 template <int MODEL>
 CPI_HD NavState predict_state(const NavState &xi, V3 alpha, V3 beta, Q4 q_KtoK1, double dt, V3 grav) {

@@ -13,7 +13,6 @@ const int OUTD = 308;  // DT1 alpha3 beta3 q4 R9 Jq9 Ja9 Jb9 Ha9 Hb9 Oa9 Ob9 P22
 void put_cm(double *dst, const M3 &A) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) dst[j * 3 + i] = A.m[i][j]; }
 V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
 M3 ld_cm(const double *p) { M3 A; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A.m[i][j] = p[j * 3 + i]; return A; }
-Q4 ldq(const double *p) { Q4 q; q.x = p[0]; q.y = p[1]; q.z = p[2]; q.w = p[3]; return q; }
 
 template <int MODEL, bool JAC, bool AVG>
 void mean_window(int L, int n, const double *kn, const double *lin, const double *qk, const double *grav, double *o) {
@@ -127,18 +126,15 @@ extern "C" void hs_factor(int model, long F, const double *rec, const double *xi
     for (long k = 0; k < F; k++) {
         const double *r = rec + k * 87;
         FactorMeas f;
-        f.alpha = ld3(r); f.beta = ld3(r + 3); f.q_KtoK1 = ldq(r + 6); f.ba_lin = ld3(r + 10); f.bg_lin = ld3(r + 13);
-        f.J_q = ld_cm(r + 16); f.J_beta = ld_cm(r + 25); f.J_alpha = ld_cm(r + 34); f.H_beta = ld_cm(r + 43); f.H_alpha = ld_cm(r + 52);
-        f.dt = r[61]; f.grav = ld3(r + 62); f.q_K_lin = ldq(r + 65); f.O_beta = ld_cm(r + 69); f.O_alpha = ld_cm(r + 78);
-        NavState a, b;
-        const double *p = xi + k * 16; a.q = ldq(p); a.bg = ld3(p + 4); a.v = ld3(p + 7); a.ba = ld3(p + 10); a.p = ld3(p + 13);
-        p = xj + k * 16; b.q = ldq(p); b.bg = ld3(p + 4); b.v = ld3(p + 7); b.ba = ld3(p + 10); b.p = ld3(p + 13);
-        FactorBlocks o;
-        if (model == 1) factor_eval<1>(f, a, b, o); else factor_eval<2>(f, a, b, o);
-        for (int i = 0; i < 15; i++) err[k * 15 + i] = pick15(o.err, i);
+        f.alpha = r; f.beta = r + 3; f.q_KtoK1 = r + 6;
+        double lin6[6] = { r[13], r[14], r[15], r[10], r[11], r[12] };   // record order is ba_lin, bg_lin
+        f.lin = lin6;
+        f.J_q = r + 16; f.J_beta = r + 25; f.J_alpha = r + 34; f.H_beta = r + 43; f.H_alpha = r + 52;
+        f.dt = r + 61; f.grav = ld3(r + 62); f.q_K_lin = r + 65; f.O_beta = r + 69; f.O_alpha = r + 78;
+        f.xi = xi + k * 16; f.xj = xj + k * 16;
         for (int c = 0; c < 15; c++) {
-            factor_H1_col(o, f, c, H1 + k * 225 + c * 15);
-            factor_H2_col(o, c, H2 + k * 225 + c * 15);
+            if (model == 1) factor_eval_col<1>(f, c, err[k * 15 + c], H1 + k * 225 + c * 15, H2 + k * 225 + c * 15);
+            else factor_eval_col<2>(f, c, err[k * 15 + c], H1 + k * 225 + c * 15, H2 + k * 225 + c * 15);
         }
     }
 }
