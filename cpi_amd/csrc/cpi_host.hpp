@@ -13,6 +13,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -176,6 +177,70 @@ public:
 private:
     std::vector<CpiBase *> win_;
 };
+
+// ---- caller-side data formats --------------------------------------------
+// The reference's simulated-IMU wire format, one reading per line "wx wy wz ax ay az 0 t_ms"
+// (cpi_compare/src/sim/SimParser.h:130-193: fields split on single spaces, empty fields skipped, column 8 is
+// the stamp in milliseconds).  Returns knot records {t[s], w[3], a[3]}.
+inline std::vector<double> parse_imu_text(const std::string &text) {
+    std::vector<double> knots;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        double f[8];
+        int nf = 0;
+        size_t p = pos;
+        while (p < eol && nf < 8) {
+            while (p < eol && text[p] == ' ') p++;
+            if (p >= eol) break;
+            size_t q = p;
+            while (q < eol && text[q] != ' ') q++;
+            f[nf++] = std::atof(text.substr(p, q - p).c_str());
+            p = q;
+        }
+        if (nf == 8) {
+            knots.push_back(1e-3 * f[7]);
+            for (int i = 0; i < 6; i++) knots.push_back(f[i]);
+        }
+        pos = eol + 1;
+    }
+    return knots;
+}
+
+// Cutting ONE IMU stream into preintegration windows at successive update times exactly like
+// GraphSolver::createimufactor_cpi_v1/v2 (GraphSolver_IMU.cpp:50-69): whole intervals while
+// imu_times[1] <= updatetime, then the partial tail interval with the front reading repeated, after which the
+// front stamp is overwritten by the update time.  Output is the knots/first/count layout of cpi_amd.h.
+struct WindowSet {
+    std::vector<double> knots;
+    std::vector<int64_t> first;
+    std::vector<int32_t> count;
+    int32_t max_count = 0;
+};
+inline WindowSet assemble_windows(const std::vector<double> &stream, const std::vector<double> &update_times) {
+    WindowSet ws;
+    const size_t K = stream.size() / 7;
+    if (K == 0) return ws;
+    size_t front = 0;
+    double front_t = stream[0];
+    auto push = [&](double t, const double *r) { ws.knots.push_back(t); for (int i = 1; i < 7; i++) ws.knots.push_back(r[i]); };
+    for (double T : update_times) {
+        ws.first.push_back((int64_t)(ws.knots.size() / 7));
+        push(front_t, &stream[front * 7]);
+        int32_t n = 0;
+        while (K - front > 1 && stream[(front + 1) * 7] <= T) {
+            front++;
+            front_t = stream[front * 7];
+            push(front_t, &stream[front * 7]);   // dt < 0 intervals stay in the list: the kernels skip them
+            n++;
+        }
+        if (T - front_t > 0) { push(T, &stream[front * 7]); front_t = T; n++; }
+        ws.count.push_back(n);
+        if (n > ws.max_count) ws.max_count = n;
+    }
+    return ws;
+}
 
 // evaluateError-shaped evaluator (ImuFactorCPIv1.h:139 / ImuFactorCPIv2.h:151).  state = 16 doubles
 // [q(4) bg(3) v(3) ba(3) p(3)]; error[15]; H1/H2 column-major 15x15, may be nullptr.

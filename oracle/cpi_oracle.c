@@ -558,6 +558,34 @@ void cpi_oracle_batch(const cpi_oracle_params *prm, long W, int n, const double 
                    q_k_lin ? q_k_lin + (size_t)w * 4 : NULL, out + w, NULL);
 }
 
+/* GraphSolver_IMU.cpp:50-69 with the three deques replaced by a front index into the stream plus the
+ * (possibly overwritten) front timestamp. */
+void cpi_oracle_stream(const cpi_oracle_params *prm, long K, const double *stream, long U,
+                       const double *update_times, const double *lin, const double *q_k_lin, cpi_oracle_out *out) {
+    long front = 0;                       /* index of imu_*.at(0) in the stream */
+    double front_t = stream[0];           /* imu_times.at(0): overwritten by updatetime after a tail interval */
+    cpi_state *s = (cpi_state *)malloc(sizeof(cpi_state));
+    for (long u = 0; u < U; u++) {
+        const double updatetime = update_times[u];
+        state_init(s, prm, lin + u * 6, q_k_lin ? q_k_lin + u * 4 : NULL);
+        while ((K - front) > 1 && stream[(front + 1) * 7] <= updatetime) {
+            const double *k0 = stream + front * 7, *k1 = stream + (front + 1) * 7;
+            double dt = k1[0] - front_t;
+            if (dt >= 0) feed_imu(s, front_t, k1[0], k0 + 1, k0 + 4, k1 + 1, k1 + 4);
+            front++;                       /* erase(begin()) */
+            front_t = stream[front * 7];
+        }
+        double dt_f = updatetime - front_t;
+        if (dt_f > 0) {
+            const double *k0 = stream + front * 7;
+            feed_imu(s, front_t, updatetime, k0 + 1, k0 + 4, k0 + 1, k0 + 4);
+            front_t = updatetime;          /* imu_times.at(0) = updatetime */
+        }
+        state_export(s, out + u);
+    }
+    free(s);
+}
+
 typedef struct {
     const cpi_oracle_params *prm; long w0, w1; int n;
     const double *knots, *lin, *q; cpi_oracle_out *out;

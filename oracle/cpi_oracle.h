@@ -56,6 +56,15 @@ void cpi_oracle_window_trace(const cpi_oracle_params *prm, int n, const double *
 void cpi_oracle_batch(const cpi_oracle_params *prm, long W, int n, const double *knots,
                       const double *lin, const double *q_k_lin, cpi_oracle_out *out);
 
+/* Window assembly exactly as GraphSolver::createimufactor_cpi_v1/v2 does it (GraphSolver_IMU.cpp:50-69): ONE
+ * IMU stream (K knots {t,w,a}) is consumed front to back by U successive update times; each update
+ * integrates whole intervals while imu_times[1] <= updatetime, then the partial tail interval
+ * [imu_times[0], updatetime] with the front reading repeated, and overwrites imu_times[0] = updatetime.
+ * lin [U][6], q_k_lin [U][4] (may be NULL for model 1); out [U]. */
+void cpi_oracle_stream(const cpi_oracle_params *prm, long K, const double *stream, long U,
+                       const double *update_times, const double *lin, const double *q_k_lin,
+                       cpi_oracle_out *out);
+
 /* Same, spread over nthreads pthreads (CPU baseline on all host cores). */
 void cpi_oracle_batch_mt(const cpi_oracle_params *prm, long W, int n, const double *knots,
                          const double *lin, const double *q_k_lin, cpi_oracle_out *out,

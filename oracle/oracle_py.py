@@ -117,7 +117,7 @@ def reference():
 class _OracleLib(_Lib):
     def __init__(self, path):
         super().__init__(path, "cpi_oracle")
-        for name in ("cpi_oracle_window_trace", "cpi_oracle_factor_v1", "cpi_oracle_factor_v2",
+        for name in ("cpi_oracle_window_trace", "cpi_oracle_stream", "cpi_oracle_factor_v1", "cpi_oracle_factor_v2",
                      "cpi_oracle_predict", "cpi_oracle_retract", "cpi_oracle_local"):
             getattr(self.lib, name).restype = None
 
@@ -128,6 +128,17 @@ class _OracleLib(_Lib):
         lin1 = np.ascontiguousarray(lin1, dtype=np.float64)
         q1 = None if q1 is None else np.ascontiguousarray(q1, dtype=np.float64)
         self.lib.cpi_oracle_window_trace(C.byref(prm), C.c_int(n), _dp(knots1), _dp(lin1), _dp(q1), _dp(raw))
+        return split_out(raw)
+
+    def stream(self, prm, stream_knots, update_times, lin, q_k_lin=None):
+        """GraphSolver_IMU.cpp:50-69 window assembly + preintegration over one IMU stream."""
+        st = np.ascontiguousarray(stream_knots, dtype=np.float64)
+        ut = np.ascontiguousarray(update_times, dtype=np.float64)
+        lin = np.ascontiguousarray(lin, dtype=np.float64)
+        q = None if q_k_lin is None else np.ascontiguousarray(q_k_lin, dtype=np.float64)
+        raw = np.zeros((ut.shape[0], OUT_DOUBLES))
+        self.lib.cpi_oracle_stream(C.byref(prm), C.c_long(st.shape[0]), _dp(st), C.c_long(ut.shape[0]), _dp(ut), _dp(lin),
+                                   _dp(q), _dp(raw))
         return split_out(raw)
 
     def factor(self, model, frec, xi, xj, want_H=True):
