@@ -28,6 +28,18 @@ FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernel
 BYTES = {"v1_mean": 2856 + 88, "v1_full": 2856 + 2320, "v2_full": 2888 + 2392,
          "factor_v1": 776 + 3720, "factor_v2": 952 + 3720}
 MALL_BYTES = 256 << 20
+# HBM traffic per launch measured with separate rocprofv3 --pmc passes of the same workloads
+# (profiles/r01_pmc_counters.md) and corrected as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE / WRITE_SIZE are
+# KiB and gfx950's FETCH_SIZE reports half of a streaming read -> bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.
+# bench.py cannot collect PMC counters itself (that needs the rocprofv3 wrapper), so the figure is only reported for
+# the exact (workload, size) it was measured on; any other configuration reports null.
+PMC_TRAFFIC_KIB = {("v1_mean", 10000, 50): (15402.9, 859.4), ("v1_mean", 1000000, 50): (1818710.0, 85946.0),
+                   ("v2_full", 100000, 50): (150127.0, 242188.0), ("factor_v1", 1000000, 50): (421995.0, 3882790.0)}
+
+
+def pmc_traffic(workload, W, N):
+    t = PMC_TRAFFIC_KIB.get((workload, W, N))
+    return None if t is None else (2.0 * t[0] + t[1]) * 1024.0
 
 
 def parse():
@@ -190,7 +202,9 @@ def main():
             ", CPI model 1, mean-only (BASELINE.json configs[1])" if a.workload == "v1_mean" and W == 10000 else ""),
             "pool_batches": wl.nbatch, "parallelism": "windows sharded over %d GPU(s), final all_gather" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a.workload, W, a.samples),
+                     "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_counters.md)",
+                     "algorithmic_bytes_per_launch": BYTES[a.workload] * W,
                      "kernel": {"v1_mean": "cpi_mean_kernel", "v1_full": "cpi_cov_kernel<1>", "v2_full": "cpi_cov_kernel<2>",
                                 "factor_v1": "cpi_factor_kernel<1>", "factor_v2": "cpi_factor_kernel<2>"}[a.workload],
                      "launch_us": launch_s * 1e6, "algorithmic_bytes_per_unit": BYTES[a.workload]},

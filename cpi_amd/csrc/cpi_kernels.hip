@@ -263,10 +263,10 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
 // ============================================================================================
 // covariance (+ state transition) kernel
 // ============================================================================================
-// Measured on MI355X: the 18+9-column model-2 recursion is faster with two co-resident wavefronts per SIMD
-// (<= 256 registers, a few spilled values) than alone with 342; the 15-column model-1 one is the reverse.
+// Measured on MI355X: forcing two co-resident wavefronts per SIMD (<= 256 registers) costs spills and does not pay;
+// the recursion runs one wavefront per SIMD and hides LDS latency with instruction-level parallelism instead.
 template <int MODEL, bool AVG>
-__global__ __launch_bounds__(64, (MODEL == 2 ? 2 : 1)) void cpi_cov_kernel(PreArgs A) {
+__global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
     typedef CovDims<MODEL> D;
     constexpr int GROUP = D::GROUP;   // lanes per window
     constexpr int G = 64 / GROUP;     // windows per wavefront
