@@ -403,6 +403,7 @@ struct FactorArgs {
     double *err;
     double *H1;
     double *H2;
+    const double *sqrt_info;   // optional [F][225] upper-triangular R: outputs are whitened (R err, R H1, R H2)
 };
 
 __device__ __forceinline__ NavState ld_state(const double *p) {
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     constexpr int FPW = 4;                       // factors per wavefront
     constexpr int HB = FPW * 225;                // doubles of H1 (or H2) per wavefront
     __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
+    __shared__ __attribute__((aligned(16))) double sR[HB];                  // whitening only: the 4 factors' R
     const int lane = threadIdx.x;
     const int c = lane & 15, fl = lane >> 4;
     const long long f0 = (long long)blockIdx.x * FPW;
@@ -465,6 +467,24 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     factor_shared<MODEL>(m, min(c, 14), S);
     double h1[15];
     if (A.H1) factor_H1_column<MODEL>(S, m, h1);
+    // ---- optional whitening (GTSAM Gaussian::WhitenSystem): y = R x with R upper triangular, column-major
+    const bool whiten = A.sqrt_info != nullptr;
+    const double *Rf = sR + fl * 225;
+    if (whiten) {
+        const long long nfac = min((long long)FPW, A.F - f0);
+        for (int i = lane; i < (int)nfac * 225; i += 64) sR[i] = A.sqrt_info[f0 * 225 + i];
+        wave_lds_fence();
+    }
+    auto whiten_col = [&](double *h) {   // in place: out[i] = sum_{k >= i} R[i][k] h[k]
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = i; k < 15; k++) acc = fma(Rf[k * 15 + i], h[k], acc);
+            h[i] = acc;                   // rows are finished top-down, so h[k], k > i, is still unwhitened
+        }
+    };
+    if (whiten && A.H1) whiten_col(h1);
     wave_lds_fence();   // every lane is done reading the input staging area (in-order DS)
 
     // ---- this lane's column -> LDS (layout identical to the global layout of this wavefront's span) -> HBM,
@@ -483,6 +503,15 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
             for (int i = lane; i < n; i += 64) dst[i] = src[i];
         }
     };
+    if (whiten) {   // R err needs the whole residual: exchange it through LDS first
+        if (c < 15) se[fl * 15 + c] = S.err_c;
+        wave_lds_fence();
+        double acc = 0.0;
+        const int cr = min(c, 14);
+        for (int k = 0; k < 15; k++) acc = fma((k >= cr) ? Rf[k * 15 + cr] : 0.0, se[fl * 15 + k], acc);
+        wave_lds_fence();
+        S.err_c = acc;
+    }
     if (c < 15) {
         se[fl * 15 + c] = S.err_c;
         if (A.H1) {
@@ -498,12 +527,54 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
         if (c < 15) {
             double h2[15];
             factor_H2_column(S, h2);
+            if (whiten) whiten_col(h2);
 #pragma unroll
             for (int i = 0; i < 15; i++) s1[fl * 225 + c * 15 + i] = h2[i];
         }
         wave_lds_fence();
         flush(A.H2 + f0 * 225, s1, nd);
     }
+}
+
+// R = chol_upper(P^-1) = B^-1 with P = B B^T, B upper triangular ("reverse" Cholesky, from the last pivot up).
+// 16 lanes per factor, the working matrix in LDS; lane j owns column j.  One-off per factor (GTSAM builds the
+// noise model in the factor constructor), so clarity over speed.
+__global__ __launch_bounds__(64) void cpi_sqrt_info_kernel(long long F, const double *P, double *Rout) {
+    constexpr int FPW = 4;
+    __shared__ __attribute__((aligned(16))) double sA[FPW * 225];   // working copy / B (column-major)
+    __shared__ __attribute__((aligned(16))) double sU[FPW * 225];   // B^-1
+    const int lane = threadIdx.x, j = lane & 15, fl = lane >> 4;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const long long nf = min((long long)FPW, F - f0);
+    for (int i = lane; i < (int)nf * 225; i += 64) { sA[i] = P[f0 * 225 + i]; sU[i] = 0.0; }
+    wave_lds_fence();
+    double *A = sA + fl * 225, *U = sU + fl * 225;
+    const bool act = (fl < nf) && (j < 15);
+    // P = B B^T: for k = 14..0:  B[k][k] = sqrt(A[k][k]);  B[i][k] = A[i][k] / B[k][k] (i < k);
+    //                           A[i][j] -= B[i][k] B[j][k]  (i <= j < k)
+    for (int k = 14; k >= 0; --k) {
+        const double bkk = sqrt(A[k * 15 + k]);
+        wave_lds_fence();
+        if (act && j <= k) A[k * 15 + j] = (j == k) ? bkk : A[k * 15 + j] / bkk;   // lane j = row j of column k
+        wave_lds_fence();
+        if (act && j < k) {
+            const double bjk = A[k * 15 + j];
+            for (int i = 0; i <= j; ++i) A[j * 15 + i] -= A[k * 15 + i] * bjk;      // column j, rows i <= j
+        }
+        wave_lds_fence();
+    }
+    // U = B^-1 (upper): column j by back substitution, U[j][j] = 1/B[j][j],
+    //   U[i][j] = -(sum_{m=i+1..j} B[i][m] U[m][j]) / B[i][i]
+    if (act) {
+        U[j * 15 + j] = 1.0 / A[j * 15 + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double sacc = 0.0;
+            for (int m = i + 1; m <= j; ++m) sacc = fma(A[m * 15 + i], U[j * 15 + m], sacc);
+            U[j * 15 + i] = -sacc / A[i * 15 + i];
+        }
+    }
+    wave_lds_fence();
+    for (int i = lane; i < (int)nf * 225; i += 64) Rout[f0 * 225 + i] = sU[i];
 }
 
 struct PredictArgs {
@@ -681,10 +752,20 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     return CPI_OK;
 }
 
+static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F, const cpi_outputs *meas,
+                            const double *lin, const double *q_k_lin, const double *states, const int32_t *idx_i,
+                            const int32_t *idx_j, const double *sqrt_info, double *err, double *H1, double *H2);
+
 extern "C" int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                                      const cpi_outputs *meas, const double *lin, const double *q_k_lin,
                                      const double *states, const int32_t *idx_i, const int32_t *idx_j,
                                      double *err, double *H1, double *H2) {
+    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, idx_i, idx_j, nullptr, err, H1, H2);
+}
+
+static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F, const cpi_outputs *meas,
+                            const double *lin, const double *q_k_lin, const double *states, const int32_t *idx_i,
+                            const int32_t *idx_j, const double *sqrt_info, double *err, double *H1, double *H2) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: model must be 1 or 2");
     if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: negative size");
@@ -700,12 +781,32 @@ extern "C" int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double g
     a.F = F;
     for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
     a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.idx_i = idx_i; a.idx_j = idx_j;
-    a.err = err; a.H1 = H1; a.H2 = H2;
+    a.err = err; a.H1 = H1; a.H2 = H2; a.sqrt_info = sqrt_info;
     const long long nb = (F + 3) / 4;
     if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_kernel<1>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
     else hipLaunchKernelGGL((cpi_factor_kernel<2>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
+}
+
+extern "C" int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double *P, double *sqrt_info) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: negative size");
+    if (F == 0) return CPI_OK;
+    if (!P || !sqrt_info) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: NULL argument");
+    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    const long long nb = (F + 3) / 4;
+    hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, (long long)F, P, sqrt_info);
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+
+extern "C" int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                              const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                              const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                              const double *sqrt_info, double *err, double *H1, double *H2) {
+    if (ctx && !sqrt_info) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_whitened_batch: sqrt_info is NULL");
+    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, idx_i, idx_j, sqrt_info, err, H1, H2);
 }
 
 extern "C" int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,

@@ -116,8 +116,16 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ factors
+    def sqrt_information(self, P):
+        """R = chol_upper(P^-1) per factor (GTSAM noiseModel::Gaussian::Covariance); P [F,225] -> R [F,225]."""
+        F = P.shape[0]
+        R = torch.empty((F, 225), dtype=torch.float64, device=self.device)
+        self._check(self.lib.cpi_sqrt_information_batch(self.ctx, F, _ptr(P), _ptr(R)))
+        return R
+
     def factor_eval(self, model, meas, lin, q_k_lin, states, idx_i=None, idx_j=None, want_H=True, grav=DEFAULT_GRAV,
-                    out=None):
+                    out=None, sqrt_info=None):
+        """sqrt_info [F,225] (from sqrt_information): return the WHITENED residual / Jacobians (R e, R H1, R H2)."""
         F = lin.shape[0]
         if out is None:
             out = {"err": torch.empty((F, 15), dtype=torch.float64, device=self.device)}
@@ -126,9 +134,15 @@ class Engine:
                 out["H2"] = torch.empty((F, 225), dtype=torch.float64, device=self.device)
         m = self._outputs_struct(meas)
         g = (C.c_double * 3)(*grav)
-        self._check(self.lib.cpi_factor_eval_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin),
-                                                   _ptr(states), _ptr(idx_i), _ptr(idx_j), _ptr(out["err"]),
-                                                   _ptr(out.get("H1")), _ptr(out.get("H2"))))
+        if sqrt_info is None:
+            self._check(self.lib.cpi_factor_eval_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin),
+                                                       _ptr(states), _ptr(idx_i), _ptr(idx_j), _ptr(out["err"]),
+                                                       _ptr(out.get("H1")), _ptr(out.get("H2"))))
+        else:
+            self._check(self.lib.cpi_factor_eval_whitened_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin),
+                                                                _ptr(q_k_lin), _ptr(states), _ptr(idx_i), _ptr(idx_j),
+                                                                _ptr(sqrt_info), _ptr(out["err"]), _ptr(out.get("H1")),
+                                                                _ptr(out.get("H2"))))
         return out
 
     def predict(self, model, meas, states_i, idx_i=None, grav=DEFAULT_GRAV):

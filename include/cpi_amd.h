@@ -113,6 +113,22 @@ int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int
                           const double *states, const int32_t *idx_i, const int32_t *idx_j,
                           double *err, double *H1, double *H2);
 
+/* Replaces: gtsam::noiseModel::Gaussian::Covariance(P_meas) in the factor constructors
+ * (ImuFactorCPIv1.h:82, ImuFactorCPIv2.h:86).  GTSAM (bitbucket gtborg/gtsam @ c21186c6, not in the
+ * reference tree) builds the square-root information  R = chol_upper(P^-1)  (Gaussian::Covariance ->
+ * Gaussian::Information(cov.inverse()) -> Eigen::LLT::matrixU) once per factor, R^T R = P^-1.
+ * Here R = B^-1 with P = B B^T, B upper triangular (the same matrix, obtained without forming P^-1).
+ * P [F][225] column-major symmetric positive definite; sqrt_info [F][225] column-major upper triangular
+ * (strict lower part written as zeros).  A non-positive pivot yields NaNs in that factor's R. */
+int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double *P, double *sqrt_info);
+
+/* cpi_factor_eval_batch followed by GTSAM's NoiseModelFactor::linearize whitening
+ * (Gaussian::WhitenSystem): err <- R err, H1 <- R H1, H2 <- R H2 with R = sqrt_info[f]. */
+int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                   const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                   const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                   const double *sqrt_info, double *err, double *H1, double *H2);
+
 /* Replaces: GraphSolver::getpredictedstate_v1 / _v2 (GraphSolver_IMU.cpp:263-281, 289-307):
  * states_j[f] = prediction of X(k+1) from states_i[idx_i[f]] and measurement f. */
 int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
