@@ -66,6 +66,17 @@ __device__ __forceinline__ M3 shfl_down(const M3 &A, int d) {
         for (int j = 0; j < 3; j++) r.m[i][j] = __shfl_down(A.m[i][j], d);
     return r;
 }
+__device__ __forceinline__ V3 shfl_down(V3 v, int d, int width) {
+    return mk(__shfl_down(v.x, d, width), __shfl_down(v.y, d, width), __shfl_down(v.z, d, width));
+}
+__device__ __forceinline__ M3 shfl_up(const M3 &A, int d, int width) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = __shfl_up(A.m[i][j], d, width);
+    return r;
+}
 template <bool JAC>
 __device__ __forceinline__ MeanState<JAC> shfl_down(const MeanState<JAC> &s, int d) {
     MeanState<JAC> r;
@@ -265,16 +276,27 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
 // ============================================================================================
 // Measured on MI355X: forcing two co-resident wavefronts per SIMD (<= 256 registers) costs spills and does not pay;
 // the recursion runs one wavefront per SIMD and hides LDS latency with instruction-level parallelism instead.
+// Two co-resident wavefronts per SIMD hide the LDS exchange latency of the recursion: <= 256 registers and
+// <= 20 KB of LDS per wavefront.  The latter is why a phase-A pass stages GROUP/2 intervals per window
+// (half the lanes take part in it); measured on MI355X against the one-wave-per-SIMD variant:
+// model 2 5.0 -> 3.8 ms, model 1 2.27 -> 2.0 ms per 100 k windows.
+#ifndef CPI_COV_WPS
+#define CPI_COV_WPS 2
+#endif
+#ifndef CPI_COV_CHDIV
+#define CPI_COV_CHDIV 2
+#endif
 template <int MODEL, bool AVG>
-__global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
+__global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     typedef CovDims<MODEL> D;
     constexpr int GROUP = D::GROUP;   // lanes per window
     constexpr int G = 64 / GROUP;     // windows per wavefront
-    constexpr int CH = GROUP;         // intervals per window processed by one phase-A pass
-    constexpr int RD = SAMPLE_REC_DOUBLES;
+    constexpr int CH = GROUP / CPI_COV_CHDIV;   // intervals per window processed by one phase-A pass
     constexpr int EP = EXCH_PITCH;
-    __shared__ __attribute__((aligned(16))) double recs[64 * RD];
-    __shared__ __attribute__((aligned(16))) double exch[G * EXCH_ROWS * EP];
+    constexpr int IRD = IrSize<MODEL>::V;
+    __shared__ __attribute__((aligned(16))) double irs[G * CH * IRD];          // interval records (phase A -> C)
+    __shared__ __attribute__((aligned(16))) double exch[(G * EXCH_GROUP_ROWS + EXCH_SHARED_ROWS) * EP];   // transpose exchange
+    __shared__ __attribute__((aligned(16))) double gsh[G * GS_DOUBLES];        // carried rotation / means per window
 
     const int lane = threadIdx.x;
     const int g = lane / GROUP, j = lane % GROUP;
@@ -293,18 +315,24 @@ __global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
     const int jj = min(j, (int)D::NCOL);  // idle lanes (j >= NCOL) run as a harmless zero transition column
     CovLane<MODEL> Ln;
     cov_init(Ln, jj, q4);
-    double *ex_g = exch + g * EXCH_ROWS * EP;
-    const double *ex_row = ex_g + cov_read_row<MODEL>(jj) * EP;
-    for (int i = lane; i < G * EXCH_ROWS * EP; i += 64) exch[i] = 0.0;
+    double *ex_g = exch + g * EXCH_GROUP_ROWS * EP;
+    double *ex_shared = exch + G * EXCH_GROUP_ROWS * EP;
+    const double *ex_row = cov_row_ptr<MODEL>(ex_g, ex_shared, jj);
+    const int hoff = cov_h_offset<MODEL>(jj);
+    double *gs = gsh + g * GS_DOUBLES;
+    for (int i = lane; i < (G * EXCH_GROUP_ROWS + EXCH_SHARED_ROWS) * EP; i += 64) exch[i] = 0.0;
+    if (j == 0) cov_gs_init(gs);
     __syncthreads();
-    cov_exch_init<MODEL>(ex_g, jj, q4);
+    cov_exch_init<MODEL>(ex_shared, jj, q4);
 
     for (int base = 0; base < nmax; base += CH) {
-        // ---- phase A: lane (g, j) evaluates the closed forms of interval base + j of its window
+        // ---- phase A: lane (g, j) owns interval base + j of its window: closed forms, then the running rotation
+        // at its start by a prefix product over the group's lanes, then everything phase C shares
         {
+            const bool part = j < CH;                  // lanes taking part in this pass
             const int s = base + j;
             SampleRec r;
-            if (s < n) {
+            if (part && s < n) {
                 const double *ka = A.knots + (k0 + s) * 7;
                 double a[14];
 #pragma unroll
@@ -315,20 +343,42 @@ __global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
                 r.dt = 0; r.w = mk(0, 0, 0); r.a0 = mk(0, 0, 0); r.a1 = mk(0, 0, 0);
                 r.f1 = r.f2 = r.f3 = r.f4 = 0; r.Rstep = eye(); r.Rhalf = eye();
             }
-            rec_store(recs + (g * CH + j) * RD, r);
+            M3 inc = r.Rstep;   // inclusive prefix product (later factors on the left), Hillis-Steele
+#pragma unroll
+            for (int d = 1; d < CH; d <<= 1) {
+                const M3 t = shfl_up(inc, d, GROUP);
+                if (j >= d) inc = mm(inc, t);
+            }
+            M3 pre = shfl_up(inc, 1, GROUP);
+            if (j == 0) pre = eye();
+            const M3 Rc = rec_mat(gs, GS_R);                       // rotation carried in from the previous chunk
+            double *irw = irs + (g * CH + min(j, CH - 1)) * IRD;
+            MeanInc mi;
+            if (part) mi = finish_interval<MODEL, AVG>(r, mm(pre, Rc), gk, irw);
+            else { mi.alpha = mk(0, 0, 0); mi.beta = mk(0, 0, 0); mi.dt = 0; }
+#pragma unroll
+            for (int d = 1; d < CH; d <<= 1) {                     // ordered reduction: lane j <- j (earlier) o j+d (later)
+                MeanInc o;
+                o.beta = shfl_down(mi.beta, d, GROUP); o.alpha = shfl_down(mi.alpha, d, GROUP);
+                o.dt = __shfl_down(mi.dt, d, GROUP);
+                mi = inc_combine(mi, o);
+            }
+            wave_lds_fence();   // every lane has read the carried rotation
+            if (j == 0) gs_apply_inc(gs, mi);
+            if (j == CH - 1) rec_put_mat(gs, GS_R, mm(inc, Rc));
         }
-        __syncthreads();
+        wave_lds_fence();
 
-        // ---- phase C: sequential recursion over the staged intervals
+        // ---- phase C: sequential RK4 recursion over the staged intervals; F x is lane-local, P F^T arrives
+        // through the exchange rows
         const int cnt = min(CH, nmax - base);
         for (int sl = 0; sl < cnt; ++sl) {
-            const double *rp = recs + (g * CH + sl) * RD;  // group-uniform address: LDS broadcast
-            cov_begin<MODEL, AVG>(Ln, rp, gk);
+            const double *ir = irs + (g * CH + sl) * IRD;  // group-uniform address: LDS broadcast
+            cov_begin<MODEL>(Ln, ir, hoff);
 #pragma unroll
             for (int stg = 0; stg < 4; ++stg) {
-                cov_stage_rot(Ln, stg, rp);
                 double M[9];
-                cov_stage_M(Ln, stg, M);
+                cov_stage_M(Ln, stg, ir, M);
                 if (j < D::NPCOL) {
 #pragma unroll
                     for (int rr = 0; rr < 9; rr++) ex_g[rr * EP + j] = M[rr];
@@ -339,7 +389,7 @@ __global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
                 wave_lds_fence();
                 cov_stage_finish(Ln, stg, M, ex_row);
             }
-            cov_end(Ln, rp);
+            cov_end(Ln);
             if (MODEL == 2) {  // column clone: columns 15:18 := columns 0:3 (CpiV2.h:436-441)
                 const int src = (j >= 15 && j < 18) ? lane - 15 : lane;
 #pragma unroll
@@ -349,7 +399,7 @@ __global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
                 }
             }
         }
-        __syncthreads();
+        wave_lds_fence();
     }
 
     if (!valid) return;
@@ -359,11 +409,11 @@ __global__ __launch_bounds__(64) void cpi_cov_kernel(PreArgs A) {
         for (int i = 0; i < 15; i++) p[i] = Ln.P0[i];
     }
     if (A.write_means && j == 0) {
-        if (A.out.DT) A.out.DT[w] = Ln.DT;
-        if (A.out.alpha) stv3(A.out.alpha + w * 3, Ln.alpha);
-        if (A.out.beta) stv3(A.out.beta + w * 3, Ln.beta);
+        if (A.out.DT) A.out.DT[w] = gs[GS_DT];
+        if (A.out.alpha) stv3(A.out.alpha + w * 3, rec_v3(gs, GS_ALPHA));
+        if (A.out.beta) stv3(A.out.beta + w * 3, rec_v3(gs, GS_BETA));
         if (A.out.q) {
-            const Q4 q = rot_2_quat(Ln.R);
+            const Q4 q = rot_2_quat(rec_mat(gs, GS_R));
             double *p = A.out.q + w * 4;
             p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
         }
@@ -614,6 +664,20 @@ static int fail(cpi_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg; else g_create_err = msg;
     return code;
 }
+// Selects the context's device for the duration of a call and restores the caller's current device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t enter(int dev) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev == dev) return hipSuccess;
+        e = hipSetDevice(dev);
+        changed = (e == hipSuccess);
+        return e;
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
 #define CPI_HIP(ctx, call)                                                                      \
     do {                                                                                        \
         hipError_t e_ = (call);                                                                 \
@@ -645,7 +709,8 @@ extern "C" void cpi_ctx_destroy(cpi_ctx *ctx) { delete ctx; }
 extern "C" const char *cpi_last_error(const cpi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" int cpi_ctx_synchronize(cpi_ctx *ctx) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
-    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
     CPI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CPI_OK;
 }
@@ -713,7 +778,8 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     const bool want_cov = out->P != nullptr;
     if (!want_mean && !want_jac && !want_cov) return CPI_OK;
 
-    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
     PreArgs a;
     memset(&a, 0, sizeof a);
     a.W = W; a.N = N; a.knots = knots; a.first = (const long long *)first; a.count = count;
@@ -775,7 +841,9 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
         return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
     if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
         return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: model 2 needs q_k_lin, O_a, O_b");
-    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    if (F > ((int64_t)1 << 33)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: F too large for one launch");
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
     FactorArgs a;
     memset(&a, 0, sizeof a);
     a.F = F;
@@ -794,7 +862,8 @@ extern "C" int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double 
     if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: negative size");
     if (F == 0) return CPI_OK;
     if (!P || !sqrt_info) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: NULL argument");
-    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
     const long long nb = (F + 3) / 4;
     hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, (long long)F, P, sqrt_info);
     CPI_HIP(ctx, hipGetLastError());
@@ -818,7 +887,8 @@ extern "C" int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[
     if (F == 0) return CPI_OK;
     if (!grav || !meas || !states_i || !states_j || !meas->DT || !meas->alpha || !meas->beta || !meas->q)
         return fail(ctx, CPI_ERR_INVALID, "cpi_predict_batch: NULL argument");
-    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
     PredictArgs a;
     memset(&a, 0, sizeof a);
     a.F = F;
@@ -859,7 +929,8 @@ extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, 
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (!prm || !out || !knots || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch_host: NULL argument");
     if (W <= 0) return W == 0 ? CPI_OK : fail(ctx, CPI_ERR_INVALID, "negative size");
-    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
     if (!first) n_knots = W * (int64_t)(N + 1);
     DevBuf dk, df, dc, dl, dq, dout[12];
     CPI_UP(dk, knots, (size_t)n_knots * 7 * sizeof(double));
@@ -890,7 +961,8 @@ extern "C" int cpi_factor_eval_batch_host(cpi_ctx *ctx, int32_t model, const dou
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (!meas || !lin || !states || !err || !grav) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch_host: NULL argument");
     if (F <= 0) return F == 0 ? CPI_OK : fail(ctx, CPI_ERR_INVALID, "negative size");
-    CPI_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
     DevBuf dl, dq, ds, di, dj, de, dh1, dh2, dm[11];
     cpi_outputs hm = *meas, d;
     memset(&d, 0, sizeof d);

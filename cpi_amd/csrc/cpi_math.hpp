@@ -21,15 +21,11 @@
 #else
 #define CPI_HD inline
 #endif
-// Pin a value in a VGPR before it feeds a runtime select chain: stops LLVM from folding
-// "select of loads" into "load of a selected address", which would force the whole block to scratch.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define CPI_REG(x) asm volatile("" : "+v"(x))
 // Scheduling fence: keeps hipcc from hoisting every operand load of a long straight-line block to its top
 // (which maximises registers, i.e. minimises co-resident wavefronts, in kernels that are latency-bound).
 #define CPI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
-#define CPI_REG(x) ((void)0)
 #define CPI_SCHED_FENCE() ((void)0)
 #endif
 
@@ -104,14 +100,6 @@ CPI_HD M3 madd(const M3 &A, const M3 &B) {
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) r.m[i][j] = A.m[i][j] + B.m[i][j];
-    return r;
-}
-CPI_HD M3 maxpy(double s, const M3 &A, const M3 &B) {  // s A + B
-    M3 r;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) r.m[i][j] = fma(s, A.m[i][j], B.m[i][j]);
     return r;
 }
 CPI_HD V3 col(const M3 &A, int j) { return mk(A.m[0][j], A.m[1][j], A.m[2][j]); }
@@ -559,19 +547,6 @@ struct CovDims {
     static const int GROUP = (MODEL == 1) ? 16 : 32; // lanes per window
 };
 
-// Record layout (doubles) of SampleRec as staged in LDS by the kernel / in memory by the host emulator.
-static const int REC_DT = 0, REC_W = 1, REC_A0 = 4, REC_A1 = 7, REC_F = 10, REC_RSTEP = 14, REC_RHALF = 23;
-CPI_HD void rec_store(double *rp, const SampleRec &r) {
-    rp[REC_DT] = r.dt;
-    rp[REC_W] = r.w.x; rp[REC_W + 1] = r.w.y; rp[REC_W + 2] = r.w.z;
-    rp[REC_A0] = r.a0.x; rp[REC_A0 + 1] = r.a0.y; rp[REC_A0 + 2] = r.a0.z;
-    rp[REC_A1] = r.a1.x; rp[REC_A1 + 1] = r.a1.y; rp[REC_A1 + 2] = r.a1.z;
-    rp[REC_F] = r.f1; rp[REC_F + 1] = r.f2; rp[REC_F + 2] = r.f3; rp[REC_F + 3] = r.f4;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) { rp[REC_RSTEP + i * 3 + k] = r.Rstep.m[i][k]; rp[REC_RHALF + i * 3 + k] = r.Rhalf.m[i][k]; }
-}
 CPI_HD M3 rec_mat(const double *rp, int at) {
     M3 A;
 #pragma unroll
@@ -580,12 +555,84 @@ CPI_HD M3 rec_mat(const double *rp, int at) {
         for (int k = 0; k < 3; k++) A.m[i][k] = rp[at + i * 3 + k];
     return A;
 }
+CPI_HD void rec_put_mat(double *rp, int at, const M3 &A) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) rp[at + i * 3 + k] = A.m[i][k];
+}
 CPI_HD V3 rec_v3(const double *rp, int at) { return mk(rp[at], rp[at + 1], rp[at + 2]); }
+CPI_HD void put3(double *o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 
-// Exchange-buffer rows of one window group: 0..8 = rows (theta,v,p) of F X written every stage;
-// 9..14 = constant rows q_j e_j for the b_w / b_a covariance columns (their only k contribution is the
-// process noise on the diagonal); 15 = zeros (columns with no transposed row: clone and transition lanes).
-static const int EXCH_ROWS = 16;
+// ---- phase A -> phase C interval record (doubles; every vector / matrix starts on a 16-byte boundary).
+// Phase A does ALL the work that the lanes of a group share -- closed forms, the running rotation (a prefix
+// product over the chunk's intervals), the three RK4 stage rotations, gravity terms and the mean increments --
+// once per interval, lane-parallel over intervals; phase C only reads it back as LDS broadcasts.
+static const int IR_DT = 0, IR_W = 2, IR_A = 6, IR_GTAU = 10, IR_ROLD = 14, IR_RMID = 24, IR_RNEW = 34,
+                 IR_ZERO = 44, IR_H = 48 /* model 2: 3 vectors of 4, R_old (g_k x e_l), l = 0..2 */;
+template <int MODEL> struct IrSize { static const int V = (MODEL == 1) ? 48 : 60; };   // doubles per record
+// group-shared carry across chunks: running rotation and means
+static const int GS_R = 0, GS_ALPHA = 10, GS_BETA = 14, GS_DT = 18, GS_DOUBLES = 20;
+CPI_HD void cov_gs_init(double *gs) {
+#pragma unroll
+    for (int i = 0; i < GS_DOUBLES; i++) gs[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+}
+// The mean increment of one interval in the window-start frame, as a composable element:
+// (beta, alpha, dt) o (beta', alpha', dt') = (beta + beta', alpha + dt' beta + alpha', dt + dt')   (CpiV1.h:153-154)
+struct MeanInc { V3 beta, alpha; double dt; };
+CPI_HD MeanInc inc_combine(const MeanInc &A, const MeanInc &B) {   // A earlier, B later
+    MeanInc r;
+    r.alpha = A.alpha + (B.dt * A.beta + B.alpha);
+    r.beta = A.beta + B.beta;
+    r.dt = A.dt + B.dt;
+    return r;
+}
+// Finish one interval once its start rotation R_old is known: writes the phase-C record and returns the
+// interval's mean increment.  (CpiV1.h:123-154,267-269 / CpiV2.h:99,141-186,315-323)
+template <int MODEL, bool AVG>
+CPI_HD MeanInc finish_interval(const SampleRec &r, const M3 &R_old, V3 gk, double *ir) {
+    const M3 R_new = mm(r.Rstep, R_old), R_mid = mm(r.Rhalf, R_old);
+    V3 a = r.a0, gtau = mk(0, 0, 0);
+    if (MODEL == 2) {
+        gtau = mul(R_old, gk);
+        a = a - gtau;
+        if (AVG) a = 0.5 * (a + (r.a1 - mul(R_new, gk)));   // CpiV2.h:146-149: average the LOCAL acceleration
+    }
+    StepCoef k;
+    k.dt = r.dt; k.f1 = r.f1; k.f2 = r.f2; k.f3 = r.f3; k.f4 = r.f4;
+    V3 ua, ub;
+    arg_times(r.w, a, k, ua, ub);
+    MeanInc inc;
+    inc.alpha = mulT(R_new, ua);
+    inc.beta = mulT(R_new, ub);
+    inc.dt = r.dt;
+    ir[IR_DT] = r.dt; ir[IR_DT + 1] = 0.0;
+    put3(ir + IR_W, r.w); ir[IR_W + 3] = 0.0;
+    put3(ir + IR_A, a); ir[IR_A + 3] = 0.0;
+    put3(ir + IR_GTAU, gtau); ir[IR_GTAU + 3] = 0.0;
+    rec_put_mat(ir, IR_ROLD, R_old); ir[IR_ROLD + 9] = 0.0;
+    rec_put_mat(ir, IR_RMID, R_mid); ir[IR_RMID + 9] = 0.0;
+    rec_put_mat(ir, IR_RNEW, R_new); ir[IR_RNEW + 9] = 0.0;
+    if (MODEL == 2) {
+#pragma unroll
+        for (int l = 0; l < 3; l++) { put3(ir + IR_H + 4 * l, mul(R_old, cross(gk, unit(l)))); ir[IR_H + 4 * l + 3] = 0.0; }
+    }
+    ir[IR_ZERO] = 0.0; ir[IR_ZERO + 1] = 0.0; ir[IR_ZERO + 2] = 0.0; ir[IR_ZERO + 3] = 0.0;
+    return inc;
+}
+// Fold a chunk's composed increment into the carried means (gs): alpha += dt_c beta + alpha_c, beta += beta_c.
+CPI_HD void gs_apply_inc(double *gs, const MeanInc &c) {
+    const V3 beta = rec_v3(gs, GS_BETA);
+    put3(gs + GS_ALPHA, rec_v3(gs, GS_ALPHA) + (c.dt * beta + c.alpha));
+    put3(gs + GS_BETA, beta + c.beta);
+    gs[GS_DT] += c.dt;
+}
+
+// Exchange-buffer rows: per window group rows 0..8 = rows (theta,v,p) of F X, rewritten every stage; then,
+// shared by all groups of the wavefront, rows 9..14 = constant rows q_j e_j for the b_w / b_a covariance columns
+// (their only k contribution is the process noise on the diagonal) and row 15 = zeros (columns with no
+// transposed row: clone and transition lanes).
+static const int EXCH_GROUP_ROWS = 9, EXCH_SHARED_ROWS = 7;
 static const int EXCH_PITCH = 18;  // doubles: 16-B aligned rows on distinct LDS bank slots
 
 template <int MODEL>
@@ -593,15 +640,9 @@ struct CovLane {
     double P0[CovDims<MODEL>::NR];   // column at the start of the interval
     double X[CovDims<MODEL>::NR];    // RK4 stage value
     double acc[CovDims<MODEL>::NR];  // running RK4 sum
-    V3 xl;                           // theta_klin part of the column (constant; non-zero only for 3 D-columns)
     V3 hqt, hqv;                     // half the process-noise variance on this column's own diagonal row
                                      // (theta / v columns only): k_jj = (M_jj + q/2) + (M_jj + q/2)
-    // shared per-window running state, replicated in every lane of the group
-    M3 R;                            // R_k2tau
-    V3 alpha, beta;
-    double DT;
-    // per-interval scratch
-    M3 Rs;                           // rotation used by the current RK4 stage (R_old, R_mid, R_mid, R_new)
+    // per-interval scratch (read from the interval record)
     V3 w, a, gtau, h;
     double dt;
 };
@@ -620,12 +661,26 @@ CPI_HD int cov_read_row(int j) {
     if (j >= 9 && j < 12) return 12 + (j - 9);
     return 15;
 }
-// Initialise the constant rows (9..15) of a window group's exchange buffer.  Called by every lane j of the
-// group for its own column index (idle lanes included); rows 9..15 must have been zeroed before.
+// Offset (doubles, inside an interval record) of this column's h = R_old (g_k x x_klin): the theta_klin
+// transition columns (model 2, columns NPCOL+6..8) own one of the three stored vectors, everyone else zero.
 template <int MODEL>
-CPI_HD void cov_exch_init(double *ex_g, int j, const double q4[4]) {
-    if (j >= 3 && j < 6) ex_g[(9 + (j - 3)) * EXCH_PITCH + j] = q4[1];
-    if (j >= 9 && j < 12) ex_g[(12 + (j - 9)) * EXCH_PITCH + j] = q4[3];
+CPI_HD int cov_h_offset(int j) {
+    typedef CovDims<MODEL> D;
+    const int d = j - D::NPCOL;
+    return (MODEL == 2 && d >= 6 && d < 9) ? IR_H + 4 * (d - 6) : IR_ZERO;
+}
+// Initialise the shared constant rows (9..15).  Called by every lane for its own column index (all groups write
+// identical values); the rows must have been zeroed before.
+template <int MODEL>
+CPI_HD void cov_exch_init(double *ex_shared, int j, const double q4[4]) {   // ex_shared = row 9 of the layout above
+    if (j >= 3 && j < 6) ex_shared[(j - 3) * EXCH_PITCH + j] = q4[1];
+    if (j >= 9 && j < 12) ex_shared[(3 + (j - 9)) * EXCH_PITCH + j] = q4[3];
+}
+// Pointer to the row a column reads as Mt: its group's exchange rows or one of the shared constant rows.
+template <int MODEL>
+CPI_HD const double *cov_row_ptr(const double *ex_g, const double *ex_shared, int j) {
+    const int r = cov_read_row<MODEL>(j);
+    return (r < EXCH_GROUP_ROWS) ? ex_g + r * EXCH_PITCH : ex_shared + (r - EXCH_GROUP_ROWS) * EXCH_PITCH;
 }
 
 // j = column index inside the window's lane group: [0,NPCOL) covariance, [NPCOL,NCOL) transition, NCOL = idle.
@@ -634,57 +689,36 @@ CPI_HD void cov_init(CovLane<MODEL> &L, int j, const double q4[4]) {
     typedef CovDims<MODEL> D;
 #pragma unroll
     for (int i = 0; i < D::NR; i++) { L.P0[i] = 0; L.X[i] = 0; L.acc[i] = 0; }
-    L.xl = mk(0, 0, 0);
     if (MODEL == 2 && j >= D::NPCOL) {
-        // Discrete_J_b starts at identity (CpiV2.h:49): columns b_w (rows 3:6), b_a (9:12), theta_klin (18:21)
+        // Discrete_J_b starts at identity (CpiV2.h:49): columns b_w (rows 3:6), b_a (9:12); the theta_klin columns
+        // (18:21) have their unit entry outside the carried rows -- it enters through h (cov_h_offset)
         const int d = j - D::NPCOL;  // runtime per lane: selects only, no dynamically indexed registers
         const int hot = (d < 3) ? 3 + d : ((d < 6) ? 9 + (d - 3) : -1);
 #pragma unroll
         for (int i = 0; i < D::NR; i++) L.P0[i] = (i == hot) ? 1.0 : 0.0;
-        if (d >= 6) L.xl = unit(d - 6);
     }
     // G Qc G^T = blkdiag(s_w^2, s_wb^2, s_a^2, s_ab^2, 0) (x) I  (CpiV1.h:283-291; Rs^T Rs = I)
     const double ht = 0.5 * q4[0], hv = 0.5 * q4[2];
     L.hqt = mk(j == 0 ? ht : 0.0, j == 1 ? ht : 0.0, j == 2 ? ht : 0.0);
     L.hqv = mk(j == 6 ? hv : 0.0, j == 7 ? hv : 0.0, j == 8 ? hv : 0.0);
-    L.R = eye();
-    L.alpha = mk(0, 0, 0); L.beta = mk(0, 0, 0); L.DT = 0;
 }
 
-// Start of an interval (rp = the interval's SampleRec record): specific force, gravity terms, stage-0 rotation.
-template <int MODEL, bool AVG>
-CPI_HD void cov_begin(CovLane<MODEL> &L, const double *rp, V3 gk) {
-    typedef CovDims<MODEL> D;
-    L.dt = rp[REC_DT];
-    L.w = rec_v3(rp, REC_W);
-    V3 a = rec_v3(rp, REC_A0);
-    if (MODEL == 2) {
-        L.gtau = mul(L.R, gk);
-        L.h = mul(L.R, cross(gk, L.xl));
-        a = a - L.gtau;
-        if (AVG) {  // CpiV2.h:146-149: average the LOCAL acceleration, the second one in the frame after the step
-            const M3 Rn = mm(rec_mat(rp, REC_RSTEP), L.R);
-            a = 0.5 * (a + (rec_v3(rp, REC_A1) - mul(Rn, gk)));
-        }
-    } else {
-        L.gtau = mk(0, 0, 0); L.h = mk(0, 0, 0);
-    }
-    L.a = a;
-    L.Rs = L.R;
-    (void)sizeof(D);  // stage 0 works on P0 directly: no X / acc initialisation copies
-}
-
-// Rotation of RK4 stage s (CpiV1.h:267-269,279,300,332): called before cov_stage_M for s = 1 and s = 3.
+// Start of an interval: pick up the shared per-interval vectors (ir = the interval record, hoff = cov_h_offset).
 template <int MODEL>
-CPI_HD void cov_stage_rot(CovLane<MODEL> &L, int s, const double *rp) {
-    if (s == 1) L.Rs = mm(rec_mat(rp, REC_RHALF), L.R);
-    if (s == 3) L.Rs = mm(rec_mat(rp, REC_RSTEP), L.R);
+CPI_HD void cov_begin(CovLane<MODEL> &L, const double *ir, int hoff) {
+    L.dt = ir[IR_DT];
+    L.w = rec_v3(ir, IR_W);
+    L.a = rec_v3(ir, IR_A);
+    if (MODEL == 2) { L.gtau = rec_v3(ir, IR_GTAU); L.h = rec_v3(ir, hoff); }
+    else { L.gtau = mk(0, 0, 0); L.h = mk(0, 0, 0); }
 }
 
 // Stage s: M = rows (theta, v, p) of F x for this lane's column (+ half its own diagonal process noise).
+// Classic RK4 stage rotations R_old, R_mid, R_mid, R_new (CpiV1.h:279,300,332) come from the record.
 template <int MODEL>
-CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, double M[9]) {
+CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, const double *ir, double M[9]) {
     const double *X = (s == 0) ? L.P0 : L.X;   // s is a compile-time constant after unrolling
+    const M3 Rs = rec_mat(ir, (s == 0) ? IR_ROLD : ((s == 3) ? IR_RNEW : IR_RMID));
     const V3 xt = mk(X[0], X[1], X[2]);
     const V3 xbw = mk(X[3], X[4], X[5]);
     const V3 xba = mk(X[9], X[10], X[11]);
@@ -695,7 +729,7 @@ CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, double M[9]) {
         const V3 xc = mk(X[o], X[o + 1], X[o + 2]);
         y = y + cross(L.gtau, xc) + L.h;
     }
-    const V3 mv = L.hqv - mulT(L.Rs, y);
+    const V3 mv = L.hqv - mulT(Rs, y);
     M[0] = mt.x; M[1] = mt.y; M[2] = mt.z;
     M[3] = mv.x; M[4] = mv.y; M[5] = mv.z;
     M[6] = X[6]; M[7] = X[7]; M[8] = X[8];
@@ -724,24 +758,15 @@ CPI_HD void cov_stage_finish(CovLane<MODEL> &L, int s, const double M[9], const 
     }
 }
 
-// End of interval: means (CpiV1.h:145-154 with R' = the stage-3 rotation), commit; model 2 row-clone
-// theta -> theta_clone (B_k of CpiV2.h:436-443).  The column clone (columns 15:18 := columns 0:3) is a
-// cross-lane copy done by the kernel.
+// End of interval: model 2 row-clone theta -> theta_clone (B_k of CpiV2.h:436-443).  The column clone
+// (columns 15:18 := columns 0:3) is a cross-lane copy done by the kernel.
 template <int MODEL>
-CPI_HD void cov_end(CovLane<MODEL> &L, const double *rp) {
+CPI_HD void cov_end(CovLane<MODEL> &L) {
     typedef CovDims<MODEL> D;
-    StepCoef k;
-    k.dt = L.dt; k.f1 = rp[REC_F]; k.f2 = rp[REC_F + 1]; k.f3 = rp[REC_F + 2]; k.f4 = rp[REC_F + 3];
-    V3 ua, ub;
-    arg_times(L.w, L.a, k, ua, ub);
-    L.alpha = L.alpha + (L.dt * L.beta + mulT(L.Rs, ua));
-    L.beta = L.beta + mulT(L.Rs, ub);
-    L.DT += L.dt;
     if (MODEL == 2) {
         constexpr int o = (D::NR >= 18) ? 15 : 0;   // (model 1 never takes this branch)
         L.P0[o] = L.P0[0]; L.P0[o + 1] = L.P0[1]; L.P0[o + 2] = L.P0[2];
     }
-    L.R = L.Rs;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -785,7 +810,6 @@ CPI_HD V3 pick5(V3 a0, V3 a1, V3 a2, V3 a3, V3 a4, int b) {
               b == 0 ? a0.y : (b == 1 ? a1.y : (b == 2 ? a2.y : (b == 3 ? a3.y : a4.y))),
               b == 0 ? a0.z : (b == 1 ? a1.z : (b == 2 ? a2.z : (b == 3 ? a3.z : a4.z))));
 }
-CPI_HD void put3(double *o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 
 // One lane's share of evaluateError: the residual component err[c] and column c (0..14) of the dense
 // 15x15 H1 and H2.  A column of a block is "block times unit vector", so with u = e_(c mod 3) held as a

@@ -53,35 +53,70 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
     if (MODEL == 2) gk = mul(quat_2_Rot(ldq(qk)), ld3(grav));
     const double q4[4] = { sig[0] * sig[0], sig[1] * sig[1], sig[2] * sig[2], sig[3] * sig[3] };
     const int NL = D::GROUP;   // all lanes of the group, idle ones included (as in the kernel)
+    const int CH = D::GROUP;   // intervals per phase-A pass
     std::vector<CovLane<MODEL>> lane(NL);
-    std::vector<double> exch(EXCH_ROWS * EXCH_PITCH, 0.0);
-    for (int j = 0; j < NL; j++) { const int jj = std::min(j, (int)D::NCOL); cov_init(lane[j], jj, q4); cov_exch_init<MODEL>(exch.data(), jj, q4); }
-    double rec[SAMPLE_REC_DOUBLES];
-    for (int s = 0; s < n; s++) {
-        const double *k0 = kn + 7 * s, *k1 = kn + 7 * (s + 1);
-        rec_store(rec, make_sample_rec<MODEL, AVG>(k0[0], k1[0], ld3(k0 + 1), ld3(k0 + 4), ld3(k1 + 1), ld3(k1 + 4), bw, ba));
-        for (int j = 0; j < NL; j++) cov_begin<MODEL, AVG>(lane[j], rec, gk);
-        for (int st = 0; st < 4; st++) {
-            double M[32][9];
-            for (int j = 0; j < NL; j++) {
-                cov_stage_rot(lane[j], st, rec);
-                cov_stage_M(lane[j], st, M[j]);
-                if (j < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + j] = M[j][rr];
+    const int IRD = IrSize<MODEL>::V;
+    std::vector<double> exch((EXCH_GROUP_ROWS + EXCH_SHARED_ROWS) * EXCH_PITCH, 0.0), irs(CH * IRD, 0.0);
+    double *ex_shared = exch.data() + EXCH_GROUP_ROWS * EXCH_PITCH;
+    double gs[GS_DOUBLES];
+    cov_gs_init(gs);
+    for (int j = 0; j < NL; j++) { const int jj = std::min(j, (int)D::NCOL); cov_init(lane[j], jj, q4); cov_exch_init<MODEL>(ex_shared, jj, q4); }
+    for (int base = 0; base < n; base += CH) {
+        // ---- phase A, as the kernel does it: per-lane closed forms, Hillis-Steele prefix product of the step
+        // rotations, finish_interval, ordered tree reduction of the mean increments
+        std::vector<SampleRec> r(CH);
+        std::vector<M3> inc(CH);
+        for (int sl = 0; sl < CH; sl++) {
+            const int s = base + sl;
+            if (s < n) {
+                const double *k0 = kn + 7 * s, *k1 = kn + 7 * (s + 1);
+                r[sl] = make_sample_rec<MODEL, AVG>(k0[0], k1[0], ld3(k0 + 1), ld3(k0 + 4), ld3(k1 + 1), ld3(k1 + 4), bw, ba);
+            } else {
+                r[sl].dt = 0; r[sl].w = mk(0, 0, 0); r[sl].a0 = mk(0, 0, 0); r[sl].a1 = mk(0, 0, 0);
+                r[sl].f1 = r[sl].f2 = r[sl].f3 = r[sl].f4 = 0; r[sl].Rstep = eye(); r[sl].Rhalf = eye();
             }
-            for (int j = 0; j < NL; j++)
-                cov_stage_finish(lane[j], st, M[j], exch.data() + cov_read_row<MODEL>(std::min(j, (int)D::NCOL)) * EXCH_PITCH);
+            inc[sl] = r[sl].Rstep;
         }
-        for (int j = 0; j < NL; j++) cov_end(lane[j], rec);
-        if (MODEL == 2)
-            for (int b = 0; b < 3; b++) for (int i = 0; i < D::NR; i++) lane[15 + b].P0[i] = lane[b].P0[i];
+        for (int d = 1; d < CH; d <<= 1) {
+            std::vector<M3> prev = inc;
+            for (int sl = d; sl < CH; sl++) inc[sl] = mm(prev[sl], prev[sl - d]);
+        }
+        const M3 Rc = rec_mat(gs, GS_R);
+        std::vector<MeanInc> mi(CH);
+        for (int sl = 0; sl < CH; sl++) {
+            const M3 pre = (sl == 0) ? eye() : inc[sl - 1];
+            mi[sl] = finish_interval<MODEL, AVG>(r[sl], mm(pre, Rc), gk, irs.data() + sl * IRD);
+        }
+        for (int d = 1; d < CH; d <<= 1)
+            for (int sl = 0; sl + d < CH; sl += 2 * d) mi[sl] = inc_combine(mi[sl], mi[sl + d]);
+        gs_apply_inc(gs, mi[0]);
+        rec_put_mat(gs, GS_R, mm(inc[CH - 1], Rc));
+        // ---- phase C
+        const int cnt = std::min(CH, n - base);
+        for (int sl = 0; sl < cnt; sl++) {
+            const double *ir = irs.data() + sl * IRD;
+            for (int j = 0; j < NL; j++) cov_begin<MODEL>(lane[j], ir, cov_h_offset<MODEL>(std::min(j, (int)D::NCOL)));
+            for (int st = 0; st < 4; st++) {
+                double M[32][9];
+                for (int j = 0; j < NL; j++) {
+                    cov_stage_M(lane[j], st, ir, M[j]);
+                    if (j < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + j] = M[j][rr];
+                }
+                for (int j = 0; j < NL; j++)
+                    cov_stage_finish(lane[j], st, M[j], cov_row_ptr<MODEL>(exch.data(), ex_shared, std::min(j, (int)D::NCOL)));
+            }
+            for (int j = 0; j < NL; j++) cov_end(lane[j]);
+            if (MODEL == 2)
+                for (int b = 0; b < 3; b++) for (int i = 0; i < D::NR; i++) lane[15 + b].P0[i] = lane[b].P0[i];
+        }
     }
-    const CovLane<MODEL> &z = lane[0];
-    o[0] = z.DT;
-    o[1] = z.alpha.x; o[2] = z.alpha.y; o[3] = z.alpha.z;
-    o[4] = z.beta.x; o[5] = z.beta.y; o[6] = z.beta.z;
-    const Q4 q = rot_2_quat(z.R);
+    o[0] = gs[GS_DT];
+    o[1] = gs[GS_ALPHA]; o[2] = gs[GS_ALPHA + 1]; o[3] = gs[GS_ALPHA + 2];
+    o[4] = gs[GS_BETA]; o[5] = gs[GS_BETA + 1]; o[6] = gs[GS_BETA + 2];
+    const M3 Rfin = rec_mat(gs, GS_R);
+    const Q4 q = rot_2_quat(Rfin);
     o[7] = q.x; o[8] = q.y; o[9] = q.z; o[10] = q.w;
-    put_cm(o + 11, z.R);
+    put_cm(o + 11, Rfin);
     for (int j = 0; j < 15; j++) for (int i = 0; i < 15; i++) o[83 + j * 15 + i] = lane[j].P0[i];
     if (MODEL == 2) {
         for (int c = 0; c < 3; c++) {
