@@ -98,6 +98,14 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// lanes 4..7 of DPP rows 0 and 2 (= the clone lanes of the two 32-lane model-2 groups) <- lanes 0..3 of the same
+// row; every other lane keeps its value.  row_shr:4, row_mask 0b0101, bank_mask 0b0010, bound_ctrl 0.
+__device__ __forceinline__ double dpp_clone_shr4(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int nlo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0x5, 0x2, false);
+    const int nhi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0x5, 0x2, false);
+    return __hiloint2double(nhi, nlo);
+}
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     if (MODEL == 2) gk = mul(quat_2_Rot(ldq4(A.qk + w * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
     const double q4[4] = { A.q4[0], A.q4[1], A.q4[2], A.q4[3] };
 
-    const int jj = min(j, (int)D::NCOL);  // idle lanes (j >= NCOL) run as a harmless zero transition column
+    const int jj = cov_col_of_lane<MODEL>(j);  // column owned by this lane; idle lanes (NCOL) run as a harmless zero transition column
     CovLane<MODEL> Ln;
     cov_init(Ln, jj, q4);
     double *ex_g = exch + g * EXCH_GROUP_ROWS * EP;
@@ -379,9 +387,9 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
             for (int stg = 0; stg < 4; ++stg) {
                 double M[9];
                 cov_stage_M(Ln, stg, ir, M);
-                if (j < D::NPCOL) {
+                if (jj < D::NPCOL) {
 #pragma unroll
-                    for (int rr = 0; rr < 9; rr++) ex_g[rr * EP + j] = M[rr];
+                    for (int rr = 0; rr < 9; rr++) ex_g[rr * EP + jj] = M[rr];
                 }
                 // The exchange is private to this wavefront and a wave's DS instructions execute in issue
                 // order, so the row reads below see the writes above without draining lgkmcnt; only the
@@ -391,20 +399,16 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
             }
             cov_end(Ln);
             if (MODEL == 2) {  // column clone: columns 15:18 := columns 0:3 (CpiV2.h:436-441)
-                const int src = (j >= 15 && j < 18) ? lane - 15 : lane;
 #pragma unroll
-                for (int i = 0; i < D::NR; i++) {
-                    const double t = __shfl(Ln.P0[i], src);
-                    Ln.P0[i] = t;
-                }
+                for (int i = 0; i < D::NR; i++) Ln.P0[i] = dpp_clone_shr4(Ln.P0[i]);
             }
         }
         wave_lds_fence();
     }
 
     if (!valid) return;
-    if (A.out.P && j < 15) {
-        double *p = A.out.P + w * 225 + j * 15;
+    if (A.out.P && jj < 15) {
+        double *p = A.out.P + w * 225 + jj * 15;
 #pragma unroll
         for (int i = 0; i < 15; i++) p[i] = Ln.P0[i];
     }
@@ -418,9 +422,9 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
             p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
         }
     }
-    if (MODEL == 2 && A.write_jac && j >= D::NPCOL && j < D::NCOL) {
+    if (MODEL == 2 && A.write_jac && jj >= D::NPCOL && jj < D::NCOL) {
         // Jacobian read-out of Discrete_J_b (CpiV2.h:450-458); d = which column, c = column within the block
-        const int d = (j - D::NPCOL) / 3, c = (j - D::NPCOL) % 3;
+        const int d = (jj - D::NPCOL) / 3, c = (jj - D::NPCOL) % 3;
         const V3 th = mk(Ln.P0[0], Ln.P0[1], Ln.P0[2]);
         const V3 vv = mk(Ln.P0[6], Ln.P0[7], Ln.P0[8]);
         const V3 pp = mk(Ln.P0[12], Ln.P0[13], Ln.P0[14]);

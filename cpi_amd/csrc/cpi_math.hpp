@@ -647,6 +647,21 @@ struct CovLane {
     double dt;
 };
 
+// Column owned by lane l of a window group.  Model 1: lane = column (lane 15 idle).  Model 2: the three
+// clone columns (15,16,17) sit exactly one 4-lane DPP bank above the theta columns they are copied from,
+//   lanes 0-2 theta | 3 idle | 4-6 clone | 7 idle | 8-19 columns 3..14 | 20-28 transition columns | 29-31 idle
+// so the per-interval column clone (CpiV2.h:436-441) is a single masked row_shr:4 DPP move per register instead of a
+// round trip through the LDS crossbar.  Idle lanes get column index NCOL.
+template <int MODEL>
+CPI_HD int cov_col_of_lane(int l) {
+    typedef CovDims<MODEL> D;
+    if (MODEL == 1) return (l < D::NCOL) ? l : D::NCOL;
+    if (l < 3) return l;
+    if (l == 3 || l == 7 || l >= 29) return D::NCOL;
+    if (l < 7) return 15 + (l - 4);
+    if (l < 20) return l - 5;
+    return 18 + (l - 20);
+}
 // Which exchange row this column reads as its transposed contribution.
 CPI_HD int cov_exch_row(int j) {
     return (j < 3) ? j : ((j >= 6 && j < 9) ? j - 3 : ((j >= 12 && j < 15) ? j - 6 : -1));

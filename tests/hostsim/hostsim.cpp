@@ -60,7 +60,8 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
     double *ex_shared = exch.data() + EXCH_GROUP_ROWS * EXCH_PITCH;
     double gs[GS_DOUBLES];
     cov_gs_init(gs);
-    for (int j = 0; j < NL; j++) { const int jj = std::min(j, (int)D::NCOL); cov_init(lane[j], jj, q4); cov_exch_init<MODEL>(ex_shared, jj, q4); }
+    std::vector<int> colof(NL);
+    for (int j = 0; j < NL; j++) { colof[j] = cov_col_of_lane<MODEL>(j); cov_init(lane[j], colof[j], q4); cov_exch_init<MODEL>(ex_shared, colof[j], q4); }
     for (int base = 0; base < n; base += CH) {
         // ---- phase A, as the kernel does it: per-lane closed forms, Hillis-Steele prefix product of the step
         // rotations, finish_interval, ordered tree reduction of the mean increments
@@ -95,19 +96,19 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
         const int cnt = std::min(CH, n - base);
         for (int sl = 0; sl < cnt; sl++) {
             const double *ir = irs.data() + sl * IRD;
-            for (int j = 0; j < NL; j++) cov_begin<MODEL>(lane[j], ir, cov_h_offset<MODEL>(std::min(j, (int)D::NCOL)));
+            for (int j = 0; j < NL; j++) cov_begin<MODEL>(lane[j], ir, cov_h_offset<MODEL>(colof[j]));
             for (int st = 0; st < 4; st++) {
                 double M[32][9];
                 for (int j = 0; j < NL; j++) {
                     cov_stage_M(lane[j], st, ir, M[j]);
-                    if (j < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + j] = M[j][rr];
+                    if (colof[j] < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + colof[j]] = M[j][rr];
                 }
                 for (int j = 0; j < NL; j++)
-                    cov_stage_finish(lane[j], st, M[j], cov_row_ptr<MODEL>(exch.data(), ex_shared, std::min(j, (int)D::NCOL)));
+                    cov_stage_finish(lane[j], st, M[j], cov_row_ptr<MODEL>(exch.data(), ex_shared, colof[j]));
             }
             for (int j = 0; j < NL; j++) cov_end(lane[j]);
-            if (MODEL == 2)
-                for (int b = 0; b < 3; b++) for (int i = 0; i < D::NR; i++) lane[15 + b].P0[i] = lane[b].P0[i];
+            if (MODEL == 2)   // the masked row_shr:4 DPP move: lanes 4..7 <- lanes 0..3
+                for (int b = 0; b < 4; b++) for (int i = 0; i < D::NR; i++) lane[4 + b].P0[i] = lane[b].P0[i];
         }
     }
     o[0] = gs[GS_DT];
@@ -117,10 +118,12 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
     const Q4 q = rot_2_quat(Rfin);
     o[7] = q.x; o[8] = q.y; o[9] = q.z; o[10] = q.w;
     put_cm(o + 11, Rfin);
-    for (int j = 0; j < 15; j++) for (int i = 0; i < 15; i++) o[83 + j * 15 + i] = lane[j].P0[i];
+    std::vector<int> laneof(D::NCOL + 1, 0);
+    for (int j = 0; j < NL; j++) if (colof[j] < D::NCOL) laneof[colof[j]] = j;
+    for (int c = 0; c < 15; c++) for (int i = 0; i < 15; i++) o[83 + c * 15 + i] = lane[laneof[c]].P0[i];
     if (MODEL == 2) {
         for (int c = 0; c < 3; c++) {
-            const CovLane<MODEL> &g = lane[D::NPCOL + c], &a = lane[D::NPCOL + 3 + c], &l = lane[D::NPCOL + 6 + c];
+            const CovLane<MODEL> &g = lane[laneof[D::NPCOL + c]], &a = lane[laneof[D::NPCOL + 3 + c]], &l = lane[laneof[D::NPCOL + 6 + c]];
             for (int i = 0; i < 3; i++) {
                 o[20 + c * 3 + i] = -g.P0[0 + i];   // J_q = -D(0:3, 3:6)
                 o[29 + c * 3 + i] = g.P0[12 + i];   // J_a = D(12:15, 3:6)
