@@ -473,12 +473,12 @@ __device__ __forceinline__ NavState ld_state(const double *p) {
 #ifndef CPI_FACTOR_WPS
 #define CPI_FACTOR_WPS 1
 #endif
-template <int MODEL>
+template <int MODEL, bool WHITEN>
 __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
     constexpr int FPW = 4;                       // factors per wavefront
     constexpr int HB = FPW * 225;                // doubles of H1 (or H2) per wavefront
     __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
-    __shared__ __attribute__((aligned(16))) double sR[HB];                  // whitening only: the 4 factors' R
+    __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the 4 factors' R
     const int lane = threadIdx.x;
     const int c = lane & 15, fl = lane >> 4;
     const long long f0 = (long long)blockIdx.x * FPW;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     double h1[15];
     if (A.H1) factor_H1_column<MODEL>(S, m, h1);
     // ---- optional whitening (GTSAM Gaussian::WhitenSystem): y = R x with R upper triangular, column-major
-    const bool whiten = A.sqrt_info != nullptr;
+    constexpr bool whiten = WHITEN;
     const double *Rf = sR + fl * 225;
     if (whiten) {
         const long long nfac = min((long long)FPW, A.F - f0);
@@ -855,8 +855,13 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
     a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.idx_i = idx_i; a.idx_j = idx_j;
     a.err = err; a.H1 = H1; a.H2 = H2; a.sqrt_info = sqrt_info;
     const long long nb = (F + 3) / 4;
-    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_kernel<1>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((cpi_factor_kernel<2>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+    if (sqrt_info) {
+        if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_kernel<1, true>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((cpi_factor_kernel<2, true>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+    } else {
+        if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_kernel<1, false>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((cpi_factor_kernel<2, false>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+    }
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }

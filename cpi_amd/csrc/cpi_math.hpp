@@ -888,18 +888,26 @@ CPI_HD void factor_H1_column(const FactorShared &S, const FactorMeas &f, double 
     const V3 qnv = mk(S.q_n.x, S.q_n.y, S.q_n.z), qmv = mk(S.q_m.x, S.q_m.y, S.q_m.z);
     const V3 tt = -(qLmul(S.q_n, -1.0, qLmul(S.q_m, -1.0, u)) + dot(qmv, u) * qnv);         // (0,0)
     const V3 tg = qLmul(S.q_rminus, -1.0, colcm(f.J_q, cc));                                 // (0,3)
+    put3(h1 + 0, pick5(tt, tg, z, z, z, bc));
+    put3(h1 + 3, (bc == 1) ? -u : z);
+    put3(h1 + 9, (bc == 3) ? -u : z);
+    CPI_SCHED_FENCE();
     V3 vt = cross(S.Rb, u), pt = cross(S.Ra, u);                                             // (6,0) (12,0)
     if (MODEL == 2) {
         const V3 Lu = qLmul(S.q_kR, +1.0, u);
         vt = vt - mulcm(f.O_beta, Lu);
         pt = pt - mulcm(f.O_alpha, Lu);
     }
-    const V3 jb = colcm(f.J_beta, cc), ja = colcm(f.J_alpha, cc), hb = colcm(f.H_beta, cc), ha = colcm(f.H_alpha, cc);
-    put3(h1 + 0, pick5(tt, tg, z, z, z, bc));
-    put3(h1 + 3, (bc == 1) ? -u : z);
-    put3(h1 + 6, pick5(vt, -jb, -S.rku, -hb, z, bc));
-    put3(h1 + 9, (bc == 3) ? -u : z);
-    put3(h1 + 12, pick5(pt, -ja, -(f.dt[0] * S.rku), -ha, -S.rku, bc));
+    CPI_SCHED_FENCE();
+    {
+        const V3 jb = colcm(f.J_beta, cc), hb = colcm(f.H_beta, cc);
+        put3(h1 + 6, pick5(vt, -jb, -S.rku, -hb, z, bc));
+    }
+    CPI_SCHED_FENCE();
+    {
+        const V3 ja = colcm(f.J_alpha, cc), ha = colcm(f.H_alpha, cc);
+        put3(h1 + 12, pick5(pt, -ja, -(f.dt[0] * S.rku), -ha, -S.rku, bc));
+    }
 }
 // H2, column c: blkdiag(q_r,w I + [q_r,v]x, I, Rk, I, Rk)
 CPI_HD void factor_H2_column(const FactorShared &S, double h2[15]) {
