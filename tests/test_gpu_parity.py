@@ -312,3 +312,44 @@ def test_config3_size_structure_properties(eng):
     # model 1 on the same windows: identical rotation, covariance of the same magnitude
     o1 = eng.preintegrate(kn, lin, q, eng.make_params(1), want=("mean", "cov"))
     assert (o1["q"] - out["q"]).abs().max().item() < 1e-12
+
+
+# --------------------------------------------------------------------------- edge sizes and rare branches
+@pytest.mark.parametrize("W,N", [(1, 1), (1, 50), (3, 2), (63, 7), (65, 33), (130, 129), (17, 257)])
+def test_edge_sizes(eng, orc, W, N):
+    """Single windows / single intervals / sizes that straddle every tile, chunk and group boundary
+    (mean-kernel chunks, phase-A passes of 8/16 intervals, 4- and 2-window wavefronts)."""
+    kn, lin, q = synth.make_windows(W, N, seed=1000 + W + N)
+    kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
+    for mode in [(1, 0, 1), (2, 0, 1), (2, 1, 0)]:
+        ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=min(8, os.cpu_count() or 1))
+        check_pre(_run(eng, mode, kn, lin, q), ref, v2=(mode[0] == 2), label="W%d N%d %s" % (W, N, mode))
+    for lanes in (0, 1, 64):
+        out = _run(eng, (1, 0, 1), kn, lin, q, want=("mean",), lanes=lanes)
+        check_pre(out, orc.oracle().run(orc.make_params(1, 0, 1), kn, lin, q), what=("mean",))
+
+
+def test_large_rotation_angles_take_the_reduced_sincos_path(eng, orc):
+    """|w| dt far beyond anything physical (up to ~8 rad per interval): exercises the Cody-Waite range
+    reduction of the device sin/cos (cpi_math.hpp: sincos_fast), which no realistic window reaches."""
+    kn, lin, q = synth.make_windows(96, 50, seed=77, edge_cases=False)
+    kn, lin, q = kn.numpy().copy(), lin.numpy(), q.numpy()
+    kn[:, :, 1:4] *= np.linspace(5.0, 400.0, 96)[:, None, None]        # up to ~1000 rad/s
+    for mode in [(1, 0, 1), (2, 0, 1)]:
+        ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=min(8, os.cpu_count() or 1))
+        wdt = np.linalg.norm(kn[:, :-1, 1:4] - lin[:, None, 0:3], axis=2) * np.diff(kn[:, :, 0], axis=1)
+        assert wdt.max() > 3.0 and (wdt > 1.0).mean() > 0.3
+        out = _run(eng, mode, kn, lin, q)
+        # rotations this violent amplify round-off: gate the means at 1e-9 relative to their magnitude
+        for k in ("alpha", "beta", "q", "DT"):
+            assert np.abs(out[k] - ref[k]).max() <= 1e-9 * max(1.0, np.abs(ref[k]).max()), k
+        # Classic RK4 of the Lyapunov equation (eigenvalues = pairwise sums, up to 2|w|) is only stable for
+        # |w| dt < 1.39; beyond that the reference's own covariance explodes (up to 1e70) and round-off differences
+        # are amplified without bound, so the covariance gate applies to the windows inside the stability region --
+        # which still includes reduced-path angles in (1, 1.3).
+        wmax = wdt.max(axis=1)
+        ok = wmax < 1.3
+        assert ok.sum() >= 8 and (wmax[ok] > 1.0).any()
+        assert cov_rel_err(out["P"][ok], ref["P"][ok]) <= 1e-6
+        m = _run(eng, mode, kn, lin, q, want=("mean",))
+        assert np.abs(m["q"] - ref["q"]).max() <= 1e-9
