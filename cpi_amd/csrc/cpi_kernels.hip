@@ -28,9 +28,6 @@ using namespace cpi;
 #ifndef CPI_MEAN_PREFETCH
 #define CPI_MEAN_PREFETCH 1
 #endif
-#ifndef CPI_MEAN_UNROLL
-#define CPI_MEAN_UNROLL 0
-#endif
 
 // ============================================================================================
 // device helpers
@@ -228,11 +225,7 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
         commit();
         __syncthreads();
 #endif
-#if CPI_MEAN_UNROLL
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
+#pragma unroll   // C <= 2: the two steps of a chunk share one basic block (no knot copy between them)
         for (int c = 0; c < C; ++c) {
             const int s = it * C + c;
             const double *nk = &tile[lane * PITCH + c * 7];
@@ -723,10 +716,10 @@ static int pick_lanes(const cpi_params *prm, int64_t W, int N) {
     if (prm->model == CPI_MODEL_V2) return 1;  // model 2 means depend on the running rotation: sequential per window
     int L = prm->lanes_per_window;
     if (L <= 0) {
-        // Tuned on MI355X (1024 SIMDs): a launch wants at least ~1 wavefront per SIMD; beyond that, more lanes
-        // per window only adds composition work.  Small batches are latency-bound per wavefront and prefer
-        // fewer, longer segments than mid-size ones.
-        const int64_t target = (W < 50000) ? 80000 : 160000;
+        // Tuned on MI355X (1024 SIMDs): a launch wants roughly one wavefront per SIMD (64 K lanes); beyond that,
+        // more lanes per window only add composition work.  Measured optima: L = 8 at 10 k windows, 2 at 30 k,
+        // 1 from ~60 k windows up.
+        const int64_t target = 56000;
         L = 1;
         while (L < 64 && W * L < target && 2 * L <= N) L *= 2;
     }

@@ -295,18 +295,32 @@ CPI_HD StepCoef step_coef(V3 w, double dt) {
     k.wdt = k.mag * dt;
     k.small = (k.mag < 0.008726646);  // threshold on the rate, CpiV1.h:101
     sincos_fast(k.wdt, k.sn, k.cs);
-    // Both forms are evaluated and selected (no branch): the Taylor side is a handful of multiplies.
-    // (1/3, 1/6 as constants: <= 1 ulp from the reference's divisions.)
-    const double t2 = dt * dt, t3 = t2 * dt;
+    // Closed forms first (CpiV1.h:120,137-141); the Taylor forms of the |w| < 0.0087 rad/s branch (:119,132-135)
+    // are patched in under a WAVE-UNIFORM test, so a wavefront without such a lane -- every wavefront of a real,
+    // noisy IMU stream -- skips them.  (1/3, 1/6 as constants: <= 1 ulp from the reference's divisions.)
     const double im2 = im * im, im3 = im2 * im, im4 = im2 * im2;
     const double omc = 1.0 - k.cs;
+    k.s1 = k.sn * im;
+    k.s2 = omc * im2;
+    k.f1 = (k.wdt * k.cs - k.sn) * im3;
+    k.f2 = (k.wdt * k.wdt - 2 * k.cs - 2 * k.wdt * k.sn + 2) * (0.5 * im4);
+    k.f3 = -omc * im2;
+    k.f4 = (k.wdt - k.sn) * im3;
     const bool sm = k.small;
-    k.s1 = sm ? dt : k.sn * im;
-    k.s2 = sm ? 0.5 * t2 : omc * im2;
-    k.f1 = sm ? -(t3 * (1.0 / 3.0)) : (k.wdt * k.cs - k.sn) * im3;
-    k.f2 = sm ? (t2 * t2 * 0.125) : (k.wdt * k.wdt - 2 * k.cs - 2 * k.wdt * k.sn + 2) * (0.5 * im4);
-    k.f3 = sm ? -(0.5 * t2) : -omc * im2;
-    k.f4 = sm ? (t3 * (1.0 / 6.0)) : (k.wdt - k.sn) * im3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64(sm) != 0)
+#else
+    if (sm)
+#endif
+    {
+        const double t2 = dt * dt, t3 = t2 * dt;
+        k.s1 = sm ? dt : k.s1;
+        k.s2 = sm ? 0.5 * t2 : k.s2;
+        k.f1 = sm ? -(t3 * (1.0 / 3.0)) : k.f1;
+        k.f2 = sm ? (t2 * t2 * 0.125) : k.f2;
+        k.f3 = sm ? -(0.5 * t2) : k.f3;
+        k.f4 = sm ? (t3 * (1.0 / 6.0)) : k.f4;
+    }
     return k;
 }
 CPI_HD M3 R_step_of(V3 w, const StepCoef &k) { return poly_wx(w, 1.0, -k.s1, k.s2); }
