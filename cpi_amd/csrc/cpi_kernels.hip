@@ -11,8 +11,8 @@
 //        of P (or of Discrete_J_b).  Phase A computes the per-interval closed forms lane-parallel over
 //        samples into LDS; phase C walks the samples sequentially: F x is lane-local, P F^T arrives
 //        through a 9-row LDS transpose exchange; classic RK4.  Replaces CpiV1.h:266-353 / CpiV2.h:314-464.
-//   cpi_factor_kernel<MODEL>           evaluateError residual + dense 15x15 H1/H2; 16 lanes per
-//        factor, lane c emits column c.  Replaces ImuFactorCPIv1.cpp:37-208 / ImuFactorCPIv2.cpp:38-212.
+//   cpi_factor_kernel<MODEL,WHITEN,LPF> evaluateError residual + dense 15x15 H1/H2; LPF (16/8/4) lanes per
+//        factor, lane q emits columns q, q+LPF, ...  Replaces ImuFactorCPIv1.cpp:37-208 / ImuFactorCPIv2.cpp:38-212.
 //   cpi_predict_kernel<MODEL>          GraphSolver_IMU.cpp:263-307.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -459,49 +459,104 @@ __device__ __forceinline__ NavState ld_state(const double *p) {
     return s;
 }
 
-// 16 lanes per factor, 4 factors per wavefront.  Every lane evaluates the (cheap) shared quaternion algebra;
-// lane c < 15 owns column c of H1 / H2 and err[c].  The sweep is HBM-WRITE bound (3 720 of 4 496 B per factor
-// are the dense 15x15 pair), so the columns are transposed through LDS and leave the wavefront as full,
-// consecutive 16-byte stores: the 4 factors' H1 blocks are one contiguous 7 200-byte span of the output.
+// One SoA input field (K doubles per factor) of the FPW consecutive factors of a wavefront: FPW*K contiguous
+// doubles, lane i takes doubles i, i + 64, ...  load() is unconditional (index clamped to the last valid double),
+// store() writes record-major into the LDS staging area.
+template <int FPW, int K>
+struct FieldFetch {
+    static constexpr int R = (FPW * K + 63) / 64;
+    double v[R];
+    __device__ __forceinline__ void load(const double *src, long long f0, int nf, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = src[f0 * K + min(lane + 64 * r, nf * K - 1)];
+    }
+    __device__ __forceinline__ void store(double *sIn, int pitch, int off, int lane) const {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = lane + 64 * r, g = i / K;
+            if (i < FPW * K) sIn[g * pitch + off + (i - g * K)] = v[r];
+        }
+    }
+};
+
+// LPF lanes per factor (16, 8 or 4), FPW = 64 / LPF factors per wavefront.  Every lane evaluates the shared
+// quaternion algebra of its factor (so it is done LPF times per factor); lane q of a factor then owns columns
+// q, q + LPF, ... of H1 / H2.  The sweep is HBM-WRITE bound (3 720 of 4 496 B per factor are the dense 15x15
+// pair), so the columns are transposed through LDS and leave the wavefront as full, consecutive 16-byte stores:
+// the FPW factors' H1 blocks are one contiguous FPW x 1 800-byte span of the output (measured on MI355X: that
+// pattern stores at 4.8 TB/s, per-column 120/240-byte pieces at 2.5 TB/s -- which rules out one lane per factor).
+// LPF = 16 has the most wavefronts (small sweeps fill the chip); LPF = 8 / 4 do 2x / 4x less redundant arithmetic.
 #ifndef CPI_FACTOR_WPS
 #define CPI_FACTOR_WPS 1
 #endif
-template <int MODEL, bool WHITEN>
+template <int MODEL, bool WHITEN, int LPF>
 __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
-    constexpr int FPW = 4;                       // factors per wavefront
+    constexpr int FPW = 64 / LPF;                // factors per wavefront
+    constexpr int CPL = (15 + LPF - 1) / LPF;    // columns per lane
     constexpr int HB = FPW * 225;                // doubles of H1 (or H2) per wavefront
-    __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
-    __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the 4 factors' R
-    const int lane = threadIdx.x;
-    const int c = lane & 15, fl = lane >> 4;
-    const long long f0 = (long long)blockIdx.x * FPW;
-    const bool valid = (f0 + fl) < A.F;
-    (void)valid;
-
-    // ---- cooperative, de-duplicated input fetch: every double of the 4 factors' records is loaded from HBM
-    // exactly once per wavefront (consecutive lanes = consecutive doubles of one SoA field) into LDS, from
-    // where the 16 lanes of a factor read it as broadcasts.  The staging area is reused for the outputs.
     constexpr int O_ALPHA = 0, O_BETA = 3, O_Q = 6, O_LIN = 10, O_JQ = 16, O_JB = 25, O_JA = 34, O_HB = 43, O_HA = 52,
                   O_DT = 61, O_QK = 62, O_OB = 66, O_OA = 75, O_XI = 84, O_XJ = 100, IN_D = 116;
-    static_assert(FPW * IN_D <= HB, "input staging must fit in the output staging area");
-    double *sIn = sH;
+    __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
+    __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];         // the factors' input records
+    __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the factors' R
+    const int lane = threadIdx.x;
+    const int q = lane % LPF, fl = lane / LPF;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const int nf = (int)min((long long)FPW, A.F - f0);
+    constexpr bool whiten = WHITEN;
+
+    // ---- cooperative, de-duplicated input fetch: every double of the FPW factors' records is loaded from HBM
+    // exactly once per wavefront (consecutive lanes = consecutive doubles of one SoA field) into LDS, from
+    // where the lanes of a factor read it as broadcasts.  All loads are issued unconditionally (clamped
+    // addresses) before the first LDS write, so the wavefront pays ONE memory latency (two for the states
+    // when they are gathered through idx_i / idx_j), not one per field.
     {
-        auto fetch = [&](const double *src, int k, int off) {   // field with k doubles per factor
-            if (lane < FPW * k) {
-                const int q = lane / k, e = lane - q * k;
-                const long long ff = min(f0 + q, A.F - 1);
-                sIn[q * IN_D + off + e] = src[ff * k + e];
-            }
-        };
-        fetch(A.meas.alpha, 3, O_ALPHA); fetch(A.meas.beta, 3, O_BETA); fetch(A.meas.q, 4, O_Q);
-        fetch(A.lin, 6, O_LIN); fetch(A.meas.J_q, 9, O_JQ); fetch(A.meas.J_b, 9, O_JB); fetch(A.meas.J_a, 9, O_JA);
-        fetch(A.meas.H_b, 9, O_HB); fetch(A.meas.H_a, 9, O_HA); fetch(A.meas.DT, 1, O_DT);
-        if (MODEL == 2) { fetch(A.qk, 4, O_QK); fetch(A.meas.O_b, 9, O_OB); fetch(A.meas.O_a, 9, O_OA); }
-        const long long ff = min(f0 + fl, A.F - 1);
-        const long long ii = A.idx_i ? A.idx_i[ff] : ff;
-        const long long ij = A.idx_j ? A.idx_j[ff] : ff + 1;
-        sIn[fl * IN_D + O_XI + c] = A.states[ii * 16 + c];
-        sIn[fl * IN_D + O_XJ + c] = A.states[ij * 16 + c];
+        constexpr int SR = (FPW * 16 + 63) / 64;
+        long long si[SR], sj[SR];
+#pragma unroll
+        for (int r = 0; r < SR; r++) {
+            const int i = min(lane + 64 * r, FPW * 16 - 1), g = i >> 4;
+            const long long ff = min(f0 + g, A.F - 1);
+            // branch-free NULL handling (a valid dummy address is read and discarded) keeps all loads in one block
+            const int vi = (A.idx_i ? A.idx_i : reinterpret_cast<const int *>(A.states))[ff];
+            const int vj = (A.idx_j ? A.idx_j : reinterpret_cast<const int *>(A.states))[ff];
+            si[r] = A.idx_i ? (long long)vi : ff;
+            sj[r] = A.idx_j ? (long long)vj : ff + 1;
+        }
+        FieldFetch<FPW, 3> f_alpha, f_beta; FieldFetch<FPW, 4> f_q, f_qk; FieldFetch<FPW, 6> f_lin;
+        FieldFetch<FPW, 9> f_jq, f_jb, f_ja, f_hb, f_ha, f_ob, f_oa; FieldFetch<FPW, 1> f_dt;
+        f_alpha.load(A.meas.alpha, f0, nf, lane); f_beta.load(A.meas.beta, f0, nf, lane); f_q.load(A.meas.q, f0, nf, lane);
+        f_lin.load(A.lin, f0, nf, lane); f_jq.load(A.meas.J_q, f0, nf, lane); f_jb.load(A.meas.J_b, f0, nf, lane);
+        f_ja.load(A.meas.J_a, f0, nf, lane); f_hb.load(A.meas.H_b, f0, nf, lane); f_ha.load(A.meas.H_a, f0, nf, lane);
+        f_dt.load(A.meas.DT, f0, nf, lane);
+        if (MODEL == 2) { f_qk.load(A.qk, f0, nf, lane); f_ob.load(A.meas.O_b, f0, nf, lane); f_oa.load(A.meas.O_a, f0, nf, lane); }
+        double xi[SR], xj[SR];
+#pragma unroll
+        for (int r = 0; r < SR; r++) {
+            const int e = lane & 15;
+            xi[r] = A.states[si[r] * 16 + e];
+            xj[r] = A.states[sj[r] * 16 + e];
+        }
+        double R_[WHITEN ? (HB + 63) / 64 : 1];
+        if (whiten) {
+#pragma unroll
+            for (int r = 0; r < (HB + 63) / 64; r++) R_[r] = A.sqrt_info[f0 * 225 + min(lane + 64 * r, nf * 225 - 1)];
+        }
+        f_alpha.store(sIn, IN_D, O_ALPHA, lane); f_beta.store(sIn, IN_D, O_BETA, lane); f_q.store(sIn, IN_D, O_Q, lane);
+        f_lin.store(sIn, IN_D, O_LIN, lane); f_jq.store(sIn, IN_D, O_JQ, lane); f_jb.store(sIn, IN_D, O_JB, lane);
+        f_ja.store(sIn, IN_D, O_JA, lane); f_hb.store(sIn, IN_D, O_HB, lane); f_ha.store(sIn, IN_D, O_HA, lane);
+        f_dt.store(sIn, IN_D, O_DT, lane);
+        if (MODEL == 2) { f_qk.store(sIn, IN_D, O_QK, lane); f_ob.store(sIn, IN_D, O_OB, lane); f_oa.store(sIn, IN_D, O_OA, lane); }
+#pragma unroll
+        for (int r = 0; r < SR; r++) {
+            const int i = lane + 64 * r, g = i >> 4, e = i & 15;
+            if (i < FPW * 16) { sIn[g * IN_D + O_XI + e] = xi[r]; sIn[g * IN_D + O_XJ + e] = xj[r]; }
+        }
+        if (whiten) {
+#pragma unroll
+            for (int r = 0; r < (HB + 63) / 64; r++)
+                if (lane + 64 * r < HB) sR[lane + 64 * r] = R_[r];
+        }
     }
     __syncthreads();
     const double *in = sIn + fl * IN_D;
@@ -510,18 +565,26 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     m.J_beta = in + O_JB; m.J_alpha = in + O_JA; m.H_beta = in + O_HB; m.H_alpha = in + O_HA; m.dt = in + O_DT;
     m.q_K_lin = in + O_QK; m.O_beta = in + O_OB; m.O_alpha = in + O_OA; m.xi = in + O_XI; m.xj = in + O_XJ;
     m.grav = mk(A.grav[0], A.grav[1], A.grav[2]);
-    FactorShared S;
-    factor_shared<MODEL>(m, min(c, 14), S);
-    double h1[15];
-    if (A.H1) factor_H1_column<MODEL>(S, m, h1);
-    // ---- optional whitening (GTSAM Gaussian::WhitenSystem): y = R x with R upper triangular, column-major
-    constexpr bool whiten = WHITEN;
+    double *s1 = sH, *se = sH + HB;
     const double *Rf = sR + fl * 225;
-    if (whiten) {
-        const long long nfac = min((long long)FPW, A.F - f0);
-        for (int i = lane; i < (int)nfac * 225; i += 64) sR[i] = A.sqrt_info[f0 * 225 + i];
-        wave_lds_fence();
+    const int nd = nf * 225, ne = nf * 15;
+
+    // ---- shared algebra; the residual goes to the staging area at once.  Lane q of a factor publishes rows
+    // q, q + LPF, ... of the 15-vector.
+    FactorShared S;
+    {
+        V3 e5[5];
+        factor_shared_core<MODEL>(m, S, e5);
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int c = q + LPF * k;
+            if (c < 15) {
+                const V3 ec = pick5(e5[0], e5[1], e5[2], e5[3], e5[4], c / 3);
+                se[fl * 15 + c] = sel3(ec.x, ec.y, ec.z, c % 3);
+            }
+        }
     }
+    // ---- optional whitening (GTSAM Gaussian::WhitenSystem): y = R x with R upper triangular, column-major
     auto whiten_col = [&](double *h) {   // in place: out[i] = sum_{k >= i} R[i][k] h[k]
 #pragma unroll
         for (int i = 0; i < 15; i++) {
@@ -531,55 +594,62 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
             h[i] = acc;                   // rows are finished top-down, so h[k], k > i, is still unwhitened
         }
     };
-    if (whiten && A.H1) whiten_col(h1);
-    wave_lds_fence();   // every lane is done reading the input staging area (in-order DS)
+    if (whiten) {   // R err needs the whole residual
+        wave_lds_fence();
+        double acc[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int cr = min(q + LPF * k, 14);
+            acc[k] = 0.0;
+            for (int j = 0; j < 15; j++) acc[k] = fma((j >= cr) ? Rf[j * 15 + cr] : 0.0, se[fl * 15 + j], acc[k]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int c = q + LPF * k;
+            if (c < 15) se[fl * 15 + c] = acc[k];
+        }
+    }
 
-    // ---- this lane's column -> LDS (layout identical to the global layout of this wavefront's span) -> HBM,
-    // consecutive lanes = consecutive 16-byte pieces (8-byte pieces for an output pointer that is not
-    // 16-byte aligned).  H1 and H2 take turns in the same staging area to keep LDS per wavefront small.
-    double *s1 = sH, *se = sH + HB;
-    const long long nf = min((long long)FPW, A.F - f0);
-    const int nd = (int)nf * 225, ne = (int)nf * 15;
-    typedef double d2 __attribute__((ext_vector_type(2)));
+    // ---- this lane's columns -> LDS (layout identical to the global layout of this wavefront's span) -> HBM,
+    // consecutive lanes = consecutive 16-byte pieces (gfx950 global memory takes dwordx4 at 8-byte alignment).
+    // H1 and H2 take turns in the same staging area to keep LDS per wavefront small.
+    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
     auto flush = [&](double *dst, const double *src, int n) {
-        if ((((unsigned long long)dst) & 15ULL) == 0) {
-            const int n2 = n >> 1;
-            for (int i = lane; i < n2; i += 64) ((d2 *)dst)[i] = ((const d2 *)src)[i];
-            if ((n & 1) && lane == 0) dst[n - 1] = src[n - 1];
-        } else {
-            for (int i = lane; i < n; i += 64) dst[i] = src[i];
-        }
+        const int n2 = n >> 1;
+        for (int i = lane; i < n2; i += 64) { d2u v; v.a = src[2 * i]; v.b = src[2 * i + 1]; ((d2u *)dst)[i] = v; }
+        if ((n & 1) && lane == 0) dst[n - 1] = src[n - 1];
     };
-    if (whiten) {   // R err needs the whole residual: exchange it through LDS first
-        if (c < 15) se[fl * 15 + c] = S.err_c;
-        wave_lds_fence();
-        double acc = 0.0;
-        const int cr = min(c, 14);
-        for (int k = 0; k < 15; k++) acc = fma((k >= cr) ? Rf[k * 15 + cr] : 0.0, se[fl * 15 + k], acc);
-        wave_lds_fence();
-        S.err_c = acc;
-    }
-    if (c < 15) {
-        se[fl * 15 + c] = S.err_c;
-        if (A.H1) {
+    const Q4 qi = ldq(m.xi);
 #pragma unroll
-            for (int i = 0; i < 15; i++) s1[fl * 225 + c * 15 + i] = h1[i];
-        }
-    }
-    wave_lds_fence();
-    flush(A.err + f0 * 15, se, ne);
-    if (A.H1) flush(A.H1 + f0 * 225, s1, nd);
-    if (A.H2) {
-        wave_lds_fence();   // in-order DS: the H1 reads above complete before these writes land
-        if (c < 15) {
-            double h2[15];
-            factor_H2_column(S, h2);
-            if (whiten) whiten_col(h2);
+    for (int pass = 0; pass < 2; pass++) {
+        double *H = pass == 0 ? A.H1 : A.H2;
+        if (H) {
+            if (pass == 1 && A.H1) wave_lds_fence();   // in-order DS: the H1 flush reads complete before these writes land
 #pragma unroll
-            for (int i = 0; i < 15; i++) s1[fl * 225 + c * 15 + i] = h2[i];
+            for (int k = 0; k < CPL; k++) {
+                const int c = q + LPF * k;
+                if (c < 15) {
+                    double h[15];
+                    S.bc = c / 3; S.cc = c - 3 * S.bc;
+                    S.u = unit(S.cc);
+                    S.rku = qrot(qi, S.u);      // column cc of quat_2_Rot(q_GtoK)
+                    if (pass == 0) factor_H1_column<MODEL>(S, m, h);
+                    else factor_H2_column(S, h);
+                    if (whiten) whiten_col(h);
+#pragma unroll
+                    for (int i = 0; i < 15; i++) s1[fl * 225 + c * 15 + i] = h[i];
+                }
+            }
         }
-        wave_lds_fence();
-        flush(A.H2 + f0 * 225, s1, nd);
+        if (pass == 0) {
+            wave_lds_fence();
+            flush(A.err + f0 * 15, se, ne);
+            if (A.H1) flush(A.H1 + f0 * 225, s1, nd);
+        } else if (H) {
+            wave_lds_fence();
+            flush(A.H2 + f0 * 225, s1, nd);
+        }
     }
 }
 
@@ -815,6 +885,18 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     return CPI_OK;
 }
 
+// Lanes per factor of the factor kernel.  CPI_AMD_FACTOR_LANES (16 | 8 | 4) overrides the size heuristic
+// (tuning / A-B measurements).
+static int factor_lanes(int64_t F) {
+    static int forced = [] {
+        const char *e = getenv("CPI_AMD_FACTOR_LANES");
+        const int v = e ? atoi(e) : 0;
+        return (v == 16 || v == 8 || v == 4) ? v : 0;
+    }();
+    if (forced) return forced;
+    return F >= 32768 ? 8 : 16;
+}
+
 static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F, const cpi_outputs *meas,
                             const double *lin, const double *q_k_lin, const double *states, const int32_t *idx_i,
                             const int32_t *idx_j, const double *sqrt_info, double *err, double *H1, double *H2);
@@ -847,14 +929,19 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
     for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
     a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.idx_i = idx_i; a.idx_j = idx_j;
     a.err = err; a.H1 = H1; a.H2 = H2; a.sqrt_info = sqrt_info;
-    const long long nb = (F + 3) / 4;
+    // lanes per factor: 16 gives the most wavefronts (small sweeps), fewer lanes do less redundant arithmetic
+    const int lpf = factor_lanes(F);
+#define CPI_LAUNCH_FACTOR(M, WH, L) \
+    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a)
+#define CPI_LAUNCH_FACTOR_L(M, WH) \
+    do { if (lpf == 16) CPI_LAUNCH_FACTOR(M, WH, 16); else if (lpf == 8) CPI_LAUNCH_FACTOR(M, WH, 8); else CPI_LAUNCH_FACTOR(M, WH, 4); } while (0)
     if (sqrt_info) {
-        if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_kernel<1, true>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((cpi_factor_kernel<2, true>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+        if (model == CPI_MODEL_V1) CPI_LAUNCH_FACTOR_L(1, true); else CPI_LAUNCH_FACTOR_L(2, true);
     } else {
-        if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_kernel<1, false>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((cpi_factor_kernel<2, false>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, a);
+        if (model == CPI_MODEL_V1) CPI_LAUNCH_FACTOR_L(1, false); else CPI_LAUNCH_FACTOR_L(2, false);
     }
+#undef CPI_LAUNCH_FACTOR_L
+#undef CPI_LAUNCH_FACTOR
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }

@@ -273,10 +273,11 @@ CPI_HD Q4 quat_multiply(Q4 q, Q4 p) {  // quat_ops.h:115-128
 CPI_HD Q4 quat_inv(Q4 q) { Q4 r; r.x = -q.x; r.y = -q.y; r.z = -q.z; r.w = q.w; return r; }
 CPI_HD M3 Exp_so3(V3 w) {  // quat_ops.h:145-162
     const double theta = sqrt(dot(w, w));
-    if (theta == 0) return eye();
+    // theta == 0 returns the identity (quat_ops.h:148-150); branch-free: with w = 0 any finite coefficients give I
+    const double th = (theta == 0) ? 1.0 : theta;
     double s, c;
     sincos_fast(theta, s, c);
-    return poly_wx(w, 1.0, s / theta, (1 - c) / (theta * theta));
+    return poly_wx(w, 1.0, s / th, (1 - c) / (th * th));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -853,10 +854,10 @@ struct FactorShared {
     double err_c;
     int bc, cc;
 };
+// Column-independent part: the five quaternions, R_k (p_j - p_i - ...), R_k (v_j - v_i ...) and the five
+// 3-vector residual blocks e[0..4] = [2 q_r,vec ; b_g,K+1 - b_g,K ; betahat - beta ; b_a,K+1 - b_a,K ; alphahat - alpha].
 template <int MODEL>
-CPI_HD void factor_shared(const FactorMeas &f, int c, FactorShared &S) {
-    S.bc = c / 3; S.cc = c - 3 * S.bc;
-    S.u = unit(S.cc);
+CPI_HD void factor_shared_core(const FactorMeas &f, FactorShared &S, V3 e[5]) {
     const V3 dbg = ldv(f.xi + 4) - ldv(f.lin), dba = ldv(f.xi + 10) - ldv(f.lin + 3);
     V3 ja = mulcm(f.J_alpha, dbg) + mulcm(f.H_alpha, dba);      // alpha corrections
     CPI_SCHED_FENCE();
@@ -879,8 +880,8 @@ CPI_HD void factor_shared(const FactorMeas &f, int c, FactorShared &S) {
         if (MODEL == 1) { pa = pa + (0.5 * dt * dt) * f.grav; pb = pb + dt * f.grav; }
         S.Ra = qrot(qi, pa); S.Rb = qrot(qi, pb);
     }
-    const V3 e4 = (S.Ra - ja) - ldv(f.alpha);   // alphahat - alpha
-    const V3 e2 = (S.Rb - jb) - ldv(f.beta);    // betahat - beta
+    e[4] = (S.Ra - ja) - ldv(f.alpha);   // alphahat - alpha
+    e[2] = (S.Rb - jb) - ldv(f.beta);    // betahat - beta
     CPI_SCHED_FENCE();
     const Q4 q_meas = ldq(f.q_KtoK1);
     const Q4 q_b = rot_2_quat(Exp_so3(-(mulcm(f.J_q, dbg))));
@@ -888,11 +889,23 @@ CPI_HD void factor_shared(const FactorMeas &f, int c, FactorShared &S) {
     S.q_rminus = quat_multiply(S.q_n, quat_inv(q_meas));
     S.q_r = quat_multiply(S.q_rminus, q_b);
     S.q_m = quat_multiply(quat_inv(q_b), q_meas);
-    // residual [2 q_r,vec ; b_g,K+1 - b_g,K ; betahat - beta ; b_a,K+1 - b_a,K ; alphahat - alpha]
-    const V3 e = pick5(mk(2 * S.q_r.x, 2 * S.q_r.y, 2 * S.q_r.z), ldv(f.xj + 4) - ldv(f.xi + 4), e2,
-                       ldv(f.xj + 10) - ldv(f.xi + 10), e4, S.bc);
-    S.err_c = sel3(e.x, e.y, e.z, S.cc);
-    S.rku = qrot(qi, S.u);  // column cc of quat_2_Rot(q_GtoK)
+    e[0] = mk(2 * S.q_r.x, 2 * S.q_r.y, 2 * S.q_r.z);
+    e[1] = ldv(f.xj + 4) - ldv(f.xi + 4);
+    e[3] = ldv(f.xj + 10) - ldv(f.xi + 10);
+}
+// Select the column: u = e_(c mod 3), R_k u.
+CPI_HD void factor_set_column(const FactorMeas &f, int c, FactorShared &S) {
+    S.bc = c / 3; S.cc = c - 3 * S.bc;
+    S.u = unit(S.cc);
+    S.rku = qrot(ldq(f.xi), S.u);  // column cc of quat_2_Rot(q_GtoK)
+}
+template <int MODEL>
+CPI_HD void factor_shared(const FactorMeas &f, int c, FactorShared &S) {
+    V3 e[5];
+    factor_shared_core<MODEL>(f, S, e);
+    factor_set_column(f, c, S);
+    const V3 ec = pick5(e[0], e[1], e[2], e[3], e[4], S.bc);
+    S.err_c = sel3(ec.x, ec.y, ec.z, S.cc);
     CPI_SCHED_FENCE();
 }
 template <int MODEL>
