@@ -25,9 +25,6 @@
 
 using namespace cpi;
 
-#ifndef CPI_MEAN_PREFETCH
-#define CPI_MEAN_PREFETCH 1
-#endif
 
 // ============================================================================================
 // device helpers
@@ -135,16 +132,19 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     constexpr int WPB = 64 / L;       // windows per wavefront
     // knots staged per lane per chunk: measured on MI355X -- 1 is best when a wave is latency-bound (few
     // intervals per lane, small batches), 2 when the launch is throughput-bound (one window per lane)
-    constexpr int C = (L == 1 && !JAC) ? 2 : 1;
+#ifndef CPI_MEAN_C_MULTI
+#define CPI_MEAN_C_MULTI 1
+#endif
+    constexpr int C = (L == 1 && !JAC) ? 2 : CPI_MEAN_C_MULTI;
     constexpr int SEGD = 7 * C;       // doubles per lane per chunk
     constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
     __shared__ double tile[64 * PITCH];
     __shared__ unsigned long long segdesc[64];  // per lane-segment: (first double of the segment << 16) | intervals
 
     const int lane = threadIdx.x;
-    const int l = lane % L;
-    long long w = (long long)blockIdx.x * WPB + lane / L;
-    const bool valid = w < A.W;
+    const int grp = lane / L, l = lane - grp * L;
+    long long w = (long long)blockIdx.x * WPB + grp;
+    const bool valid = (w < A.W) && (grp < WPB);   // L not a power of two leaves 64 - WPB*L idle lanes
     if (!valid) w = A.W - 1;
     const int n = A.count ? A.count[w] : A.N;
     const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
@@ -174,7 +174,15 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     // on the chunk index is hoisted: per staged element a lane keeps one pointer and the last chunk for
     // which its knot exists (later chunks re-read that knot; the value is never consumed), so the hot loop
     // spends ~3 VALU per element on addressing and no load is ever out of bounds.
-    double stage[SEGD];
+    // Prefetch distance in chunks, rotating through PFD register stages.  Measured on MI355X (10 k windows x 50,
+    // L = 6, one wavefront per SIMD): 13.1 / 13.7 / 14.4 / 14.7 us for PFD = 1 / 2 / 3 / 4 -- the small-batch
+    // launch is bound by its fixed latencies (launch, first round trip, composition tree: 6.2 us for 64 windows)
+    // and by FP64 issue, not by the per-chunk round trips, so one chunk ahead is the default.
+#ifndef CPI_MEAN_PFD
+#define CPI_MEAN_PFD 1
+#endif
+    constexpr int PFD = (L == 1) ? 1 : CPI_MEAN_PFD;
+    double stage[PFD][SEGD];
     const double *sptr[SEGD];
     int smax[SEGD];
     int tofs[SEGD];
@@ -197,53 +205,57 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     // Dense layout, not one of the last waves: reading a few knots past a short segment's end stays inside
     // the knot array, so the running pointers advance unconditionally (1 VALU per element per chunk).
     const bool safe_overread = (A.first == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W);
-    auto issue = [&](int it) {
+    auto issue = [&](int it, double *stg) {   // chunks are issued in order: the pointers run ahead of the compute
         if (safe_overread) {
 #pragma unroll
-            for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += SEGD; }
+            for (int e = 0; e < SEGD; ++e) { stg[e] = *sptr[e]; sptr[e] += SEGD; }
         } else {
 #pragma unroll
-            for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += (it < smax[e]) ? SEGD : 0; }
+            for (int e = 0; e < SEGD; ++e) { stg[e] = *sptr[e]; sptr[e] += (it < smax[e]) ? SEGD : 0; }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](const double *stg) {
 #pragma unroll
-        for (int e = 0; e < SEGD; ++e) tile[tofs[e]] = stage[e];
+        for (int e = 0; e < SEGD; ++e) tile[tofs[e]] = stg[e];
     };
 
     const int nchunks = (maxlen + C - 1) / C;
-#if CPI_MEAN_PREFETCH
-    if (nchunks > 0) issue(0);
-#endif
-    for (int it = 0; it < nchunks; ++it) {
-#if CPI_MEAN_PREFETCH
-        commit();
-        __syncthreads();
-        if (it + 1 < nchunks) issue(it + 1);   // next chunk's HBM round trip overlaps this chunk's FP64 work
-#else
-        issue(it);
-        commit();
-        __syncthreads();
-#endif
+#pragma unroll
+    for (int d = 0; d < PFD; ++d)
+        if (d < nchunks) issue(d, stage[d]);
+    for (int it0 = 0; it0 < nchunks; it0 += PFD) {
+#pragma unroll
+        for (int b = 0; b < PFD; ++b) {
+            const int it = it0 + b;
+            if (it < nchunks) {
+                commit(stage[b]);
+                __syncthreads();
+                if (it + PFD < nchunks) issue(it + PFD, stage[b]);   // HBM round trips overlap the FP64 work
 #pragma unroll   // C <= 2: the two steps of a chunk share one basic block (no knot copy between them)
-        for (int c = 0; c < C; ++c) {
-            const int s = it * C + c;
-            const double *nk = &tile[lane * PITCH + c * 7];
-            double q[7];
+                for (int c = 0; c < C; ++c) {
+                    const int s = it * C + c;
+                    const double *nk = &tile[lane * PITCH + c * 7];
+                    double q[7];
 #pragma unroll
-            for (int i = 0; i < 7; i++) q[i] = nk[i];
-            mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
-                                       mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, s < len);
+                    for (int i = 0; i < 7; i++) q[i] = nk[i];
+                    mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                               mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, s < len);
 #pragma unroll
-            for (int i = 0; i < 7; i++) pk[i] = q[i];
+                    for (int i = 0; i < 7; i++) pk[i] = q[i];
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
 
     // order-preserving composition tree over the L lanes of a window (earlier = lower lane)
 #pragma unroll
     for (int stp = 1; stp < L; stp <<= 1) {
-        const MeanState<JAC> B = shfl_down(st, stp);
+        MeanState<JAC> B = shfl_down(st, stp);
+        if ((L & (L - 1)) != 0) {
+            // L not a power of two: lane l + stp may belong to the next window -- compose with the identity instead
+            if (l + stp >= L) mean_init(B);
+        }
         mean_combine(st, B);
     }
 
@@ -782,16 +794,31 @@ extern "C" int cpi_ctx_synchronize(cpi_ctx *ctx) {
     return CPI_OK;
 }
 
+static const int kMeanLanes[] = {1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64};
+static bool mean_lanes_supported(int L) {
+    for (int c : kMeanLanes) if (c == L) return true;
+    return false;
+}
 static int pick_lanes(const cpi_params *prm, int64_t W, int N) {
     if (prm->model == CPI_MODEL_V2) return 1;  // model 2 means depend on the running rotation: sequential per window
     int L = prm->lanes_per_window;
     if (L <= 0) {
-        // Tuned on MI355X (1024 SIMDs): a launch wants roughly one wavefront per SIMD (64 K lanes); beyond that,
-        // more lanes per window only add composition work.  Measured optima: L = 8 at 10 k windows, 2 at 30 k,
-        // 1 from ~60 k windows up.
-        const int64_t target = 56000;
+        // Small batches are latency-bound: as long as every wavefront gets a SIMD of its own (<= 1024 wavefronts
+        // on MI355X) the launch lasts as long as one wavefront -- intervals per lane plus composition levels
+        // (measured: ~0.55 us per interval, ~0.3 us per level).  Splitting further makes wavefronts share SIMDs
+        // and loses; batches with more than 1024 single-lane wavefronts are throughput-bound and want L = 1.
+        // Measured optima: L = 12 at 5 k windows x 50, 6 at 10 k, 3 at 20 k, 2 at 30 k, 1 from ~60 k.
+        double best = 1e300;
         L = 1;
-        while (L < 64 && W * L < target && 2 * L <= N) L *= 2;
+        for (int c : kMeanLanes) {
+            if (c > 1 && 2 * c > N) break;
+            const int64_t waves = (W + (64 / c) - 1) / (64 / c);
+            if (c > 1 && waves > 1024) break;
+            int levels = 0;
+            while ((1 << levels) < c) levels++;
+            const double cost = 0.55 * (double)((N + c - 1) / c) + 0.3 * levels;
+            if (cost < best) { best = cost; L = c; }
+        }
     }
     return L;
 }
@@ -800,12 +827,13 @@ template <int MODEL, bool JAC, bool AVG>
 static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
 #define CPI_LAUNCH_L(LL)                                                                         \
     case LL: {                                                                                   \
-        const long long nb = (a.W * LL + 63) / 64;                                               \
+        const long long nb = (a.W + (64 / LL) - 1) / (64 / LL);                                  \
         hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL>), dim3((unsigned)nb), dim3(64), 0, st, a); \
     } break;
     if constexpr (MODEL == 2) { switch (L) { CPI_LAUNCH_L(1) default: break; } } else
     switch (L) {
-        CPI_LAUNCH_L(1) CPI_LAUNCH_L(2) CPI_LAUNCH_L(4) CPI_LAUNCH_L(8) CPI_LAUNCH_L(16) CPI_LAUNCH_L(32) CPI_LAUNCH_L(64)
+        CPI_LAUNCH_L(1) CPI_LAUNCH_L(2) CPI_LAUNCH_L(3) CPI_LAUNCH_L(4) CPI_LAUNCH_L(5) CPI_LAUNCH_L(6) CPI_LAUNCH_L(8)
+        CPI_LAUNCH_L(12) CPI_LAUNCH_L(16) CPI_LAUNCH_L(32) CPI_LAUNCH_L(64)
         default: break;
     }
 #undef CPI_LAUNCH_L
@@ -838,7 +866,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     if (W > ((int64_t)1 << 31) * 4) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: W too large for one launch");
     if (N > 65535) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: N (intervals per window) must be <= 65535");
     int L = prm->lanes_per_window;
-    if (L != 0 && (L < 1 || L > 64 || (L & (L - 1)))) return fail(ctx, CPI_ERR_INVALID, "lanes_per_window must be 0 or a power of two <= 64");
+    if (L != 0 && !mean_lanes_supported(L)) return fail(ctx, CPI_ERR_INVALID, "lanes_per_window must be 0 or one of 1,2,3,4,5,6,8,12,16,32,64");
 
     const bool want_mean = out->DT || out->alpha || out->beta || out->q;
     const bool want_jac = out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b;

@@ -59,7 +59,7 @@ def test_full_outputs_vs_reference_golden(eng, golden_dir, fname, mode):
     check_pre(out, _mode_out(d, mode), v2=(mode[0] == 2), label="%s %s" % (fname, mode))
 
 
-@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize("lanes", [0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64])
 @pytest.mark.parametrize("avg", [0, 1])
 def test_mean_only_vs_reference_golden_all_lane_splits(eng, golden_dir, lanes, avg):
     d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
@@ -138,7 +138,7 @@ def test_ragged_windows_cut_from_one_stream(eng, orc):
         assert out["DT"][0] == 0.0 and np.array_equal(out["q"][0], [0, 0, 0, 1]) and np.all(out["P"][0] == 0)
         # mean-only kernel on the same ragged layout, several lane splits
         if mode[0] == 1:
-            for lanes in (1, 4, 64):
+            for lanes in (1, 4, 6, 64):
                 prm = eng.make_params(*mode, lanes_per_window=lanes)
                 o2 = _host(eng.preintegrate(_dev(stream, eng), _dev(lin, eng), _dev(q, eng), prm, want=("mean",),
                                             first=_dev(first, eng), count=_dev(lens, eng), N=N))
@@ -156,7 +156,7 @@ def test_empty_batch_and_bad_arguments(eng):
     with pytest.raises(cpi_amd.CpiError):
         eng.preintegrate(kn, lin, q, eng.make_params(3))
     with pytest.raises(cpi_amd.CpiError):
-        eng.preintegrate(kn, lin, q, eng.make_params(1, lanes_per_window=3))
+        eng.preintegrate(kn, lin, q, eng.make_params(1, lanes_per_window=7))
 
 
 # --------------------------------------------------------------------------- factors
@@ -271,7 +271,7 @@ def test_config2_size_composition_property(eng):
     assert (A["DT"] + B["DT"] - whole["DT"]).abs().max().item() < 1e-13
     # every lane split gives the same answer to round-off; launches are deterministic
     ref = whole
-    for lanes in (1, 8, 64):
+    for lanes in (1, 5, 8, 12, 64):
         o = eng.preintegrate(kn, lin, q, eng.make_params(1, lanes_per_window=lanes), want=("mean",))
         assert (o["alpha"] - ref["alpha"]).abs().max().item() < 1e-12
         assert (o["q"] - ref["q"]).abs().max().item() < 1e-13

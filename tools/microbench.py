@@ -19,7 +19,10 @@ def main():
         name, W, lanes = spec.split(":")[:3]
         W, lanes = int(W), int(lanes)
         steps = int(spec.split(":")[3]) if spec.count(":") >= 3 else (200 if W <= 20000 else 10)
-        wl = bench.Workload(eng, name, W, 50, seed=1234, lanes=lanes)
+        kw = {}
+        if os.environ.get("CPI_MB_POOL_BYTES"):      # e.g. 1 = a single batch, re-read from L2 / Infinity Cache
+            kw["pool_bytes"] = int(os.environ["CPI_MB_POOL_BYTES"])
+        wl = bench.Workload(eng, name, W, 50, seed=1234, lanes=lanes, **kw)
         best = 1e30
         for rep in range(3):
             wall, k_ms = bench.time_steps(wl, steps, 5)
