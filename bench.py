@@ -45,8 +45,8 @@ def pmc_traffic(workload, W, N):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--workload", default="v1_mean", choices=sorted(BYTES))
     ap.add_argument("--windows", type=int, default=0, help="windows (factors) per step; 0 = BASELINE config size")
     ap.add_argument("--samples", type=int, default=50)
@@ -206,7 +206,7 @@ def main():
                      "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_counters.md)",
                      "algorithmic_bytes_per_launch": BYTES[a.workload] * W,
                      "kernel": {"v1_mean": "cpi_mean_kernel", "v1_full": "cpi_cov_kernel<1>", "v2_full": "cpi_cov_kernel<2>",
-                                "factor_v1": "cpi_factor_kernel<1>", "factor_v2": "cpi_factor_kernel<2>"}[a.workload],
+                                "factor_v1": "cpi_factor_kernel<1,false,8>", "factor_v2": "cpi_factor_kernel<2,false,8>"}[a.workload],
                      "launch_us": launch_s * 1e6, "algorithmic_bytes_per_unit": BYTES[a.workload]},
     }
     if rank == 0 and world == 1 and not a.no_cpu and not is_factor:
@@ -215,11 +215,11 @@ def main():
         extra = []
         del wl
         torch.cuda.empty_cache()
-        for name, Wx, steps in (("v1_mean", 1000000, 10), ("v1_full", 100000, 10), ("v2_full", 100000, 10),
-                                ("factor_v1", 1000000, 10), ("factor_v2", 1000000, 10)):
+        for name, Wx, steps in (("v1_mean", 1000000, 40), ("v1_full", 100000, 30), ("v2_full", 100000, 30),
+                                ("factor_v1", 1000000, 40), ("factor_v2", 1000000, 40)):
             try:
                 w2 = Workload(eng, name, Wx, a.samples, seed=4242, pool_bytes=MALL_BYTES * 5 // 4)
-                wall2, k2 = time_steps(w2, steps, 2)
+                wall2, k2 = time_steps(w2, steps, 10)
                 ls = k2 * 1e-3 / steps
                 ach = BYTES[name] * Wx / ls / 1e9
                 extra.append({"workload": name, "units_per_step": Wx, "value": Wx * steps / wall2,

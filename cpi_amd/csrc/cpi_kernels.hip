@@ -130,12 +130,10 @@ struct PreArgs {
 template <int MODEL, bool JAC, bool AVG, int L>
 __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     constexpr int WPB = 64 / L;       // windows per wavefront
-    // knots staged per lane per chunk: measured on MI355X -- 1 is best when a wave is latency-bound (few
-    // intervals per lane, small batches), 2 when the launch is throughput-bound (one window per lane)
-#ifndef CPI_MEAN_C_MULTI
-#define CPI_MEAN_C_MULTI 1
-#endif
-    constexpr int C = (L == 1 && !JAC) ? 2 : CPI_MEAN_C_MULTI;
+    // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has many intervals (L <= 3: batches of
+    // >= ~20 k windows; 20 k x 50 with L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us), 1 when a wave is
+    // latency-bound with few intervals per lane (5 k with L = 12: 10.2 vs 10.6 us)
+    constexpr int C = (L <= 3 && !JAC) ? 2 : 1;
     constexpr int SEGD = 7 * C;       // doubles per lane per chunk
     constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
     __shared__ double tile[64 * PITCH];
@@ -151,7 +149,7 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     const int per = (n + L - 1) / L;
     const int s0 = min(n, l * per), s1 = min(n, s0 + per);
     const int len = s1 - s0;
-    const int maxlen = wave_max(len);
+    const int maxlen = __builtin_amdgcn_readfirstlane(wave_max(len));   // wave-uniform: loop control stays scalar
 
     segdesc[lane] = ((unsigned long long)((k0 + s0) * 7) << 16) | (unsigned long long)(unsigned)len;
 
@@ -666,44 +664,76 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
 }
 
 // R = chol_upper(P^-1) = B^-1 with P = B B^T, B upper triangular ("reverse" Cholesky, from the last pivot up).
-// 16 lanes per factor, the working matrix in LDS; lane j owns column j.  One-off per factor (GTSAM builds the
-// noise model in the factor constructor), so clarity over speed.
-__global__ __launch_bounds__(64) void cpi_sqrt_info_kernel(long long F, const double *P, double *Rout) {
+// 16 lanes (one DPP row) per factor, 4 factors per wavefront; lane j keeps the FULL symmetric column j of the
+// working matrix in registers, so its own B[j][k] is a static register (a[k]) and the only cross-lane traffic is
+// "every lane reads column k of lane k": DPP row_share broadcasts, no LDS in the factorisation.  The inverse of
+// the triangular factor is fused into the same sweep: back substitution for column j of U = B^-1,
+//   U[j][j] = 1/B[j][j],   U[k][j] = -(sum_{m=k+1..j} B[k][m] U[m][j]) / B[k][k]   (k < j),   0 below the diagonal,
+// consumes the columns of B in the order the factorisation produces them (k = 14 .. 0), so every lane folds the
+// broadcast column k into its running sums acc[i] = sum_m B[i][m] U[m][j] right away and B is never stored.
+// Input and output pass through LDS so that HBM sees full consecutive 16-byte pieces (see cpi_factor_kernel).
+template <int K>
+__device__ __forceinline__ double row_share(double v) {   // all 16 lanes of a DPP row read lane K of that row
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int nlo = __builtin_amdgcn_mov_dpp(lo, 0x150 + K, 0xf, 0xf, false);
+    const int nhi = __builtin_amdgcn_mov_dpp(hi, 0x150 + K, 0xf, 0xf, false);
+    return __hiloint2double(nhi, nlo);
+}
+template <int K>
+__device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], double (&acc)[15], int j) {
+    if constexpr (K >= 0) {
+        // pivot: b_kk = sqrt(A[k][k]); a non-positive (or NaN) pivot poisons the factor with NaNs
+        const double akk = row_share<K>(a[K]);
+        double bkk, inv;
+        mag_and_inverse(akk, bkk, inv);
+        if (!(akk > 0.0)) inv = __builtin_nan("");
+        // row k of column j of U
+        u[K] = (K == j) ? inv : ((K < j) ? -acc[K] * inv : 0.0);
+        // lanes j < k: trailing update of column j (all rows < k) with B[j][k] = A[k][j] / b_kk (symmetry: a
+        // static register of lane j); finished lanes multiply by zero
+        const double bjk = (j < K) ? a[K] * inv : 0.0;
+        const double uk = u[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const double c = row_share<K>(a[i]) * inv;     // B[i][k], i < k
+            a[i] = fma(-c, bjk, a[i]);
+            acc[i] = fma(c, uk, acc[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the steps in order: hoisted broadcasts would cost ~200 registers
+        chol_inv_step<K - 1>(a, u, acc, j);
+    }
+}
+__global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const double *P, double *Rout) {
     constexpr int FPW = 4;
-    __shared__ __attribute__((aligned(16))) double sA[FPW * 225];   // working copy / B (column-major)
-    __shared__ __attribute__((aligned(16))) double sU[FPW * 225];   // B^-1
+    __shared__ __attribute__((aligned(16))) double sA[FPW * 225];
     const int lane = threadIdx.x, j = lane & 15, fl = lane >> 4;
     const long long f0 = (long long)blockIdx.x * FPW;
-    const long long nf = min((long long)FPW, F - f0);
-    for (int i = lane; i < (int)nf * 225; i += 64) { sA[i] = P[f0 * 225 + i]; sU[i] = 0.0; }
-    wave_lds_fence();
-    double *A = sA + fl * 225, *U = sU + fl * 225;
-    const bool act = (fl < nf) && (j < 15);
-    // P = B B^T: for k = 14..0:  B[k][k] = sqrt(A[k][k]);  B[i][k] = A[i][k] / B[k][k] (i < k);
-    //                           A[i][j] -= B[i][k] B[j][k]  (i <= j < k)
-    for (int k = 14; k >= 0; --k) {
-        const double bkk = sqrt(A[k * 15 + k]);
-        wave_lds_fence();
-        if (act && j <= k) A[k * 15 + j] = (j == k) ? bkk : A[k * 15 + j] / bkk;   // lane j = row j of column k
-        wave_lds_fence();
-        if (act && j < k) {
-            const double bjk = A[k * 15 + j];
-            for (int i = 0; i <= j; ++i) A[j * 15 + i] -= A[k * 15 + i] * bjk;      // column j, rows i <= j
-        }
-        wave_lds_fence();
-    }
-    // U = B^-1 (upper): column j by back substitution, U[j][j] = 1/B[j][j],
-    //   U[i][j] = -(sum_{m=i+1..j} B[i][m] U[m][j]) / B[i][i]
-    if (act) {
-        U[j * 15 + j] = 1.0 / A[j * 15 + j];
-        for (int i = j - 1; i >= 0; --i) {
-            double sacc = 0.0;
-            for (int m = i + 1; m <= j; ++m) sacc = fma(A[m * 15 + i], U[j * 15 + m], sacc);
-            U[j * 15 + i] = -sacc / A[i * 15 + i];
-        }
+    const int nf = (int)min((long long)FPW, F - f0);
+    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
+    {
+        const int n2 = (nf * 225) >> 1;
+        const d2u *src = reinterpret_cast<const d2u *>(P + f0 * 225);
+        for (int i = lane; i < n2; i += 64) { const d2u v = src[i]; sA[2 * i] = v.a; sA[2 * i + 1] = v.b; }
+        if (((nf * 225) & 1) && lane == 0) sA[nf * 225 - 1] = P[f0 * 225 + nf * 225 - 1];
     }
     wave_lds_fence();
-    for (int i = lane; i < (int)nf * 225; i += 64) Rout[f0 * 225 + i] = sU[i];
+    const int fc = min(fl, nf - 1), jc = min(j, 14);   // idle lanes (j == 15, missing factors) redo a valid column
+    double a[15], u[15], acc[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) { a[i] = sA[fc * 225 + jc * 15 + i]; acc[i] = 0.0; }
+    chol_inv_step<14>(a, u, acc, j);
+    wave_lds_fence();   // the column reads above are complete (in-order DS) before the staging area is reused
+    if (j < 15 && fl < nf) {
+#pragma unroll
+        for (int i = 0; i < 15; i++) sA[fl * 225 + j * 15 + i] = u[i];
+    }
+    wave_lds_fence();
+    {
+        const int n2 = (nf * 225) >> 1;
+        d2u *dst = reinterpret_cast<d2u *>(Rout + f0 * 225);
+        for (int i = lane; i < n2; i += 64) { d2u v; v.a = sA[2 * i]; v.b = sA[2 * i + 1]; dst[i] = v; }
+        if (((nf * 225) & 1) && lane == 0) Rout[f0 * 225 + nf * 225 - 1] = sA[nf * 225 - 1];
+    }
 }
 
 struct PredictArgs {

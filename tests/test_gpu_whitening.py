@@ -51,3 +51,22 @@ def test_sqrt_information_and_whitened_sweep(eng, model):
     # (5) the whitened residual's squared norm is the Mahalanobis distance e^T P^-1 e
     maha = np.einsum("fi,fij,fj->f", e, np.linalg.inv(P), e)
     assert np.abs((ew ** 2).sum(1) - maha).max() <= 1e-6 * max(1.0, maha.max())
+
+
+def test_sqrt_information_well_conditioned_and_not_positive_definite(eng):
+    """Well-conditioned random SPD matrices must agree with LAPACK to rounding; a matrix that is not positive
+    definite poisons ITS factor with NaNs (include/cpi_amd.h) and no other factor of the wavefront."""
+    rng = np.random.default_rng(5)
+    F = 9                                                  # 2 wavefronts of 4 factors + a tail of 1
+    A = rng.standard_normal((F, 15, 15))
+    P = A @ A.transpose(0, 2, 1) + 15.0 * np.eye(15)
+    P[4] = np.eye(15)                                      # identity -> identity
+    P[6, 3, 3] = -1.0                                      # indefinite
+    R = eng.sqrt_information(torch.tensor(P.reshape(F, 225), device=eng.device))
+    torch.cuda.synchronize()
+    Rg = R.cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1)
+    ok = [f for f in range(F) if f != 6]
+    Rn = np.stack([np.linalg.cholesky(np.linalg.inv(P[f])).T for f in ok])
+    assert np.abs(Rg[ok] - Rn).max() < 1e-13
+    assert np.array_equal(Rg[4], np.eye(15))
+    assert np.isnan(Rg[6]).any()
