@@ -945,13 +945,16 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
 
 // Lanes per factor of the factor kernel.  CPI_AMD_FACTOR_LANES (16 | 8 | 4) overrides the size heuristic
 // (tuning / A-B measurements).
-static int factor_lanes(int64_t F) {
+static int factor_lanes(int64_t F, bool whiten) {
     static int forced = [] {
         const char *e = getenv("CPI_AMD_FACTOR_LANES");
         const int v = e ? atoi(e) : 0;
         return (v == 16 || v == 8 || v == 4) ? v : 0;
     }();
     if (forced) return forced;
+    // measured on MI355X, 1 M factors: plain 0.82 ms with 8 lanes vs 1.09 ms with 16; whitened (37 KB vs 19 KB of
+    // LDS per wavefront) 1.45 ms with 8 vs 1.37 ms with 16
+    if (whiten) return 16;
     return F >= 32768 ? 8 : 16;
 }
 
@@ -988,7 +991,7 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
     a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.idx_i = idx_i; a.idx_j = idx_j;
     a.err = err; a.H1 = H1; a.H2 = H2; a.sqrt_info = sqrt_info;
     // lanes per factor: 16 gives the most wavefronts (small sweeps), fewer lanes do less redundant arithmetic
-    const int lpf = factor_lanes(F);
+    const int lpf = factor_lanes(F, sqrt_info != nullptr);
 #define CPI_LAUNCH_FACTOR(M, WH, L) \
     hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a)
 #define CPI_LAUNCH_FACTOR_L(M, WH) \

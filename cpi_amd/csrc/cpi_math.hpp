@@ -139,7 +139,7 @@ CPI_HD M3 poly_wx(V3 w, double c0, double c1, double c2) {
 #define CPI_HORNER(p, z, C)                                                          \
     do {                                                                             \
         double c__ = (C);                                                            \
-        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(z), "v"(c__));        \
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(z), "s"(c__));        \
     } while (0)
 #else
 #define CPI_HORNER(p, z, C) p = fma(p, z, (C))
