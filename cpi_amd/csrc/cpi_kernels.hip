@@ -318,9 +318,6 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
     const int nmax = wave_max(n);
 
-    const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
-    V3 gk = mk(0, 0, 0);
-    if (MODEL == 2) gk = mul(quat_2_Rot(ldq4(A.qk + w * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
     const double q4[4] = { A.q4[0], A.q4[1], A.q4[2], A.q4[3] };
 
     const int jj = cov_col_of_lane<MODEL>(j);  // column owned by this lane; idle lanes (NCOL) run as a harmless zero transition column
@@ -332,7 +329,10 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     const int hoff = cov_h_offset<MODEL>(jj);
     double *gs = gsh + g * GS_DOUBLES;
     for (int i = lane; i < (G * EXCH_GROUP_ROWS + EXCH_SHARED_ROWS) * EP; i += 64) exch[i] = 0.0;
-    if (j == 0) cov_gs_init(gs);
+    if (j == 0) {
+        cov_gs_init(gs);
+        if (MODEL == 2) put3(gs + GS_GK, mul(quat_2_Rot(ldq4(A.qk + w * 4)), mk(A.grav[0], A.grav[1], A.grav[2])));
+    }
     __syncthreads();
     cov_exch_init<MODEL>(ex_shared, jj, q4);
 
@@ -342,9 +342,16 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
         {
             const bool part = j < CH;                  // lanes taking part in this pass
             const int s = base + j;
+            // Everything only phase A needs is re-read here (the linearisation biases from L2, R(q_k_lin) g from
+            // LDS) instead of living in registers across phase C: the recursion needs every register it can get.
+            long long wq = w;
+            asm volatile("" : "+v"(wq));   // opaque to the optimiser: keeps the loads inside the loop
+            V3 gk = mk(0, 0, 0);
+            if (MODEL == 2) gk = rec_v3(gs, GS_GK);
             SampleRec r;
             if (part && s < n) {
                 const double *ka = A.knots + (k0 + s) * 7;
+                const V3 bw = ldv3(A.lin + wq * 6), ba = ldv3(A.lin + wq * 6 + 3);
                 double a[14];
 #pragma unroll
                 for (int i = 0; i < 14; i++) a[i] = ka[i];

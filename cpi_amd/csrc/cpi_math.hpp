@@ -587,7 +587,7 @@ static const int IR_DT = 0, IR_W = 2, IR_A = 6, IR_GTAU = 10, IR_ROLD = 14, IR_R
                  IR_ZERO = 44, IR_H = 48 /* model 2: 3 vectors of 4, R_old (g_k x e_l), l = 0..2 */;
 template <int MODEL> struct IrSize { static const int V = (MODEL == 1) ? 48 : 60; };   // doubles per record
 // group-shared carry across chunks: running rotation and means
-static const int GS_R = 0, GS_ALPHA = 10, GS_BETA = 14, GS_DT = 18, GS_DOUBLES = 20;
+static const int GS_R = 0, GS_ALPHA = 10, GS_BETA = 14, GS_DT = 18, GS_GK = 20 /* model 2: R(q_k_lin) g */, GS_DOUBLES = 24;
 CPI_HD void cov_gs_init(double *gs) {
 #pragma unroll
     for (int i = 0; i < GS_DOUBLES; i++) gs[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
