@@ -314,6 +314,96 @@ def test_config3_size_structure_properties(eng):
     assert (o1["q"] - out["q"]).abs().max().item() < 1e-12
 
 
+@pytest.mark.parametrize("model", [1, 2])
+def test_config4_full_size_factor_sweep_properties(eng, orc, model):
+    """BASELINE configs[3] at full size (1 M factors): the large-sweep kernel (8 lanes per factor) must agree
+    bit-for-bit with the small-sweep kernel (16 lanes) on any slice, vanish at the predicted state, keep the
+    block structure of H2 (ImuFactorCPIv1.cpp:169-185), be deterministic, and match the oracle on a sample."""
+    F = 1000000
+    kn, lin, q = synth.make_windows(F, 50, seed=77, device=eng.device, edge_cases=False)
+    meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac"))
+    torch.cuda.synchronize()
+    del kn
+    qq = q if model == 2 else None
+    xi, _ = synth.make_states(meas["alpha"], meas["beta"], meas["q"], meas["DT"], lin, model, device=eng.device)
+    # at the linearisation point (biases = b_lin, model 2: q_GtoK = q_K_lin) every first-order correction is zero,
+    # so the residual at the exactly predicted state must vanish
+    xi[:, 4:7] = lin[:, 0:3]
+    xi[:, 10:13] = lin[:, 3:6]
+    if model == 2:
+        xi[:, 0:4] = q
+    xj = eng.predict(model, meas, xi)
+    states = torch.cat([xi, xj], dim=0).contiguous()
+    idx_i = torch.arange(F, dtype=torch.int32, device=eng.device)
+    idx_j = idx_i + F
+    out = eng.factor_eval(model, meas, lin, qq, states, idx_i=idx_i, idx_j=idx_j)
+    torch.cuda.synchronize()
+    assert out["err"].abs().max().item() < 1e-9
+    for k in ("err", "H1", "H2"):
+        assert torch.isfinite(out[k]).all(), k
+    H2 = out["H2"].reshape(F, 15, 15).transpose(1, 2)       # [row][col]
+    mask = torch.ones((15, 15), dtype=torch.bool, device=eng.device)
+    for b in range(5):
+        mask[3 * b:3 * b + 3, 3 * b:3 * b + 3] = False
+    assert H2[:, mask].abs().max().item() == 0.0             # block diagonal
+    eye = torch.eye(3, dtype=torch.float64, device=eng.device)
+    assert torch.equal(H2[:, 3:6, 3:6], eye.expand(F, 3, 3)) and torch.equal(H2[:, 9:12, 9:12], eye.expand(F, 3, 3))
+    assert torch.equal(H2[:, 6:9, 6:9], H2[:, 12:15, 12:15])                       # both are R(q_GtoK)
+    # slices through the small-sweep kernel
+    for lo, n in ((0, 4099), (500000, 1000), (F - 777, 777)):
+        sl = slice(lo, lo + n)
+        sub = {k: v[sl] for k, v in meas.items()}
+        o2 = eng.factor_eval(model, sub, lin[sl], None if qq is None else qq[sl], states,
+                             idx_i=idx_i[sl].contiguous(), idx_j=idx_j[sl].contiguous())
+        torch.cuda.synchronize()
+        for k in ("err", "H1", "H2"):
+            assert torch.equal(o2[k], out[k][sl]), (k, lo)
+    again = eng.factor_eval(model, meas, lin, qq, states, idx_i=idx_i, idx_j=idx_j)
+    torch.cuda.synchronize()
+    for k in ("err", "H1", "H2"):
+        assert torch.equal(again[k], out[k]), k
+    # oracle on a strided sample, with perturbed state_j so that the residual is not trivially zero
+    pick = torch.arange(0, F, 1999, device=eng.device)
+    xs = states.clone()
+    xs[F:, 4:] += 1e-3
+    o3 = eng.factor_eval(model, meas, lin, qq, xs, idx_i=idx_i, idx_j=idx_j)
+    torch.cuda.synchronize()
+    m = {k: v[pick].cpu().numpy() for k, v in meas.items()}
+    rec = orc.factor_records(m, lin[pick].cpu().numpy(), q[pick].cpu().numpy() if model == 2 else None)
+    err, H1, H2o = orc.oracle().factor(model, rec, xs[pick].cpu().numpy(), xs[pick + F].cpu().numpy())
+    assert np.abs(o3["err"][pick].cpu().numpy() - err).max() <= TOL_FACTOR * max(1.0, np.abs(err).max())
+    assert np.abs(o3["H1"][pick].cpu().numpy() - H1).max() <= TOL_FACTOR * max(1.0, np.abs(H1).max())
+    assert np.abs(o3["H2"][pick].cpu().numpy() - H2o).max() <= TOL_FACTOR
+
+
+def test_config5_one_gpu_share_1M_windows_x_100_samples(eng, orc):
+    """BASELINE configs[4] is 8 M windows x 100 samples over 8 GPUs: one GPU's share (1 M x 100, 5.7 GB of knots).
+    Size-independent checks: DT telescopes, every slice re-run with a different lane split agrees to round-off,
+    a strided sample matches the oracle, the launch is deterministic."""
+    W, N = 1000000, 100
+    kn, lin, q = synth.make_windows(W, N, seed=88, device=eng.device, edge_cases=False)
+    prm = eng.make_params(1)
+    out = eng.preintegrate(kn, lin, q, prm, want=("mean",))
+    torch.cuda.synchronize()
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    assert (out["DT"] - (kn[:, -1, 0] - kn[:, 0, 0])).abs().max().item() < 1e-12
+    assert (out["q"].norm(dim=1) - 1).abs().max().item() < 1e-14 and (out["q"][:, 3] >= 0).all()
+    for lo, n, lanes in ((0, 10000, 6), (123456, 20000, 3), (W - 5000, 5000, 12)):
+        sl = slice(lo, lo + n)
+        o = eng.preintegrate(kn[sl], lin[sl], q[sl], eng.make_params(1, lanes_per_window=lanes), want=("mean",))
+        torch.cuda.synchronize()
+        for k in ("DT", "alpha", "beta", "q"):
+            assert (o[k] - out[k][sl]).abs().max().item() < 1e-11, (k, lo)
+    pick = torch.arange(0, W, 9973, device=eng.device)
+    ref = orc.oracle().run(orc.make_params(1, 0, 1), kn[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
+    check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, ref, what=("mean",), label="1M x 100 sample")
+    again = eng.preintegrate(kn, lin, q, prm, want=("mean",))
+    torch.cuda.synchronize()
+    for k in out:
+        assert torch.equal(again[k], out[k]), k
+
+
 # --------------------------------------------------------------------------- edge sizes and rare branches
 @pytest.mark.parametrize("W,N", [(1, 1), (1, 50), (3, 2), (63, 7), (65, 33), (130, 129), (17, 257)])
 def test_edge_sizes(eng, orc, W, N):
