@@ -149,13 +149,11 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     const int per = (n + L - 1) / L;
     const int s0 = min(n, l * per), s1 = min(n, s0 + per);
     const int len = s1 - s0;
-    // Dense layout (no first[] / count[]): every window has N intervals, so the longest segment and every other
-    // lane's segment descriptor follow from arithmetic -- no shuffle reduction and no LDS round trip on the
-    // wavefront's start-up path (~0.4 us of a 13 us launch at 10 k windows).
-    const bool dense = (A.first == nullptr) && (A.count == nullptr);
-    const int maxlen = dense ? min(A.N, (A.N + L - 1) / L)
-                             : __builtin_amdgcn_readfirstlane(wave_max(len));   // wave-uniform: scalar loop control
-    if (!dense) segdesc[lane] = ((unsigned long long)((k0 + s0) * 7) << 16) | (unsigned long long)(unsigned)len;
+    const int maxlen = __builtin_amdgcn_readfirstlane(wave_max(len));   // wave-uniform: loop control stays scalar
+
+    // (Deriving the descriptors of a dense layout arithmetically instead of through LDS was measured: +0.35 us per
+    // 13 us launch -- the 64-bit integer arithmetic costs more than the shuffle reduction and the LDS round trip.)
+    segdesc[lane] = ((unsigned long long)((k0 + s0) * 7) << 16) | (unsigned long long)(unsigned)len;
 
     const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
     V3 gk = mk(0, 0, 0);
@@ -176,15 +174,7 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     // on the chunk index is hoisted: per staged element a lane keeps one pointer and the last chunk for
     // which its knot exists (later chunks re-read that knot; the value is never consumed), so the hot loop
     // spends ~3 VALU per element on addressing and no load is ever out of bounds.
-    // Prefetch distance in chunks, rotating through PFD register stages.  Measured on MI355X (10 k windows x 50,
-    // L = 6, one wavefront per SIMD): 13.1 / 13.7 / 14.4 / 14.7 us for PFD = 1 / 2 / 3 / 4 -- the small-batch
-    // launch is bound by its fixed latencies (launch, first round trip, composition tree: 6.2 us for 64 windows)
-    // and by FP64 issue, not by the per-chunk round trips, so one chunk ahead is the default.
-#ifndef CPI_MEAN_PFD
-#define CPI_MEAN_PFD 1
-#endif
-    constexpr int PFD = (L == 1) ? 1 : CPI_MEAN_PFD;
-    double stage[PFD][SEGD];
+    double stage[SEGD];
     const double *sptr[SEGD];
     int smax[SEGD];
     int tofs[SEGD];
@@ -192,21 +182,9 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
         int seg = lane / SEGD, off = lane - seg * SEGD;
 #pragma unroll
         for (int e = 0; e < SEGD; ++e) {
-            long long base;
-            int slen;
-            if (dense) {   // what lane `seg` computed above, redone for its descriptor
-                const int sg = seg / L, sl = seg - sg * L;
-                long long sw = (long long)blockIdx.x * WPB + sg;
-                if (sw >= A.W || sg >= WPB) sw = A.W - 1;
-                const int dper = (A.N + L - 1) / L;
-                const int d0 = min(A.N, sl * dper);
-                base = (sw * (long long)(A.N + 1) + d0) * 7;
-                slen = min(A.N, d0 + dper) - d0;
-            } else {
-                const unsigned long long d = segdesc[seg];
-                base = (long long)(d >> 16);
-                slen = (int)(d & 0xffffULL);
-            }
+            const unsigned long long d = segdesc[seg];
+            const long long base = (long long)(d >> 16);
+            const int slen = (int)(d & 0xffffULL);
             const int kn = off / 7;                       // knot (1 + kn) of chunk 0
             const bool ok = slen >= 1 + kn;
             sptr[e] = A.knots + base + (ok ? 7 + off : off - 7 * kn);
@@ -219,47 +197,46 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     // Dense layout, not one of the last waves: reading a few knots past a short segment's end stays inside
     // the knot array, so the running pointers advance unconditionally (1 VALU per element per chunk).
     const bool safe_overread = (A.first == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W);
-    auto issue = [&](int it, double *stg) {   // chunks are issued in order: the pointers run ahead of the compute
+    auto issue = [&](int it) {
         if (safe_overread) {
 #pragma unroll
-            for (int e = 0; e < SEGD; ++e) { stg[e] = *sptr[e]; sptr[e] += SEGD; }
+            for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += SEGD; }
         } else {
 #pragma unroll
-            for (int e = 0; e < SEGD; ++e) { stg[e] = *sptr[e]; sptr[e] += (it < smax[e]) ? SEGD : 0; }
+            for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += (it < smax[e]) ? SEGD : 0; }
         }
     };
-    auto commit = [&](const double *stg) {
+    auto commit = [&]() {
 #pragma unroll
-        for (int e = 0; e < SEGD; ++e) tile[tofs[e]] = stg[e];
+        for (int e = 0; e < SEGD; ++e) tile[tofs[e]] = stage[e];
     };
 
+    // One chunk ahead: the HBM round trip of chunk it+1 overlaps the FP64 work of chunk it.  Measured alternatives
+    // at 10 k windows x 50 (L = 6, 13.1 us): 2 / 3 / 4 chunks ahead 13.7 / 14.4 / 14.7 us (the first chunk's data
+    // queues behind the later ones: first-chunk time 2.4 -> 3.0 -> 3.8 us); a double-buffered LDS tile with the
+    // next chunk read back into registers during the integration (no LDS latency on the serial chain) 13.3 us.
+    // Per-wavefront time stamps explain why: with 1000 wavefronts in flight a chunk is 3.6 MB and takes 0.89 us
+    // (0.74 us with 625 wavefronts, 1.2 us with 2000) -- the loop streams at ~4 TB/s and is paced by the memory
+    // system, not by the latency of one wavefront's accesses.
     const int nchunks = (maxlen + C - 1) / C;
-#pragma unroll
-    for (int d = 0; d < PFD; ++d)
-        if (d < nchunks) issue(d, stage[d]);
-    for (int it0 = 0; it0 < nchunks; it0 += PFD) {
-#pragma unroll
-        for (int b = 0; b < PFD; ++b) {
-            const int it = it0 + b;
-            if (it < nchunks) {
-                commit(stage[b]);
-                __syncthreads();
-                if (it + PFD < nchunks) issue(it + PFD, stage[b]);   // HBM round trips overlap the FP64 work
+    if (nchunks > 0) issue(0);
+    for (int it = 0; it < nchunks; ++it) {
+        commit();
+        __syncthreads();
+        if (it + 1 < nchunks) issue(it + 1);
 #pragma unroll   // C <= 2: the two steps of a chunk share one basic block (no knot copy between them)
-                for (int c = 0; c < C; ++c) {
-                    const int s = it * C + c;
-                    const double *nk = &tile[lane * PITCH + c * 7];
-                    double q[7];
+        for (int c = 0; c < C; ++c) {
+            const int s = it * C + c;
+            const double *nk = &tile[lane * PITCH + c * 7];
+            double q[7];
 #pragma unroll
-                    for (int i = 0; i < 7; i++) q[i] = nk[i];
-                    mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
-                                               mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, s < len);
+            for (int i = 0; i < 7; i++) q[i] = nk[i];
+            mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                       mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, s < len);
 #pragma unroll
-                    for (int i = 0; i < 7; i++) pk[i] = q[i];
-                }
-                __syncthreads();
-            }
+            for (int i = 0; i < 7; i++) pk[i] = q[i];
         }
+        __syncthreads();
     }
 
     // order-preserving composition tree over the L lanes of a window (earlier = lower lane)
