@@ -27,6 +27,8 @@ FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernel
 # Algorithmic HBM bytes per unit: read + write, f64, compulsory traffic only
 BYTES = {"v1_mean": 2856 + 88, "v1_full": 2856 + 2320, "v2_full": 2888 + 2392,
          "factor_v1": 776 + 3720, "factor_v2": 952 + 3720}
+# sparse-minimal FP64 flop per 50-sample window (0.35-0.5 M and 0.65-0.8 M; midpoints) -- an estimate
+FLOP_EST = {"v1_full": 0.425e6, "v2_full": 0.725e6}
 MALL_BYTES = 256 << 20
 # HBM traffic per launch measured with separate rocprofv3 --pmc passes of the same workloads
 # (profiles/r01_pmc_counters.md) and corrected as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE / WRITE_SIZE are
@@ -224,9 +226,13 @@ def main():
                 wall2, k2 = time_steps(w2, steps, 10)
                 ls = k2 * 1e-3 / steps
                 ach = BYTES[name] * Wx / ls / 1e9
-                extra.append({"workload": name, "units_per_step": Wx, "value": Wx * steps / wall2,
-                              "unit": "factors/s" if name.startswith("factor") else "windows/s",
-                              "launch_ms": ls * 1e3, "hbm_GBs": ach, "hbm_frac": ach / HBM_PEAK_GBS})
+                row = {"workload": name, "units_per_step": Wx, "value": Wx * steps / wall2,
+                       "unit": "factors/s" if name.startswith("factor") else "windows/s",
+                       "launch_ms": ls * 1e3, "hbm_GBs": ach, "hbm_frac": ach / HBM_PEAK_GBS}
+                if name in FLOP_EST:   # the covariance workloads are FP64-bound: estimate from SURVEY.md 8(d)'s
+                    row["fp64_TFLOPs_est"] = FLOP_EST[name] * Wx / ls / 1e12   # sparse-minimal flop counts (midpoints)
+                    row["fp64_frac_est"] = row["fp64_TFLOPs_est"] / FP64_PEAK_TFLOPS
+                extra.append(row)
                 del w2
                 torch.cuda.empty_cache()
             except Exception as ex:  # an extra config must never take the headline down

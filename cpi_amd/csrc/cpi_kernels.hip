@@ -13,8 +13,12 @@
 //        through a 9-row LDS transpose exchange; classic RK4.  Replaces CpiV1.h:266-353 / CpiV2.h:314-464.
 //   cpi_factor_kernel<MODEL,WHITEN,LPF> evaluateError residual + dense 15x15 H1/H2; LPF (16/8/4) lanes per
 //        factor, lane q emits columns q, q+LPF, ...  Replaces ImuFactorCPIv1.cpp:37-208 / ImuFactorCPIv2.cpp:38-212.
+//   cpi_sqrt_info_kernel               R = chol_upper(P^-1) per factor (GTSAM noiseModel::Gaussian::Covariance, called
+//        from ImuFactorCPIv1.h:82 / ImuFactorCPIv2.h:86): 16 lanes per factor, columns in registers, DPP row_share
+//        broadcasts, triangular inverse fused into the factorisation.
 //   cpi_predict_kernel<MODEL>          GraphSolver_IMU.cpp:263-307.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
