@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has many intervals (L <= 3: batches of
     // >= ~20 k windows; 20 k x 50 with L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us), 1 when a wave is
     // latency-bound with few intervals per lane (5 k with L = 12: 10.2 vs 10.6 us)
-    constexpr int C = (L <= 3 && !JAC) ? 2 : 1;
+    constexpr int C = (L <= 3 && !JAC) ? 2 : 1;   // (3 / 4 knots per chunk cost the second wavefront per SIMD: slower)
     constexpr int SEGD = 7 * C;       // doubles per lane per chunk
     constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
     __shared__ double tile[64 * PITCH];
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     const int grp = lane / L, l = lane - grp * L;
     long long w = (long long)blockIdx.x * WPB + grp;
     const bool valid = (w < A.W) && (grp < WPB);   // L not a power of two leaves 64 - WPB*L idle lanes
-    if (!valid) w = A.W - 1;
+    if (grp >= WPB) w = (long long)blockIdx.x * WPB;   // idle lanes shadow the block's first window (stays near the block)
+    if (w >= A.W) w = A.W - 1;
     const int n = A.count ? A.count[w] : A.N;
     const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
     const int per = (n + L - 1) / L;
@@ -180,8 +181,10 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     // spends ~3 VALU per element on addressing and no load is ever out of bounds.
     double stage[SEGD];
     const double *sptr[SEGD];
+    unsigned voff[SEGD];   // byte offset of the element from the block's first knot (dense layouts)
     int smax[SEGD];
     int tofs[SEGD];
+    const double *blk0 = A.knots + (long long)blockIdx.x * WPB * (long long)(A.N + 1) * 7;   // wave-uniform
     {
         int seg = lane / SEGD, off = lane - seg * SEGD;
 #pragma unroll
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
             const int kn = off / 7;                       // knot (1 + kn) of chunk 0
             const bool ok = slen >= 1 + kn;
             sptr[e] = A.knots + base + (ok ? 7 + off : off - 7 * kn);
+            voff[e] = (unsigned)((sptr[e] - blk0) * 8);   // only used when safe_overread (then 0 <= offset < 2^32)
             smax[e] = ok ? (slen - 1 - kn) / C : 0;       // never-valid elements keep re-reading knot 0
             tofs[e] = seg * PITCH + off;
             off += 64 % SEGD; seg += 64 / SEGD;   // idx advances by 64 per staged element
@@ -199,12 +203,17 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
         }
     }
     // Dense layout, not one of the last waves: reading a few knots past a short segment's end stays inside
-    // the knot array, so the running pointers advance unconditionally (1 VALU per element per chunk).
+    // the knot array, so every chunk is "block base + chunk stride (scalar) + constant lane offset".
     const bool safe_overread = (A.first == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W);
     auto issue = [&](int it) {
         if (safe_overread) {
+            // scalar base (advanced by SALU) + constant 32-bit lane offsets: no vector arithmetic per element
+            const char *cb = reinterpret_cast<const char *>(blk0) + (long long)it * (SEGD * 8);
 #pragma unroll
-            for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += SEGD; }
+            for (int e = 0; e < SEGD; ++e) {
+                asm volatile("" : "+v"(voff[e]));   // keeps the zero-extension next to the load: `global_load v, v_off32, s[base]`
+                stage[e] = *reinterpret_cast<const double *>(cb + voff[e]);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += (it < smax[e]) ? SEGD : 0; }
