@@ -26,7 +26,9 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernels are VALU-bound
 # Algorithmic HBM bytes per unit: read + write, f64, compulsory traffic only
 BYTES = {"v1_mean": 2856 + 88, "v1_full": 2856 + 2320, "v2_full": 2888 + 2392,
-         "factor_v1": 776 + 3720, "factor_v2": 952 + 3720}
+         "factor_v1": 776 + 3720, "factor_v2": 952 + 3720,
+         # packed evaluateError (state-dependent blocks only, include/cpi_amd.h): NOT the dense GTSAM-shaped output
+         "factor_v1_packed": 776 + 576, "factor_v2_packed": 952 + 576}
 # sparse-minimal FP64 flop per 50-sample window (0.35-0.5 M and 0.65-0.8 M; midpoints) -- an estimate
 FLOP_EST = {"v1_full": 0.425e6, "v2_full": 0.725e6}
 MALL_BYTES = 256 << 20
@@ -61,7 +63,8 @@ def parse():
 
 
 def default_size(workload):
-    return {"v1_mean": 10000, "v1_full": 100000, "v2_full": 100000, "factor_v1": 1000000, "factor_v2": 1000000}[workload]
+    return {"v1_mean": 10000, "v1_full": 100000, "v2_full": 100000, "factor_v1": 1000000, "factor_v2": 1000000,
+            "factor_v1_packed": 1000000, "factor_v2_packed": 1000000}[workload]
 
 
 class Workload:
@@ -73,7 +76,8 @@ class Workload:
         dev = eng.device
         self.eng = eng
         if name.startswith("factor"):
-            model = 1 if name.endswith("v1") else 2
+            model = 1 if "v1" in name else 2
+            self.packed = name.endswith("_packed")
             self.model = model
             kn, lin, q = synth.make_windows(W, N, seed=seed, device=dev)
             self.meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac"))
@@ -83,9 +87,12 @@ class Workload:
                                        model, device=dev)
             self.states = torch.cat([xi, xj[-1:]], dim=0).contiguous()   # chained states: idx_i=f, idx_j=f+1
             self.lin, self.q = lin, (q if model == 2 else None)
-            self.out = {"err": torch.empty((W, 15), dtype=torch.float64, device=dev),
-                        "H1": torch.empty((W, 225), dtype=torch.float64, device=dev),
-                        "H2": torch.empty((W, 225), dtype=torch.float64, device=dev)}
+            if self.packed:
+                self.out = torch.empty((W, 72), dtype=torch.float64, device=dev)
+            else:
+                self.out = {"err": torch.empty((W, 15), dtype=torch.float64, device=dev),
+                            "H1": torch.empty((W, 225), dtype=torch.float64, device=dev),
+                            "H2": torch.empty((W, 225), dtype=torch.float64, device=dev)}
             self.nbatch = 1   # 4.5 GB per sweep: far beyond the Infinity Cache by itself
             return
         model = 2 if name.startswith("v2") else 1
@@ -101,6 +108,9 @@ class Workload:
 
     def step(self):
         if self.name.startswith("factor"):
+            if self.packed:
+                self.eng.factor_eval_packed(self.model, self.meas, self.lin, self.q, self.states, out=self.out)
+                return {"packed": self.out}
             self.eng.factor_eval(self.model, self.meas, self.lin, self.q, self.states, out=self.out)
             return self.out
         kn, lin, q = self.batches[self.i % self.nbatch]
@@ -210,7 +220,9 @@ def main():
                      "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_counters.md)",
                      "algorithmic_bytes_per_launch": BYTES[a.workload] * W,
                      "kernel": {"v1_mean": "cpi_mean_kernel", "v1_full": "cpi_cov_kernel<1>", "v2_full": "cpi_cov_kernel<2>",
-                                "factor_v1": "cpi_factor_kernel<1,false,8>", "factor_v2": "cpi_factor_kernel<2,false,8>"}[a.workload],
+                                "factor_v1": "cpi_factor_kernel<1,false,8>", "factor_v2": "cpi_factor_kernel<2,false,8>",
+                                "factor_v1_packed": "cpi_factor_packed_kernel<1>",
+                                "factor_v2_packed": "cpi_factor_packed_kernel<2>"}[a.workload],
                      "launch_us": launch_s * 1e6, "algorithmic_bytes_per_unit": BYTES[a.workload]},
     }
     if rank == 0 and world == 1 and not a.no_cpu and not is_factor:
@@ -220,7 +232,8 @@ def main():
         del wl
         torch.cuda.empty_cache()
         for name, Wx, steps in (("v1_mean", 1000000, 40), ("v1_full", 100000, 30), ("v2_full", 100000, 30),
-                                ("factor_v1", 1000000, 40), ("factor_v2", 1000000, 40)):
+                                ("factor_v1", 1000000, 40), ("factor_v2", 1000000, 40),
+                                ("factor_v1_packed", 1000000, 40), ("factor_v2_packed", 1000000, 40)):
             try:
                 w2 = Workload(eng, name, Wx, a.samples, seed=4242, pool_bytes=MALL_BYTES * 5 // 4)
                 wall2, k2 = time_steps(w2, steps, 10)

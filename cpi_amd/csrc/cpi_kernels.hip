@@ -502,32 +502,17 @@ struct FieldFetch {
     }
 };
 
-// LPF lanes per factor (16, 8 or 4), FPW = 64 / LPF factors per wavefront.  Every lane evaluates the shared
-// quaternion algebra of its factor (so it is done LPF times per factor); lane q of a factor then owns columns
-// q, q + LPF, ... of H1 / H2.  The sweep is HBM-WRITE bound (3 720 of 4 496 B per factor are the dense 15x15
-// pair), so the columns are transposed through LDS and leave the wavefront as full, consecutive 16-byte stores:
-// the FPW factors' H1 blocks are one contiguous FPW x 1 800-byte span of the output (measured on MI355X: that
-// pattern stores at 4.8 TB/s, per-column 120/240-byte pieces at 2.5 TB/s -- which rules out one lane per factor).
-// LPF = 16 has the most wavefronts (small sweeps fill the chip); LPF = 8 / 4 do 2x / 4x less redundant arithmetic.
-#ifndef CPI_FACTOR_WPS
-#define CPI_FACTOR_WPS 1
-#endif
-template <int MODEL, bool WHITEN, int LPF>
-__global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
-    constexpr int FPW = 64 / LPF;                // factors per wavefront
-    constexpr int CPL = (15 + LPF - 1) / LPF;    // columns per lane
-    constexpr int HB = FPW * 225;                // doubles of H1 (or H2) per wavefront
-    constexpr int O_ALPHA = 0, O_BETA = 3, O_Q = 6, O_LIN = 10, O_JQ = 16, O_JB = 25, O_JA = 34, O_HB = 43, O_HA = 52,
-                  O_DT = 61, O_QK = 62, O_OB = 66, O_OA = 75, O_XI = 84, O_XJ = 100, IN_D = 116;
-    __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
-    __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];         // the factors' input records
-    __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the factors' R
-    const int lane = threadIdx.x;
-    const int q = lane % LPF, fl = lane / LPF;
-    const long long f0 = (long long)blockIdx.x * FPW;
-    const int nf = (int)min((long long)FPW, A.F - f0);
+// Record layout of one factor in the LDS staging area (doubles)
+namespace fin {
+constexpr int O_ALPHA = 0, O_BETA = 3, O_Q = 6, O_LIN = 10, O_JQ = 16, O_JB = 25, O_JA = 34, O_HB = 43, O_HA = 52,
+              O_DT = 61, O_QK = 62, O_OB = 66, O_OA = 75, O_XI = 84, O_XJ = 100, IN_D = 116;
+}
+template <int MODEL, int FPW, bool WHITEN>
+__device__ __forceinline__ void factor_fetch_inputs(const FactorArgs &A, long long f0, int nf, int lane, double *sIn,
+                                                    double *sR) {
+    using namespace fin;
     constexpr bool whiten = WHITEN;
-
+    constexpr int HB = FPW * 225;
     // ---- cooperative, de-duplicated input fetch: every double of the FPW factors' records is loaded from HBM
     // exactly once per wavefront (consecutive lanes = consecutive doubles of one SoA field) into LDS, from
     // where the lanes of a factor read it as broadcasts.  All loads are issued unconditionally (clamped
@@ -581,13 +566,47 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
                 if (lane + 64 * r < HB) sR[lane + 64 * r] = R_[r];
         }
     }
-    __syncthreads();
-    const double *in = sIn + fl * IN_D;
-    FactorMeas m;   // every field is read from LDS where it is used
+}
+// All fields of a staged record, by reference (read where they are used).
+__device__ __forceinline__ FactorMeas factor_meas_of(const double *in, const double grav[3]) {
+    using namespace fin;
+    FactorMeas m;
     m.alpha = in + O_ALPHA; m.beta = in + O_BETA; m.q_KtoK1 = in + O_Q; m.lin = in + O_LIN; m.J_q = in + O_JQ;
     m.J_beta = in + O_JB; m.J_alpha = in + O_JA; m.H_beta = in + O_HB; m.H_alpha = in + O_HA; m.dt = in + O_DT;
     m.q_K_lin = in + O_QK; m.O_beta = in + O_OB; m.O_alpha = in + O_OA; m.xi = in + O_XI; m.xj = in + O_XJ;
-    m.grav = mk(A.grav[0], A.grav[1], A.grav[2]);
+    m.grav = mk(grav[0], grav[1], grav[2]);
+    return m;
+}
+
+// LPF lanes per factor (16, 8 or 4), FPW = 64 / LPF factors per wavefront.  Every lane evaluates the shared
+// quaternion algebra of its factor (so it is done LPF times per factor); lane q of a factor then owns columns
+// q, q + LPF, ... of H1 / H2.  The sweep is HBM-WRITE bound (3 720 of 4 496 B per factor are the dense 15x15
+// pair), so the columns are transposed through LDS and leave the wavefront as full, consecutive 16-byte stores:
+// the FPW factors' H1 blocks are one contiguous FPW x 1 800-byte span of the output (measured on MI355X: that
+// pattern stores at 4.8 TB/s, per-column 120/240-byte pieces at 2.5 TB/s -- which rules out one lane per factor).
+// LPF = 16 has the most wavefronts (small sweeps fill the chip); LPF = 8 / 4 do 2x / 4x less redundant arithmetic.
+#ifndef CPI_FACTOR_WPS
+#define CPI_FACTOR_WPS 1
+#endif
+template <int MODEL, bool WHITEN, int LPF>
+__global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
+    constexpr int FPW = 64 / LPF;                // factors per wavefront
+    constexpr int CPL = (15 + LPF - 1) / LPF;    // columns per lane
+    constexpr int HB = FPW * 225;                // doubles of H1 (or H2) per wavefront
+    constexpr int IN_D = fin::IN_D;
+    __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
+    __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];         // the factors' input records
+    __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the factors' R
+    const int lane = threadIdx.x;
+    const int q = lane % LPF, fl = lane / LPF;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const int nf = (int)min((long long)FPW, A.F - f0);
+    constexpr bool whiten = WHITEN;
+
+    factor_fetch_inputs<MODEL, FPW, WHITEN>(A, f0, nf, lane, sIn, sR);
+    __syncthreads();
+    const double *in = sIn + fl * IN_D;
+    const FactorMeas m = factor_meas_of(in, A.grav);   // every field is read from LDS where it is used
     double *s1 = sH, *se = sH + HB;
     const double *Rf = sR + fl * 225;
     const int nd = nf * 225, ne = nf * 15;
@@ -674,6 +693,72 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
             flush(A.H2 + f0 * 225, s1, nd);
         }
     }
+}
+
+// Packed evaluateError: only what depends on the current states (cpi_factor_eval_packed_batch, include/cpi_amd.h).
+// Of the 450 doubles of the dense H1 / H2 pair, 54 depend on the states -- the 3x3 blocks H1(0,0), H1(6,0),
+// H1(12,0), H1(0,3), H2(0,0) and R(q_GtoK), which appears five times; the rest is 0, +-I or a copy of a measurement
+// field the caller already holds.  72 doubles per factor (15 residual + 6 blocks + 3 of padding, 576 B = 36 x 16 B)
+// instead of 465: the sweep stops being bound by the write of mostly-constant matrices.
+// 8 lanes per factor: lane q = 0..2 owns column q of H1 (blocks (0,0), (6,0), (12,0)), of H2(0,0) and of R(q_GtoK);
+// lane q = 3..5 owns column q of H1 (block (0,3)); residual rows q and q + 8.
+constexpr int FACTOR_PACKED_DOUBLES = 72;
+template <int MODEL>
+__global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, double *packed) {
+    constexpr int LPF = 8, FPW = 8, PD = FACTOR_PACKED_DOUBLES, IN_D = fin::IN_D;
+    __shared__ __attribute__((aligned(16))) double sP[FPW * PD];
+    __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];
+    __shared__ double sDummy[2];
+    const int lane = threadIdx.x;
+    const int q = lane % LPF, fl = lane / LPF;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const int nf = (int)min((long long)FPW, A.F - f0);
+    factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sIn, sDummy);
+    __syncthreads();
+    const double *in = sIn + fl * IN_D;
+    const FactorMeas m = factor_meas_of(in, A.grav);
+    double *out = sP + fl * PD;
+    FactorShared S;
+    {
+        V3 e5[5];
+        factor_shared_core<MODEL>(m, S, e5);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int c = q + LPF * k;
+            if (c < 15) {
+                const V3 ec = pick5(e5[0], e5[1], e5[2], e5[3], e5[4], c / 3);
+                out[c] = sel3(ec.x, ec.y, ec.z, c % 3);
+            }
+        }
+    }
+    const Q4 qi = ldq(m.xi);
+    if (q < 6) {
+        double h[15];
+        S.bc = q / 3; S.cc = q - 3 * S.bc;
+        S.u = unit(S.cc);
+        S.rku = qrot(qi, S.u);
+        factor_H1_column<MODEL>(S, m, h);
+        if (q < 3) {
+            double *b = out + 15 + 3 * q;                    // H1(0,0), H1(6,0), H1(12,0): column q of each
+            b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
+            b[9] = h[6]; b[10] = h[7]; b[11] = h[8];
+            b[18] = h[12]; b[19] = h[13]; b[20] = h[14];
+            double h2[15];
+            factor_H2_column(S, h2);
+            double *r = out + 51 + 3 * q;                    // R(q_GtoK) column q, then H2(0,0) column q
+            r[0] = S.rku.x; r[1] = S.rku.y; r[2] = S.rku.z;
+            r[9] = h2[0]; r[10] = h2[1]; r[11] = h2[2];
+        } else {
+            double *b = out + 42 + 3 * (q - 3);              // H1(0,3) column q - 3
+            b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
+        }
+    } else if (q == 6) {
+        out[69] = 0.0; out[70] = 0.0; out[71] = 0.0;
+    }
+    wave_lds_fence();
+    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
+    d2u *dst = reinterpret_cast<d2u *>(packed + f0 * PD);
+    for (int i = lane; i < nf * (PD / 2); i += 64) { d2u v; v.a = sP[2 * i]; v.b = sP[2 * i + 1]; dst[i] = v; }
 }
 
 // R = chol_upper(P^-1) = B^-1 with P = B B^T, B upper triangular ("reverse" Cholesky, from the last pivot up).
@@ -1016,6 +1101,34 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
     }
 #undef CPI_LAUNCH_FACTOR_L
 #undef CPI_LAUNCH_FACTOR
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+
+extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                            const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                            const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                            double *packed) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: model must be 1 or 2");
+    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: negative size");
+    if (F == 0) return CPI_OK;
+    if (!grav || !meas || !lin || !states || !packed) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: NULL argument");
+    if (!meas->DT || !meas->alpha || !meas->beta || !meas->q || !meas->J_q || !meas->J_a || !meas->J_b || !meas->H_a || !meas->H_b)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
+    if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
+        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: model 2 needs q_k_lin, O_a, O_b");
+    if (F > ((int64_t)1 << 33)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: F too large for one launch");
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    FactorArgs a;
+    memset(&a, 0, sizeof a);
+    a.F = F;
+    for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
+    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.idx_i = idx_i; a.idx_j = idx_j;
+    const unsigned nb = (unsigned)((F + 7) / 8);
+    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_packed_kernel<1>), dim3(nb), dim3(64), 0, ctx->stream, a, packed);
+    else hipLaunchKernelGGL((cpi_factor_packed_kernel<2>), dim3(nb), dim3(64), 0, ctx->stream, a, packed);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }

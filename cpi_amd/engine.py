@@ -145,6 +145,19 @@ class Engine:
                                                                 _ptr(out.get("H2"))))
         return out
 
+    def factor_eval_packed(self, model, meas, lin, q_k_lin, states, idx_i=None, idx_j=None, grav=DEFAULT_GRAV, out=None):
+        """State-dependent part of evaluateError only: [F,72] = err[15] + the 3x3 blocks H1(0,0), H1(6,0), H1(12,0),
+        H1(0,3), R(q_GtoK), H2(0,0) (column-major) + 3 zeros; see include/cpi_amd.h.  unpack_factor() rebuilds the
+        dense pair."""
+        F = lin.shape[0]
+        if out is None:
+            out = torch.empty((F, 72), dtype=torch.float64, device=self.device)
+        m = self._outputs_struct(meas)
+        g = (C.c_double * 3)(*grav)
+        self._check(self.lib.cpi_factor_eval_packed_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin),
+                                                          _ptr(states), _ptr(idx_i), _ptr(idx_j), _ptr(out)))
+        return out
+
     def predict(self, model, meas, states_i, idx_i=None, grav=DEFAULT_GRAV):
         F = meas["DT"].shape[0]
         xj = torch.empty((F, 16), dtype=torch.float64, device=self.device)
@@ -152,6 +165,32 @@ class Engine:
         g = (C.c_double * 3)(*grav)
         self._check(self.lib.cpi_predict_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(states_i), _ptr(idx_i), _ptr(xj)))
         return xj
+
+
+def unpack_factor(packed, meas):
+    """Dense (err [F,15], H1 [F,225], H2 [F,225], column-major) from the packed evaluation and the measurement it was
+    computed from -- the block table of include/cpi_amd.h (ImuFactorCPIv1.cpp:109-143,169-185)."""
+    F = packed.shape[0]
+    dev, f64 = packed.device, packed.dtype
+    blk = lambda o: packed[:, o:o + 9].reshape(F, 3, 3).transpose(1, 2)      # column-major -> [row][col]
+    cm = lambda t: t.reshape(F, 3, 3).transpose(1, 2)
+    H1 = torch.zeros((F, 15, 15), dtype=f64, device=dev)
+    H2 = torch.zeros((F, 15, 15), dtype=f64, device=dev)
+    eye = torch.eye(3, dtype=f64, device=dev).expand(F, 3, 3)
+    Rk = blk(51)
+    H1[:, 0:3, 0:3], H1[:, 6:9, 0:3], H1[:, 12:15, 0:3], H1[:, 0:3, 3:6] = blk(15), blk(24), blk(33), blk(42)
+    H1[:, 3:6, 3:6] = -eye
+    H1[:, 9:12, 9:12] = -eye
+    H1[:, 6:9, 3:6], H1[:, 6:9, 6:9], H1[:, 6:9, 9:12] = -cm(meas["J_b"]), -Rk, -cm(meas["H_b"])
+    H1[:, 12:15, 3:6], H1[:, 12:15, 6:9] = -cm(meas["J_a"]), -meas["DT"][:, None, None] * Rk
+    H1[:, 12:15, 9:12], H1[:, 12:15, 12:15] = -cm(meas["H_a"]), -Rk
+    H2[:, 0:3, 0:3] = blk(60)
+    H2[:, 3:6, 3:6] = eye
+    H2[:, 6:9, 6:9] = Rk
+    H2[:, 9:12, 9:12] = eye
+    H2[:, 12:15, 12:15] = Rk
+    return (packed[:, 0:15].contiguous(), H1.transpose(1, 2).reshape(F, 225).contiguous(),
+            H2.transpose(1, 2).reshape(F, 225).contiguous())
 
 
 _default_engine = None

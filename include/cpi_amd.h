@@ -113,6 +113,24 @@ int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int
                           const double *states, const int32_t *idx_i, const int32_t *idx_j,
                           double *err, double *H1, double *H2);
 
+/* Fast path of the same evaluation for callers that assemble their own Hessian blocks (note on
+ * a11): of the 450 doubles of the dense H1 / H2 pair only 54 depend on the current states; everything else is 0, +-I
+ * or a copy of a measurement field the caller already holds.  packed [F][72] (576 B per factor), 3x3 blocks
+ * column-major:
+ *    [ 0..14]  err                                   (ImuFactorCPIv1.cpp:81-88)
+ *    [15..23]  H1(0,0)   d e_theta / d theta_K       (:109)          [24..32]  H1(6,0)   d e_v / d theta_K   (:120)
+ *    [33..41]  H1(12,0)  d e_p / d theta_K           (:132)          [42..50]  H1(0,3)   d e_theta / d b_g,K (:112)
+ *    [51..59]  Rk = quat_2_Rot(q_GtoK)                               [60..68]  H2(0,0)   d e_theta / d theta_K+1 (:169)
+ *    [69..71]  0 (padding to a multiple of 16 bytes)
+ * The remaining blocks of the dense pair follow from these and the measurement (ImuFactorCPIv1.cpp:113-143,172-185):
+ *    H1(3,3) = H1(9,9) = -I;  H1(6,3) = -J_beta;  H1(6,6) = -Rk;  H1(6,9) = -H_beta;  H1(12,3) = -J_alpha;
+ *    H1(12,6) = -deltatime Rk;  H1(12,9) = -H_alpha;  H1(12,12) = -Rk;  H2 = blkdiag(H2(0,0), I, Rk, I, Rk);  all others 0.
+ * Same arguments as cpi_factor_eval_batch.  (cpi_amd.unpack_factor in the Python mirror rebuilds the dense pair.) */
+int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                 const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                 const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                 double *packed);
+
 /* Replaces: gtsam::noiseModel::Gaussian::Covariance(P_meas) in the factor constructors
  * (ImuFactorCPIv1.h:82, ImuFactorCPIv2.h:86).  GTSAM (bitbucket gtborg/gtsam @ c21186c6, not in the
  * reference tree) builds the square-root information  R = chol_upper(P^-1)  (Gaussian::Covariance ->

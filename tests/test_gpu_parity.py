@@ -443,3 +443,35 @@ def test_large_rotation_angles_take_the_reduced_sincos_path(eng, orc):
         assert cov_rel_err(out["P"][ok], ref["P"][ok]) <= 1e-6
         m = _run(eng, mode, kn, lin, q, want=("mean",))
         assert np.abs(m["q"] - ref["q"]).max() <= 1e-9
+
+
+# --------------------------------------------------------------------------- packed evaluateError
+@pytest.mark.parametrize("model", [1, 2])
+def test_packed_factor_eval_rebuilds_the_dense_pair(eng, model):
+    """cpi_factor_eval_packed_batch: the 15 + 54 state-dependent doubles, expanded with the block table of
+    include/cpi_amd.h, must reproduce the dense evaluateError output bit for bit (same device arithmetic)."""
+    import cpi_amd
+    F = 40003                                              # not a multiple of 8: ragged last wavefront
+    kn, lin, q = synth.make_windows(F, 50, seed=123, device=eng.device)
+    meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac"))
+    torch.cuda.synchronize()
+    xi, xj = synth.make_states(meas["alpha"], meas["beta"], meas["q"], meas["DT"], lin, model, device=eng.device)
+    states = torch.cat([xi, xj[-1:]], dim=0).contiguous()
+    qq = q if model == 2 else None
+    dense = eng.factor_eval(model, meas, lin, qq, states)
+    packed = eng.factor_eval_packed(model, meas, lin, qq, states)
+    torch.cuda.synchronize()
+    assert packed.shape == (F, 72) and (packed[:, 69:] == 0).all()
+    err, H1, H2 = cpi_amd.unpack_factor(packed, meas)
+    assert torch.equal(err, dense["err"])
+    # -0.0 vs 0.0 in the constant blocks is not a difference
+    assert (H1 - dense["H1"]).abs().max().item() == 0.0
+    assert (H2 - dense["H2"]).abs().max().item() == 0.0
+    # gathered states
+    idx_i = torch.randint(0, F, (F,), dtype=torch.int32, device=eng.device)
+    idx_j = torch.randint(0, F + 1, (F,), dtype=torch.int32, device=eng.device)
+    d2 = eng.factor_eval(model, meas, lin, qq, states, idx_i=idx_i, idx_j=idx_j)
+    p2 = eng.factor_eval_packed(model, meas, lin, qq, states, idx_i=idx_i, idx_j=idx_j)
+    torch.cuda.synchronize()
+    e2, H12, H22 = cpi_amd.unpack_factor(p2, meas)
+    assert torch.equal(e2, d2["err"]) and (H12 - d2["H1"]).abs().max().item() == 0.0 and (H22 - d2["H2"]).abs().max().item() == 0.0

@@ -52,11 +52,14 @@ def main():
         t_pl = timeit(lambda: eng.factor_eval(model, meas, lin, qq, states, out=out))
         t_wh = timeit(lambda: eng.factor_eval(model, meas, lin, qq, states, out=out, sqrt_info=R))
         t_pr = timeit(lambda: eng.predict(model, meas, states))
+        pk = torch.empty((F, 72), dtype=torch.float64, device=dev)
+        t_pk = timeit(lambda: eng.factor_eval_packed(model, meas, lin, qq, states, out=pk))
         gb = lambda b, ms: b * F / (ms * 1e-3) / 1e9
         in_b = 776 if model == 1 else 952
         print("model %d F=%d  sqrt_info %.3f ms (%.0f GB/s)  factor %.3f ms (%.0f GB/s)  whitened %.3f ms (%.0f GB/s)  "
-              "predict %.3f ms (%.0f GB/s)" % (model, F, t_sq, gb(3600, t_sq), t_pl, gb(in_b + 3720, t_pl),
-                                              t_wh, gb(in_b + 3720 + 1800, t_wh), t_pr, gb(88 + 128 + 128, t_pr)), flush=True)
+              "predict %.3f ms (%.0f GB/s)  packed factor %.3f ms (%.0f GB/s)" % (
+                  model, F, t_sq, gb(3600, t_sq), t_pl, gb(in_b + 3720, t_pl), t_wh, gb(in_b + 3720 + 1800, t_wh),
+                  t_pr, gb(88 + 128 + 128, t_pr), t_pk, gb(in_b + 576, t_pk)), flush=True)
         del P, R, out, meas, states
         torch.cuda.empty_cache()
 
