@@ -251,11 +251,18 @@ def main():
             except Exception as ex:  # an extra config must never take the headline down
                 extra.append({"workload": name, "error": repr(ex)})
         res["extra"] = extra
-    if rank == 0:
-        print(json.dumps(res))
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its banner through C stdio: flush that first so the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
