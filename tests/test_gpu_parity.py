@@ -475,3 +475,49 @@ def test_packed_factor_eval_rebuilds_the_dense_pair(eng, model):
     torch.cuda.synchronize()
     e2, H12, H22 = cpi_amd.unpack_factor(p2, meas)
     assert torch.equal(e2, d2["err"]) and (H12 - d2["H1"]).abs().max().item() == 0.0 and (H22 - d2["H2"]).abs().max().item() == 0.0
+
+
+# --------------------------------------------------------------------------- randomized shapes
+def test_fuzz_random_shapes_layouts_and_lane_splits(eng, orc):
+    """40 random (W, N, model, imu_avg, Jacobian mode, dense | ragged, lanes per window) combinations against the
+    oracle: every supported lane split meets ragged tails, empty windows, short windows (N < L) and both
+    staging variants of the mean kernel (one / two knots per chunk)."""
+    rng = np.random.default_rng(20240917)
+    lanes_all = [0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64]
+    for case in range(40):
+        W = int(rng.integers(1, 260))
+        N = int(rng.integers(1, 90))
+        model = int(rng.integers(1, 3))
+        avg = int(rng.integers(0, 2))
+        stj = int(rng.integers(0, 2)) if model == 2 else 1
+        ragged = bool(rng.integers(0, 2))
+        lanes = int(rng.choice(lanes_all)) if model == 1 else 0
+        label = "case %d W%d N%d m%d avg%d stj%d %s L%d" % (case, W, N, model, avg, stj, "ragged" if ragged else "dense", lanes)
+        oprm = orc.make_params(model, avg, stj)
+        prm = eng.make_params(model, avg, stj, lanes_per_window=lanes)
+        want = ("mean",) if case % 3 == 0 else ("mean", "jac", "cov")
+        if not ragged:
+            kn, lin, q = synth.make_windows(W, N, seed=5000 + case)
+            kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
+            ref = orc.oracle().run(oprm, kn, lin, q)
+            out = _host(eng.preintegrate(_dev(kn, eng), _dev(lin, eng), _dev(q, eng), prm, want=want))
+        else:
+            lens = rng.integers(0, N + 1, W).astype(np.int32)
+            lens[rng.integers(0, W)] = N
+            K = int(lens.sum()) + 1
+            kn1, _, _ = synth.make_windows(1, max(K - 1, 1), seed=6000 + case, edge_cases=False)
+            stream = kn1.numpy()[0][:K]
+            first = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            _, lin, q = synth.make_windows(W, 4, seed=7000 + case)
+            lin, q = lin.numpy(), q.numpy()
+            out = _host(eng.preintegrate(_dev(stream, eng), _dev(lin, eng), _dev(q, eng), prm, want=want,
+                                         first=_dev(first, eng), count=_dev(lens, eng), N=N))
+            ref = None
+            for w in range(W):
+                n = int(lens[w])
+                r = orc.oracle().run(oprm, stream[first[w]:first[w] + n + 1][None], lin[w:w + 1], q[w:w + 1])
+                if ref is None:
+                    ref = {k: np.zeros((W,) + v.shape[1:]) for k, v in r.items()}
+                for k in ref:
+                    ref[k][w] = r[k][0]
+        check_pre(out, ref, what=want, v2=(model == 2), label=label)
