@@ -231,12 +231,13 @@ def main():
         extra = []
         del wl
         torch.cuda.empty_cache()
-        for name, Wx, steps in (("v1_mean", 1000000, 40), ("v1_full", 100000, 30), ("v2_full", 100000, 30),
+        for name, Wx, steps in (("v1_mean", 30000, 1000), ("v1_mean", 100000, 300), ("v1_mean", 1000000, 40),
+                                ("v1_full", 100000, 30), ("v2_full", 100000, 30),
                                 ("factor_v1", 1000000, 40), ("factor_v2", 1000000, 40),
                                 ("factor_v1_packed", 1000000, 40), ("factor_v2_packed", 1000000, 40)):
             try:
                 w2 = Workload(eng, name, Wx, a.samples, seed=4242, pool_bytes=MALL_BYTES * 5 // 4)
-                wall2, k2 = time_steps(w2, steps, 10)
+                wall2, k2 = time_steps(w2, steps, max(10, steps // 10))
                 ls = k2 * 1e-3 / steps
                 ach = BYTES[name] * Wx / ls / 1e9
                 row = {"workload": name, "units_per_step": Wx, "value": Wx * steps / wall2,
