@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from cpi_amd import synth
-from tests.tol import TOL_FACTOR, TOL_MEAN, check_pre, cov_rel_err
+from tests.tol import TOL_COV, TOL_FACTOR, TOL_MEAN, check_pre, cov_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -521,3 +521,33 @@ def test_fuzz_random_shapes_layouts_and_lane_splits(eng, orc):
                 for k in ref:
                     ref[k][w] = r[k][0]
         check_pre(out, ref, what=want, v2=(model == 2), label=label)
+
+
+@pytest.mark.parametrize("dt_scale,w_scale,a_scale", [(0.02, 1.0, 1.0), (1.0, 4.0, 1.0), (4.0, 1.0, 1.0), (1.0, 1.0, 40.0),
+                                                      (0.2, 8.0, 10.0)])
+def test_dynamic_range_stress(eng, orc, dt_scale, w_scale, a_scale):
+    """Sampling rates from 50 Hz to 10 kHz, rates up to ~20 rad/s, specific forces up to ~500 m/s^2 (all inside the
+    stability region |w| dt < 1.3 of the reference's RK4): relative parity must not depend on the scales."""
+    W = 600
+    kn, lin, q = synth.make_windows(W, 50, seed=31337, edge_cases=False)
+    kn = kn.clone()
+    t0 = kn[:, :1, 0].clone()
+    kn[:, :, 0] = t0 + (kn[:, :, 0] - t0) * dt_scale
+    kn[:, :, 1:4] *= w_scale
+    kn[:, :, 4:7] *= a_scale
+    lin = lin.clone()
+    lin[:, 0:3] *= w_scale
+    lin[:, 3:6] *= a_scale
+    kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
+    assert (np.abs(kn[:, :, 1:4]).max() * np.diff(kn[:, :, 0], axis=1).max()) < 1.3
+    for mode in [(1, 0, 1), (2, 0, 1), (1, 1, 1)]:
+        ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=os.cpu_count() or 1)
+        out = _run(eng, mode, kn, lin, q)
+        # means: relative to the magnitude of the quantity (alpha grows with a dt^2 N^2)
+        for k in ("DT", "alpha", "beta", "q"):
+            scale = max(1.0, float(np.abs(ref[k]).max()))
+            assert np.abs(out[k] - ref[k]).max() <= TOL_MEAN * scale, (mode, k)
+        assert cov_rel_err(out["P"], ref["P"]) <= TOL_COV, mode
+        for k in ("J_q", "J_a", "J_b", "H_a", "H_b"):
+            scale = max(1.0, float(np.abs(ref[k]).max()))
+            assert np.abs(out[k] - ref[k]).max() <= 1e-8 * scale, (mode, k)
