@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernels are VALU-bound
 # Algorithmic HBM bytes per unit: read + write, f64, compulsory traffic only
-BYTES = {"v1_mean": 2856 + 88, "v1_full": 2856 + 2320, "v2_full": 2888 + 2392,
+BYTES = {"v1_mean": 2856 + 88, "v2_mean": 2888 + 88, "v1_full": 2856 + 2320, "v2_full": 2888 + 2392,
          "factor_v1": 776 + 3720, "factor_v2": 952 + 3720,
          # packed evaluateError (state-dependent blocks only, include/cpi_amd.h): NOT the dense GTSAM-shaped output
          "factor_v1_packed": 776 + 576, "factor_v2_packed": 952 + 576}
@@ -63,7 +63,7 @@ def parse():
 
 
 def default_size(workload):
-    return {"v1_mean": 10000, "v1_full": 100000, "v2_full": 100000, "factor_v1": 1000000, "factor_v2": 1000000,
+    return {"v1_mean": 10000, "v2_mean": 10000, "v1_full": 100000, "v2_full": 100000, "factor_v1": 1000000, "factor_v2": 1000000,
             "factor_v1_packed": 1000000, "factor_v2_packed": 1000000}[workload]
 
 
@@ -219,7 +219,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a.workload, W, a.samples),
                      "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_counters.md)",
                      "algorithmic_bytes_per_launch": BYTES[a.workload] * W,
-                     "kernel": {"v1_mean": "cpi_mean_kernel", "v1_full": "cpi_cov_kernel<1>", "v2_full": "cpi_cov_kernel<2>",
+                     "kernel": {"v1_mean": "cpi_mean_kernel", "v2_mean": "cpi_mean_kernel", "v1_full": "cpi_cov_kernel<1>", "v2_full": "cpi_cov_kernel<2>",
                                 "factor_v1": "cpi_factor_kernel<1,false,8>", "factor_v2": "cpi_factor_kernel<2,false,8>",
                                 "factor_v1_packed": "cpi_factor_packed_kernel<1>",
                                 "factor_v2_packed": "cpi_factor_packed_kernel<2>"}[a.workload],

@@ -89,6 +89,11 @@ __device__ __forceinline__ MeanState<JAC> shfl_down(const MeanState<JAC> &s, int
     }
     return r;
 }
+__device__ __forceinline__ GravAcc shfl_down(const GravAcc &g, int d) {
+    GravAcc r;
+    r.Gam = shfl_down(g.Gam, d); r.Lam = shfl_down(g.Lam, d);
+    return r;
+}
 // Orders LDS traffic of a single-wavefront workgroup for the COMPILER only: a wave's DS instructions execute
 // in issue order, so no counter drain (and no s_barrier) is needed between a write and a dependent read.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -132,7 +137,7 @@ struct PreArgs {
 #define CPI_MEAN_WPS 1
 #endif
 template <int MODEL, bool JAC, bool AVG, int L>
-__global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
+__global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
     constexpr int WPB = 64 / L;       // windows per wavefront
     // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has many intervals (L <= 3: batches of
     // >= ~20 k windows; 20 k x 50 with L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us), 1 when a wave is
@@ -172,6 +177,11 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
     }
     MeanState<JAC> st;
     mean_init(st);
+    // model 2, mean-only, several lanes per window: a lane integrates its segment from the raw specific force and
+    // accumulates the segment's gravity response (cpi_math.hpp: mean_step_v2seg); gravity is applied after the tree
+    constexpr bool GSEG = (MODEL == 2) && !JAC && (L > 1);
+    GravAcc ga;
+    if (GSEG) grav_init(ga);
     __syncthreads();
 
     // Tile element idx = e*64 + lane belongs to segment idx / SEGD at offset idx % SEGD, so consecutive
@@ -244,8 +254,12 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
             double q[7];
 #pragma unroll
             for (int i = 0; i < 7; i++) q[i] = nk[i];
-            mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
-                                       mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, s < len);
+            if constexpr (GSEG)
+                mean_step_v2seg<AVG>(st, ga, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                     mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, s < len);
+            else
+                mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                           mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, s < len);
 #pragma unroll
             for (int i = 0; i < 7; i++) pk[i] = q[i];
         }
@@ -256,12 +270,16 @@ __global__ __launch_bounds__(64, CPI_MEAN_WPS) void cpi_mean_kernel(PreArgs A) {
 #pragma unroll
     for (int stp = 1; stp < L; stp <<= 1) {
         MeanState<JAC> B = shfl_down(st, stp);
+        GravAcc gB;
+        if constexpr (GSEG) gB = shfl_down(ga, stp);
         if ((L & (L - 1)) != 0) {
             // L not a power of two: lane l + stp may belong to the next window -- compose with the identity instead
-            if (l + stp >= L) mean_init(B);
+            if (l + stp >= L) { mean_init(B); if (GSEG) grav_init(gB); }
         }
+        if constexpr (GSEG) grav_combine(ga, st, gB, B);   // needs st.R / B.DT before they are composed
         mean_combine(st, B);
     }
+    if constexpr (GSEG) grav_apply(st, ga, gk);
 
     if (valid && l == 0) {
         if (A.write_means) {
@@ -927,8 +945,11 @@ static bool mean_lanes_supported(int L) {
     for (int c : kMeanLanes) if (c == L) return true;
     return false;
 }
-static int pick_lanes(const cpi_params *prm, int64_t W, int N) {
-    if (prm->model == CPI_MODEL_V2) return 1;  // model 2 means depend on the running rotation: sequential per window
+static int pick_lanes(const cpi_params *prm, int64_t W, int N, bool jac) {
+    // model 2 with analytic Jacobians: sequential per window (the O_a / O_b recursion is not composed); model 2
+    // mean-only composes through the gravity response matrices at roughly twice the arithmetic per interval
+    if (prm->model == CPI_MODEL_V2 && jac) return 1;
+    const double t_int = (prm->model == CPI_MODEL_V2) ? 1.2 : 0.55, t_lvl = (prm->model == CPI_MODEL_V2) ? 0.6 : 0.3;
     int L = prm->lanes_per_window;
     if (L <= 0) {
         // Small batches are latency-bound: as long as every wavefront gets a SIMD of its own (<= 1024 wavefronts
@@ -944,7 +965,7 @@ static int pick_lanes(const cpi_params *prm, int64_t W, int N) {
             if (c > 1 && waves > 1024) break;
             int levels = 0;
             while ((1 << levels) < c) levels++;
-            const double cost = 0.55 * (double)((N + c - 1) / c) + 0.3 * levels;
+            const double cost = t_int * (double)((N + c - 1) / c) + t_lvl * levels;
             if (cost < best) { best = cost; L = c; }
         }
     }
@@ -958,7 +979,7 @@ static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
         const long long nb = (a.W + (64 / LL) - 1) / (64 / LL);                                  \
         hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL>), dim3((unsigned)nb), dim3(64), 0, st, a); \
     } break;
-    if constexpr (MODEL == 2) { switch (L) { CPI_LAUNCH_L(1) default: break; } } else
+    if constexpr (MODEL == 2 && JAC) { switch (L) { CPI_LAUNCH_L(1) default: break; } } else
     switch (L) {
         CPI_LAUNCH_L(1) CPI_LAUNCH_L(2) CPI_LAUNCH_L(3) CPI_LAUNCH_L(4) CPI_LAUNCH_L(5) CPI_LAUNCH_L(6) CPI_LAUNCH_L(8)
         CPI_LAUNCH_L(12) CPI_LAUNCH_L(16) CPI_LAUNCH_L(32) CPI_LAUNCH_L(64)
@@ -1034,7 +1055,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
         PreArgs m = a;
         m.write_means = (want_mean && !run_cov) ? 1 : 0;
         m.write_jac = mean_jac ? 1 : 0;
-        const int LL = mean_jac && v2 ? 1 : pick_lanes(prm, W, N);
+        const int LL = pick_lanes(prm, W, N, mean_jac);
         if (v2) launch_mean<2>(mean_jac, avg, LL, m, ctx->stream); else launch_mean<1>(mean_jac, avg, LL, m, ctx->stream);
     }
     CPI_HIP(ctx, hipGetLastError());

@@ -511,6 +511,83 @@ CPI_HD void mean_combine(MeanState<JAC> &A, const MeanState<JAC> &B) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Model-2 means over a SEGMENT of a window (several lanes per window).  Model 2 integrates the local specific force
+// a_hat = a_m - b_a - R g_k (CpiV2.h:99), which depends on the rotation R accumulated since the START OF THE WINDOW --
+// unknown to a lane that starts in the middle.  It enters linearly: with R = R_loc R_A (R_A = everything before the
+// segment) and g' = R_A g_k,
+//     beta_seg(g')  = beta0  - Gam g',     Gam = sum_i R_new,i^T Beta_arg,i  Rg_i
+//     alpha_seg(g') = alpha0 - Lam g',     Lam: same recursion as alpha with (Gam, alpha_arg) in place of (beta, .)
+// where beta0 / alpha0 are integrated from a_m - b_a alone, all rotations are the segment's own, and
+// Rg_i = R_old,i (or (R_old,i + R_new,i)/2 with imu_avg, CpiV2.h:146-149).  Segments compose like the means,
+//     Gam_AB = Gam_A + R_A^T Gam_B R_A,      Lam_AB = Lam_A + Gam_A DT_B + R_A^T Lam_B R_A,
+// and the window's means are beta0 - Gam g_k, alpha0 - Lam g_k.
+struct GravAcc { M3 Gam, Lam; };
+CPI_HD void grav_init(GravAcc &g) { g.Gam = zero3(); g.Lam = zero3(); }
+// One interval of a model-2 segment: means from the raw specific force into s (R local), gravity response into g.
+template <bool AVG>
+CPI_HD void mean_step_v2seg(MeanState<false> &s, GravAcc &g, double t0, double t1, V3 w0, V3 a0, V3 w1, V3 a1,
+                            V3 bw, V3 ba, bool active = true) {
+    double dt = t1 - t0;
+    if (!(active && dt > 0)) dt = 0;   // exact no-op, as in mean_step
+    s.DT += dt;
+    V3 w = w0 - bw;
+    V3 a = a0 - ba;
+    if (AVG) { w = 0.5 * (w + (w1 - bw)); a = 0.5 * (a + (a1 - ba)); }
+    const StepCoef k = step_coef(w, dt);
+    M3 Rg = s.R;                       // R_old (local)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const V3 r = col(s.R, c);
+        const V3 wr = cross(w, r), wwr = cross(w, wr);
+        const V3 rn = axpy(k.s2, wwr, axpy(-k.s1, wr, r));
+        s.R.m[0][c] = rn.x; s.R.m[1][c] = rn.y; s.R.m[2][c] = rn.z;
+    }
+    if (AVG) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Rg.m[i][j] = 0.5 * (Rg.m[i][j] + s.R.m[i][j]);
+    }
+    V3 ua, ub;
+    arg_times(w, a, k, ua, ub);
+    s.alpha = s.alpha + (dt * s.beta + mulT(s.R, ua));
+    s.beta = s.beta + mulT(s.R, ub);
+    // gravity response: columns of alpha_arg Rg and Beta_arg Rg, then R_new^T (.)
+    M3 Am, Bm;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        V3 ca, cb;
+        arg_times(w, col(Rg, c), k, ca, cb);
+        Am.m[0][c] = ca.x; Am.m[1][c] = ca.y; Am.m[2][c] = ca.z;
+        Bm.m[0][c] = cb.x; Bm.m[1][c] = cb.y; Bm.m[2][c] = cb.z;
+    }
+    const M3 dL = mTm(s.R, Am), dG = mTm(s.R, Bm);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            g.Lam.m[i][j] = (g.Lam.m[i][j] + dt * g.Gam.m[i][j]) + dL.m[i][j];   // old Gam, like alpha uses old beta
+            g.Gam.m[i][j] += dG.m[i][j];
+        }
+}
+// A (earlier) o B (later); call BEFORE mean_combine(A, B) (needs A.R and B.DT as they are).
+CPI_HD void grav_combine(GravAcc &gA, const MeanState<false> &A, const GravAcc &gB, const MeanState<false> &B) {
+    const M3 tG = mm(mTm(A.R, gB.Gam), A.R), tL = mm(mTm(A.R, gB.Lam), A.R);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            gA.Lam.m[i][j] = (gA.Lam.m[i][j] + gA.Gam.m[i][j] * B.DT) + tL.m[i][j];
+            gA.Gam.m[i][j] += tG.m[i][j];
+        }
+}
+// Window result from the composed segment: subtract the gravity response to g_k = R(q_k_lin) g.
+CPI_HD void grav_apply(MeanState<false> &s, const GravAcc &g, V3 gk) {
+    s.beta = s.beta - mul(g.Gam, gk);
+    s.alpha = s.alpha - mul(g.Lam, gk);
+}
+
+// ------------------------------------------------------------------------------------------
 // Covariance / state-transition column recursion (kernel "cpi_cov").
 //
 // One lane owns ONE COLUMN x of the (symmetric) covariance -- or, for model 2, one column of the

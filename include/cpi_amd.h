@@ -47,7 +47,8 @@ typedef struct {
     int32_t model;                       /* CPI_MODEL_V1 | CPI_MODEL_V2 */
     int32_t imu_avg;                     /* 0 / 1 */
     int32_t state_transition_jacobians;  /* model 2 only; reference default 1 */
-    int32_t lanes_per_window;            /* mean kernel: 0 = auto, else 1,2,3,4,5,6,8,12,16,32,64 (tuning knob) */
+    int32_t lanes_per_window;            /* mean kernel: 0 = auto, else 1,2,3,4,5,6,8,12,16,32,64 (tuning knob;
+                                            ignored by the covariance kernel and by model 2 with analytic Jacobians) */
 } cpi_params;
 
 /* Replaces: the public result members of CpiBase / CpiV2 (CpiBase.h:99-124, CpiV2.h:62-63).

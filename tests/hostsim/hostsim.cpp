@@ -20,6 +20,31 @@ void mean_window(int L, int n, const double *kn, const double *lin, const double
     V3 gk = mk(0, 0, 0);
     if (MODEL == 2) gk = mul(quat_2_Rot(ldq(qk)), ld3(grav));
     const int per = (n + L - 1) / L;
+    if constexpr (MODEL == 2 && !JAC) {
+        if (L > 1) {   // several lanes per window: segment form with the gravity response matrices (as the kernel)
+            std::vector<MeanState<false>> sg(L);
+            std::vector<GravAcc> ga(L);
+            for (int l = 0; l < L; l++) {
+                mean_init(sg[l]); grav_init(ga[l]);
+                const int s0 = std::min(n, l * per), s1 = std::min(n, s0 + per);
+                for (int s = s0; s < s1; s++) {
+                    const double *k0 = kn + 7 * s, *k1 = kn + 7 * (s + 1);
+                    mean_step_v2seg<AVG>(sg[l], ga[l], k0[0], k1[0], ld3(k0 + 1), ld3(k0 + 4), ld3(k1 + 1), ld3(k1 + 4), bw, ba);
+                }
+            }
+            for (int st = 1; st < L; st *= 2)
+                for (int l = 0; l + st < L; l += 2 * st) { grav_combine(ga[l], sg[l], ga[l + st], sg[l + st]); mean_combine(sg[l], sg[l + st]); }
+            grav_apply(sg[0], ga[0], gk);
+            const MeanState<false> &s = sg[0];
+            o[0] = s.DT;
+            o[1] = s.alpha.x; o[2] = s.alpha.y; o[3] = s.alpha.z;
+            o[4] = s.beta.x; o[5] = s.beta.y; o[6] = s.beta.z;
+            const Q4 q = rot_2_quat(s.R);
+            o[7] = q.x; o[8] = q.y; o[9] = q.z; o[10] = q.w;
+            put_cm(o + 11, s.R);
+            return;
+        }
+    }
     std::vector<MeanState<JAC>> seg(L);
     for (int l = 0; l < L; l++) {
         mean_init(seg[l]);

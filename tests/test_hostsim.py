@@ -25,7 +25,8 @@ def _mode_out(d, m):
 
 @pytest.mark.parametrize("fname", ["pre_cfg1.npz", "pre_w48.npz"])
 @pytest.mark.parametrize("model,avg,jac,L", [(1, 0, 0, 1), (1, 0, 0, 16), (1, 1, 0, 64), (1, 0, 1, 1), (1, 0, 1, 8),
-                                              (1, 1, 1, 32), (2, 0, 0, 1), (2, 1, 0, 1), (2, 0, 1, 1), (2, 1, 1, 1)])
+                                              (1, 1, 1, 32), (2, 0, 0, 1), (2, 1, 0, 1), (2, 0, 1, 1), (2, 1, 1, 1),
+                                              (2, 0, 0, 2), (2, 0, 0, 6), (2, 1, 0, 5), (2, 1, 0, 16), (2, 0, 0, 64)])
 def test_mean_kernel_math(golden_dir, fname, model, avg, jac, L):
     d = _gold(golden_dir, fname)
     out = op.split_out(hs.mean(model, jac, avg, L, d["knots"], d["lin"], d["q_k_lin"]))
