@@ -31,6 +31,16 @@ BYTES = {"v1_mean": 2856 + 88, "v2_mean": 2888 + 88, "v1_full": 2856 + 2320, "v2
          "factor_v1_packed": 776 + 576, "factor_v2_packed": 952 + 576}
 # sparse-minimal FP64 flop per 50-sample window (0.35-0.5 M and 0.65-0.8 M; midpoints) -- an estimate
 FLOP_EST = {"v1_full": 0.425e6, "v2_full": 0.725e6}
+
+
+def bytes_per_unit(workload, samples=50):
+    """a window reads samples*56 + 8 + 48 (+32 for q_k_lin) bytes; the table above is that figure at
+    50 samples.  Factor workloads do not depend on the window length."""
+    if workload.startswith("factor"):
+        return BYTES[workload]
+    return BYTES[workload] + (samples - 50) * 56
+
+
 MALL_BYTES = 256 << 20
 # HBM traffic per launch measured with separate rocprofv3 --pmc passes of the same workloads
 # (profiles/r01_pmc_counters.md) and corrected as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE / WRITE_SIZE are
@@ -204,7 +214,8 @@ def main():
     units = W * world * a.steps
     value = units / wall
     launch_s = kern_ms * 1e-3 / a.steps
-    achieved = BYTES[a.workload] * W / launch_s / 1e9
+    bpu = bytes_per_unit(a.workload, a.samples)
+    achieved = bpu * W / launch_s / 1e9
     is_factor = a.workload.startswith("factor")
     res = {
         "metric": "evaluateError factors/sec" if is_factor else "preintegration windows/sec (50-sample windows)",
@@ -218,12 +229,12 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a.workload, W, a.samples),
                      "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_counters.md)",
-                     "algorithmic_bytes_per_launch": BYTES[a.workload] * W,
+                     "algorithmic_bytes_per_launch": bpu * W,
                      "kernel": {"v1_mean": "cpi_mean_kernel", "v2_mean": "cpi_mean_kernel", "v1_full": "cpi_cov_kernel<1>", "v2_full": "cpi_cov_kernel<2>",
                                 "factor_v1": "cpi_factor_kernel<1,false,8>", "factor_v2": "cpi_factor_kernel<2,false,8>",
                                 "factor_v1_packed": "cpi_factor_packed_kernel<1>",
                                 "factor_v2_packed": "cpi_factor_packed_kernel<2>"}[a.workload],
-                     "launch_us": launch_s * 1e6, "algorithmic_bytes_per_unit": BYTES[a.workload]},
+                     "launch_us": launch_s * 1e6, "algorithmic_bytes_per_unit": bpu},
     }
     if rank == 0 and world == 1 and not a.no_cpu and not is_factor:
         res["cpu_baseline"] = cpu_baseline(wl)
@@ -239,7 +250,7 @@ def main():
                 w2 = Workload(eng, name, Wx, a.samples, seed=4242, pool_bytes=MALL_BYTES * 5 // 4)
                 wall2, k2 = time_steps(w2, steps, max(10, steps // 10))
                 ls = k2 * 1e-3 / steps
-                ach = BYTES[name] * Wx / ls / 1e9
+                ach = bytes_per_unit(name, a.samples) * Wx / ls / 1e9
                 row = {"workload": name, "units_per_step": Wx, "value": Wx * steps / wall2,
                        "unit": "factors/s" if name.startswith("factor") else "windows/s",
                        "launch_ms": ls * 1e3, "hbm_GBs": ach, "hbm_frac": ach / HBM_PEAK_GBS}

@@ -27,7 +27,7 @@ def main():
         for rep in range(3):
             wall, k_ms = bench.time_steps(wl, steps, 5)
             best = min(best, k_ms * 1e3 / steps)
-        gbs = bench.BYTES[name] * W / (best * 1e-6) / 1e9
+        gbs = bench.bytes_per_unit(name, 50) * W / (best * 1e-6) / 1e9
         print("%-18s %-10s W=%-8d L=%-3d launch_us=%10.2f  units/s=%.4g  GB/s=%.1f  frac=%.3f" % (
             tag, name, W, lanes, best, W / (best * 1e-6), gbs, gbs / 8000.0), flush=True)
         del wl
