@@ -220,29 +220,37 @@ CPI_HD void mag_and_inverse(double m2, double &mag, double &im) {
 // ------------------------------------------------------------------------------------------
 // quaternion helpers (quat_ops.h)
 CPI_HD Q4 rot_2_quat(const M3 &R) {  // quat_ops.h:45-86
+    // sqrt(x) and 1/sqrt(x) come from ONE v_rsq_f64 seed (mag_and_inverse) instead of a sqrt and a division each:
+    // q_c = sqrt(d / 4) = sqrt(d) / 2 and 1 / (4 q_c) = 1 / (2 sqrt(d)); the final normalisation multiplies by 1 / |q|.
     const double r00 = R.m[0][0], r11 = R.m[1][1], r22 = R.m[2][2];
     const double T = r00 + r11 + r22;
     Q4 q;
+    double m, im;
     if ((r00 >= T) && (r00 >= r11) && (r00 >= r22)) {
-        q.x = sqrt((1 + (2 * r00) - T) / 4);
-        const double k = 1 / (4 * q.x);
+        mag_and_inverse(1 + (2 * r00) - T, m, im);
+        q.x = 0.5 * m;
+        const double k = 0.5 * im;
         q.y = k * (R.m[0][1] + R.m[1][0]); q.z = k * (R.m[0][2] + R.m[2][0]); q.w = k * (R.m[1][2] - R.m[2][1]);
     } else if ((r11 >= T) && (r11 >= r00) && (r11 >= r22)) {
-        q.y = sqrt((1 + (2 * r11) - T) / 4);
-        const double k = 1 / (4 * q.y);
+        mag_and_inverse(1 + (2 * r11) - T, m, im);
+        q.y = 0.5 * m;
+        const double k = 0.5 * im;
         q.x = k * (R.m[0][1] + R.m[1][0]); q.z = k * (R.m[1][2] + R.m[2][1]); q.w = k * (R.m[2][0] - R.m[0][2]);
     } else if ((r22 >= T) && (r22 >= r00) && (r22 >= r11)) {
-        q.z = sqrt((1 + (2 * r22) - T) / 4);
-        const double k = 1 / (4 * q.z);
+        mag_and_inverse(1 + (2 * r22) - T, m, im);
+        q.z = 0.5 * m;
+        const double k = 0.5 * im;
         q.x = k * (R.m[0][2] + R.m[2][0]); q.y = k * (R.m[1][2] + R.m[2][1]); q.w = k * (R.m[0][1] - R.m[1][0]);
     } else {
-        q.w = sqrt((1 + T) / 4);
-        const double k = 1 / (4 * q.w);
+        mag_and_inverse(1 + T, m, im);
+        q.w = 0.5 * m;
+        const double k = 0.5 * im;
         q.x = k * (R.m[1][2] - R.m[2][1]); q.y = k * (R.m[2][0] - R.m[0][2]); q.z = k * (R.m[0][1] - R.m[1][0]);
     }
     if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
-    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+    double n, in;
+    mag_and_inverse(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, n, in);
+    q.x *= in; q.y *= in; q.z *= in; q.w *= in;
     return q;
 }
 CPI_HD M3 quat_2_Rot(Q4 q) {  // quat_ops.h:104-109
