@@ -140,9 +140,10 @@ template <int MODEL, bool JAC, bool AVG, int L>
 __global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
     constexpr int WPB = 64 / L;       // windows per wavefront
     // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has several intervals (L <= 6; 20 k x 50 with
-    // L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us, 15 k with L = 4: 16.0 -> 15.3 us, 10 k with L = 5:
-    // 13.5 -> 12.55 us against 12.85 us for L = 6 with one knot per chunk), 1 when a wave is latency-bound with few
-    // intervals per lane (5 k with L = 12: 10.2 vs 10.6 us); 3 / 4 knots per chunk cost the second wavefront per SIMD
+    // L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us, 15 k with L = 4: 16.0 -> 15.3 us, 10 k with L = 6:
+    // 12.5 -> 11.8 us once the padded second step of an odd last chunk is skipped), 1 when a wave is latency-bound
+    // with few intervals per lane (5 k with L = 12: 10.2 vs 10.6 us); 3 / 4 knots per chunk cost the second
+    // wavefront per SIMD
     constexpr int C = (L <= 6 && !JAC) ? 2 : 1;
     constexpr int SEGD = 7 * C;       // doubles per lane per chunk
     constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_
 #pragma unroll   // C <= 2: the two steps of a chunk share one basic block (no knot copy between them)
         for (int c = 0; c < C; ++c) {
             const int s = it * C + c;
+            if (C > 1 && s >= maxlen) break;   // wave-uniform: no lane has this interval (odd longest segment)
             const double *nk = &tile[lane * PITCH + c * 7];
             double q[7];
 #pragma unroll
@@ -957,7 +959,7 @@ static int pick_lanes(const cpi_params *prm, int64_t W, int N, bool jac) {
         // on MI355X) the launch lasts as long as one wavefront -- intervals per lane plus composition levels
         // (measured: ~0.55 us per interval, ~0.3 us per level).  Splitting further makes wavefronts share SIMDs
         // and loses; batches with more than 1024 single-lane wavefronts are throughput-bound and want L = 1.
-        // Measured optima: L = 12 at 5 k windows x 50, 5 at 10 k, 4 at 15 k, 3 at 20 k, 2 at 30 k, 1 from ~60 k.
+        // Measured optima: L = 12 at 5 k windows x 50, 6 at 10 k, 4 at 15 k, 3 at 20 k, 2 at 30 k, 1 from ~60 k.
         double best = 1e300;
         L = 1;
         for (int c : kMeanLanes) {
@@ -966,9 +968,7 @@ static int pick_lanes(const cpi_params *prm, int64_t W, int N, bool jac) {
             if (c > 1 && waves > 1024) break;
             int levels = 0;
             while ((1 << levels) < c) levels++;
-            int per = (N + c - 1) / c;
-            if (c <= 6 && !jac) per = (per + 1) & ~1;   // those kernels integrate two knots per chunk
-            const double cost = t_int * (double)per + t_lvl * levels;
+            const double cost = t_int * (double)((N + c - 1) / c) + t_lvl * levels;
             if (cost < best) { best = cost; L = c; }
         }
     }
