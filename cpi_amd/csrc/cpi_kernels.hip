@@ -139,12 +139,12 @@ struct PreArgs {
 template <int MODEL, bool JAC, bool AVG, int L>
 __global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
     constexpr int WPB = 64 / L;       // windows per wavefront
-    // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has several intervals (L <= 6; 20 k x 50 with
+    // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has several intervals (L <= 8; 20 k x 50 with
     // L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us, 15 k with L = 4: 16.0 -> 15.3 us, 10 k with L = 6:
     // 12.5 -> 11.8 us once the padded second step of an odd last chunk is skipped), 1 when a wave is latency-bound
-    // with few intervals per lane (5 k with L = 12: 10.2 vs 10.6 us); 3 / 4 knots per chunk cost the second
+    // with few intervals per lane (L >= 12: 5 k windows 9.55 vs 9.65 us, 2.5 k 7.7 vs 8.0 us); 3 / 4 knots per chunk cost the second
     // wavefront per SIMD
-    constexpr int C = (L <= 6 && !JAC) ? 2 : 1;
+    constexpr int C = (L <= 8 && !JAC) ? 2 : 1;
     constexpr int SEGD = 7 * C;       // doubles per lane per chunk
     constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
     __shared__ double tile[64 * PITCH];
