@@ -194,12 +194,14 @@ CPI_HD void sincos_fast(double x, double &s, double &c) {
     c = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
 }
 // |w| and 1/|w| from ONE reciprocal-square-root seed + Newton (device); sqrt + divide on the host.
-// m2 == 0 (or denormal) returns mag = 0, im = 0: such a rate is far below the Taylor threshold, whose
-// branch never uses im.
+// Host: m2 == 0 (or denormal) returns mag = 0, im = 0.  Device: such an argument is clamped (see below); either way the
+// rate is far below the Taylor threshold, whose branch never uses im.
 CPI_HD void mag_and_inverse(double m2, double &mag, double &im) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const bool tiny = !(m2 > 1e-280);
-    const double a = tiny ? 1.0 : m2;
+    // One v_max instead of a compare and six selects: an argument below 1e-280 (exact zero, NaN) is treated as
+    // 1e-280, i.e. mag = 1e-140 and im = 1e140 -- every caller either takes its small-angle branch on such a
+    // magnitude (|w| < 0.0087) or only ever passes O(1) arguments (rot_2_quat) / checks positivity itself.
+    const double a = fmax(m2, 1e-280);
     double y = __builtin_amdgcn_rsq(a);          // ~2^-26 relative
     double g = a * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
@@ -208,8 +210,8 @@ CPI_HD void mag_and_inverse(double m2, double &mag, double &im) {
     g = fma(d, h, g);                            // sqrt(a), <= 1 ulp
     r = fma(-h, g, 0.5);
     h = fma(h, r, h);                            // 1/(2 sqrt(a)), <= 1 ulp
-    mag = tiny ? 0.0 : g;
-    im = tiny ? 0.0 : 2.0 * h;
+    mag = g;
+    im = 2.0 * h;
 #else
     mag = sqrt(m2);
     im = (m2 > 1e-280) ? 1.0 / mag : 0.0;
