@@ -178,10 +178,9 @@ CPI_HD void sincos_poly(double x, double &s, double &c) {
     CPI_HORNER(pc, z, -0.5);                             // x^2
     c = fma(z, pc, 1.0);
 }
-CPI_HD void sincos_fast(double x, double &s, double &c) {
-    const double ax = fabs(x);
-    if (ax <= 0.25) { sincos_poly<false>(x, s, c); return; }   // every lane of a wave, for any physical input
-    if (ax <= 1.0) { sincos_poly<true>(x, s, c); return; }
+// |x| > 0.25: long polynomial up to 1, Cody-Waite reduction beyond
+CPI_HD void sincos_wide(double x, double &s, double &c) {
+    if (fabs(x) <= 1.0) { sincos_poly<true>(x, s, c); return; }
     // pi/2 split into three parts with trailing zero bits (the classic fdlibm constants)
     const double k = rint(x * 6.36619772367581382433e-01);
     double r = fma(-k, 1.57079632673412561417e+00, x);
@@ -192,6 +191,23 @@ CPI_HD void sincos_fast(double x, double &s, double &c) {
     const int q = ((int)(long long)k) & 3;
     s = (q == 0) ? sr : ((q == 1) ? cr : ((q == 2) ? -sr : -cr));
     c = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
+}
+CPI_HD void sincos_fast(double x, double &s, double &c) {
+    const bool wide = fabs(x) > 0.25;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Every lane of a wave takes the short polynomial for any physical input (|w| dt <= 0.25 rad per interval); the
+    // wide path runs under a WAVE-UNIFORM test, so the common case costs one compare and one scalar branch instead of
+    // two levels of exec-mask bookkeeping.
+    sincos_poly<false>(x, s, c);
+    if (__builtin_amdgcn_ballot_w64(wide) != 0) {
+        double s2, c2;
+        sincos_wide(x, s2, c2);
+        s = wide ? s2 : s;
+        c = wide ? c2 : c;
+    }
+#else
+    if (wide) sincos_wide(x, s, c); else sincos_poly<false>(x, s, c);
+#endif
 }
 // |w| and 1/|w| from ONE reciprocal-square-root seed + Newton (device); sqrt + divide on the host.
 // Host: m2 == 0 (or denormal) returns mag = 0, im = 0.  Device: such an argument is clamped (see below); either way the
