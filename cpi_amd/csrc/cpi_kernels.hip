@@ -236,10 +236,11 @@ __global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_
         for (int e = 0; e < SEGD; ++e) tile[tofs[e]] = stage[e];
     };
 
-    // One chunk ahead: the HBM round trip of chunk it+1 overlaps the FP64 work of chunk it.  Measured alternatives
-    // at 10 k windows x 50 (L = 6, 13.1 us): 2 / 3 / 4 chunks ahead 13.7 / 14.4 / 14.7 us (the first chunk's data
-    // queues behind the later ones: first-chunk time 2.4 -> 3.0 -> 3.8 us); a double-buffered LDS tile with the
-    // next chunk read back into registers during the integration (no LDS latency on the serial chain) 13.3 us.
+    // One chunk ahead: the HBM round trip of chunk it+1 overlaps the FP64 work of chunk it.  Measured alternatives:
+    // a TRUE two-chunk pipeline (two register stages, every path issuing the same loads so that hipcc emits the partial
+    // wait s_waitcnt vmcnt(14) -- one conditional issue in the loop and it drains the queue with vmcnt(0)) is 8 % slower
+    // at 10 k windows x 50 (13.5 vs 12.5 us: the first chunk's data queues behind the second's) and 5 % slower at 1 M;
+    // a double-buffered LDS tile with the next chunk read back into registers during the integration: +2 %.
     // Per-wavefront time stamps explain why: with 1000 wavefronts in flight a chunk is 3.6 MB and takes 0.89 us
     // (0.74 us with 625 wavefronts, 1.2 us with 2000) -- the loop streams at ~4 TB/s and is paced by the memory
     // system, not by the latency of one wavefront's accesses.
