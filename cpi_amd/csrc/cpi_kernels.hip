@@ -421,10 +421,13 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
         for (int sl = 0; sl < cnt; ++sl) {
             const double *ir = irs + (g * CH + sl) * IRD;  // group-uniform address: LDS broadcast
             cov_begin<MODEL>(Ln, ir, hoff);
+            M3 Rs;
 #pragma unroll
             for (int stg = 0; stg < 4; ++stg) {
                 double M[9];
-                cov_stage_M(Ln, stg, ir, M);
+                // stages 1 and 2 share R_mid: read it once (5 fewer LDS broadcasts per interval; -3 % / -1.5 %)
+                if (stg != 2) Rs = cov_stage_rotation(ir, stg);
+                cov_stage_M(Ln, stg, Rs, M);
                 if (jj < D::NPCOL) {
 #pragma unroll
                     for (int rr = 0; rr < 9; rr++) ex_g[rr * EP + jj] = M[rr];

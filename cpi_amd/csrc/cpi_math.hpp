@@ -847,11 +847,12 @@ CPI_HD void cov_begin(CovLane<MODEL> &L, const double *ir, int hoff) {
 }
 
 // Stage s: M = rows (theta, v, p) of F x for this lane's column (+ half its own diagonal process noise).
-// Classic RK4 stage rotations R_old, R_mid, R_mid, R_new (CpiV1.h:279,300,332) come from the record.
+// Classic RK4 stage rotations R_old, R_mid, R_mid, R_new (CpiV1.h:279,300,332) come from the record (Rs).
+// The stage rotation of the record: R_old, R_mid, R_mid, R_new.
+CPI_HD M3 cov_stage_rotation(const double *ir, int s) { return rec_mat(ir, (s == 0) ? IR_ROLD : ((s == 3) ? IR_RNEW : IR_RMID)); }
 template <int MODEL>
-CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, const double *ir, double M[9]) {
+CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, const M3 &Rs, double M[9]) {
     const double *X = (s == 0) ? L.P0 : L.X;   // s is a compile-time constant after unrolling
-    const M3 Rs = rec_mat(ir, (s == 0) ? IR_ROLD : ((s == 3) ? IR_RNEW : IR_RMID));
     const V3 xt = mk(X[0], X[1], X[2]);
     const V3 xbw = mk(X[3], X[4], X[5]);
     const V3 xba = mk(X[9], X[10], X[11]);
