@@ -322,15 +322,17 @@ __global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_
 #ifndef CPI_COV_WPS
 #define CPI_COV_WPS 2
 #endif
-#ifndef CPI_COV_CHDIV
-#define CPI_COV_CHDIV 2
-#endif
 template <int MODEL, bool AVG>
 __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     typedef CovDims<MODEL> D;
     constexpr int GROUP = D::GROUP;   // lanes per window
     constexpr int G = 64 / GROUP;     // windows per wavefront
-    constexpr int CH = GROUP / CPI_COV_CHDIV;   // intervals per window processed by one phase-A pass
+    // intervals per window staged by one phase-A pass: as many as 20 KB of LDS per wavefront (two wavefronts per
+    // SIMD) leave room for -- 12 x 34 doubles (model 1), 20 x 50 doubles (model 2).  A pass costs as much as 2.3-2.5
+    // intervals of phase C (measured: 68 / 114 us per pass at 100 k windows), so fewer passes matter:
+    // 50 samples = 5 instead of 7 passes (model 1), 3 instead of 4 (model 2).
+    constexpr int CH = (MODEL == 1) ? 12 : 20;
+    static_assert(CH <= GROUP, "one lane per staged interval");
     constexpr int EP = EXCH_PITCH;
     constexpr int IRD = IrSize<MODEL>::V;
     __shared__ __attribute__((aligned(16))) double irs[G * CH * IRD];          // interval records (phase A -> C)
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
             for (int stg = 0; stg < 4; ++stg) {
                 double M[9];
                 // stages 1 and 2 share R_mid: read it once (5 fewer LDS broadcasts per interval; -3 % / -1.5 %)
-                if (stg != 2) Rs = cov_stage_rotation(ir, stg);
+                if (stg != 2) Rs = cov_stage_rotation<MODEL>(ir, stg);
                 cov_stage_M(Ln, stg, Rs, M);
                 if (jj < D::NPCOL) {
 #pragma unroll

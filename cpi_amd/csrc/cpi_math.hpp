@@ -682,13 +682,20 @@ CPI_HD void rec_put_mat(double *rp, int at, const M3 &A) {
 CPI_HD V3 rec_v3(const double *rp, int at) { return mk(rp[at], rp[at + 1], rp[at + 2]); }
 CPI_HD void put3(double *o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 
-// ---- phase A -> phase C interval record (doubles; every vector / matrix starts on a 16-byte boundary).
+// ---- phase A -> phase C interval record (doubles, tightly packed: the reads are 8-byte-aligned ds_read2_b64 pairs).
 // Phase A does ALL the work that the lanes of a group share -- closed forms, the running rotation (a prefix
 // product over the chunk's intervals), the three RK4 stage rotations, gravity terms and the mean increments --
-// once per interval, lane-parallel over intervals; phase C only reads it back as LDS broadcasts.
-static const int IR_DT = 0, IR_W = 2, IR_A = 6, IR_GTAU = 10, IR_ROLD = 14, IR_RMID = 24, IR_RNEW = 34,
-                 IR_ZERO = 44, IR_H = 48 /* model 2: 3 vectors of 4, R_old (g_k x e_l), l = 0..2 */;
-template <int MODEL> struct IrSize { static const int V = (MODEL == 1) ? 48 : 60; };   // doubles per record
+// once per interval, lane-parallel over intervals; phase C only reads it back as LDS broadcasts.  A small record
+// matters twice: fewer LDS bytes per interval, and more intervals per phase-A pass in the same LDS budget.
+template <int MODEL> struct IrL;
+template <> struct IrL<1> {   // dt, w, a, R_old, R_mid, R_new
+    static const int DT = 0, W = 1, A = 4, ROLD = 7, RMID = 16, RNEW = 25, SIZE = 34;
+    static const int GTAU = 0, H = 0, ZERO = 0;   // unused
+};
+template <> struct IrL<2> {   // + g_tau, h_l = R_old (g_k x e_l) for l = 0..2, three zeros
+    static const int DT = 0, W = 1, A = 4, GTAU = 7, ROLD = 10, RMID = 19, RNEW = 28, H = 37, ZERO = 46, SIZE = 50;
+};
+template <int MODEL> struct IrSize { static const int V = IrL<MODEL>::SIZE; };   // doubles per record
 // group-shared carry across chunks: running rotation and means
 static const int GS_R = 0, GS_ALPHA = 10, GS_BETA = 14, GS_DT = 18, GS_GK = 20 /* model 2: R(q_k_lin) g */, GS_DOUBLES = 24;
 CPI_HD void cov_gs_init(double *gs) {
@@ -724,18 +731,19 @@ CPI_HD MeanInc finish_interval(const SampleRec &r, const M3 &R_old, V3 gk, doubl
     inc.alpha = mulT(R_new, ua);
     inc.beta = mulT(R_new, ub);
     inc.dt = r.dt;
-    ir[IR_DT] = r.dt; ir[IR_DT + 1] = 0.0;
-    put3(ir + IR_W, r.w); ir[IR_W + 3] = 0.0;
-    put3(ir + IR_A, a); ir[IR_A + 3] = 0.0;
-    put3(ir + IR_GTAU, gtau); ir[IR_GTAU + 3] = 0.0;
-    rec_put_mat(ir, IR_ROLD, R_old); ir[IR_ROLD + 9] = 0.0;
-    rec_put_mat(ir, IR_RMID, R_mid); ir[IR_RMID + 9] = 0.0;
-    rec_put_mat(ir, IR_RNEW, R_new); ir[IR_RNEW + 9] = 0.0;
+    typedef IrL<MODEL> IR;
+    ir[IR::DT] = r.dt;
+    put3(ir + IR::W, r.w);
+    put3(ir + IR::A, a);
+    rec_put_mat(ir, IR::ROLD, R_old);
+    rec_put_mat(ir, IR::RMID, R_mid);
+    rec_put_mat(ir, IR::RNEW, R_new);
     if (MODEL == 2) {
+        put3(ir + IR::GTAU, gtau);
 #pragma unroll
-        for (int l = 0; l < 3; l++) { put3(ir + IR_H + 4 * l, mul(R_old, cross(gk, unit(l)))); ir[IR_H + 4 * l + 3] = 0.0; }
+        for (int l = 0; l < 3; l++) put3(ir + IR::H + 3 * l, mul(R_old, cross(gk, unit(l))));
+        ir[IR::ZERO] = 0.0; ir[IR::ZERO + 1] = 0.0; ir[IR::ZERO + 2] = 0.0; ir[IR::ZERO + 3] = 0.0;
     }
-    ir[IR_ZERO] = 0.0; ir[IR_ZERO + 1] = 0.0; ir[IR_ZERO + 2] = 0.0; ir[IR_ZERO + 3] = 0.0;
     return inc;
 }
 // Fold a chunk's composed increment into the carried means (gs): alpha += dt_c beta + alpha_c, beta += beta_c.
@@ -800,7 +808,7 @@ template <int MODEL>
 CPI_HD int cov_h_offset(int j) {
     typedef CovDims<MODEL> D;
     const int d = j - D::NPCOL;
-    return (MODEL == 2 && d >= 6 && d < 9) ? IR_H + 4 * (d - 6) : IR_ZERO;
+    return (MODEL == 2 && d >= 6 && d < 9) ? IrL<MODEL>::H + 3 * (d - 6) : IrL<MODEL>::ZERO;
 }
 // Initialise the shared constant rows (9..15).  Called by every lane for its own column index (all groups write
 // identical values); the rows must have been zeroed before.
@@ -839,17 +847,22 @@ CPI_HD void cov_init(CovLane<MODEL> &L, int j, const double q4[4]) {
 // Start of an interval: pick up the shared per-interval vectors (ir = the interval record, hoff = cov_h_offset).
 template <int MODEL>
 CPI_HD void cov_begin(CovLane<MODEL> &L, const double *ir, int hoff) {
-    L.dt = ir[IR_DT];
-    L.w = rec_v3(ir, IR_W);
-    L.a = rec_v3(ir, IR_A);
-    if (MODEL == 2) { L.gtau = rec_v3(ir, IR_GTAU); L.h = rec_v3(ir, hoff); }
+    typedef IrL<MODEL> IR;
+    L.dt = ir[IR::DT];
+    L.w = rec_v3(ir, IR::W);
+    L.a = rec_v3(ir, IR::A);
+    if (MODEL == 2) { L.gtau = rec_v3(ir, IR::GTAU); L.h = rec_v3(ir, hoff); }
     else { L.gtau = mk(0, 0, 0); L.h = mk(0, 0, 0); }
 }
 
 // Stage s: M = rows (theta, v, p) of F x for this lane's column (+ half its own diagonal process noise).
 // Classic RK4 stage rotations R_old, R_mid, R_mid, R_new (CpiV1.h:279,300,332) come from the record (Rs).
 // The stage rotation of the record: R_old, R_mid, R_mid, R_new.
-CPI_HD M3 cov_stage_rotation(const double *ir, int s) { return rec_mat(ir, (s == 0) ? IR_ROLD : ((s == 3) ? IR_RNEW : IR_RMID)); }
+template <int MODEL>
+CPI_HD M3 cov_stage_rotation(const double *ir, int s) {
+    typedef IrL<MODEL> IR;
+    return rec_mat(ir, (s == 0) ? IR::ROLD : ((s == 3) ? IR::RNEW : IR::RMID));
+}
 template <int MODEL>
 CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, const M3 &Rs, double M[9]) {
     const double *X = (s == 0) ? L.P0 : L.X;   // s is a compile-time constant after unrolling

@@ -125,7 +125,7 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
             for (int st = 0; st < 4; st++) {
                 double M[32][9];
                 for (int j = 0; j < NL; j++) {
-                    cov_stage_M(lane[j], st, cov_stage_rotation(ir, st), M[j]);
+                    cov_stage_M(lane[j], st, cov_stage_rotation<MODEL>(ir, st), M[j]);
                     if (colof[j] < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + colof[j]] = M[j][rr];
                 }
                 for (int j = 0; j < NL; j++)

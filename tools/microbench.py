@@ -22,12 +22,13 @@ def main():
         kw = {}
         if os.environ.get("CPI_MB_POOL_BYTES"):      # e.g. 1 = a single batch, re-read from L2 / Infinity Cache
             kw["pool_bytes"] = int(os.environ["CPI_MB_POOL_BYTES"])
-        wl = bench.Workload(eng, name, W, 50, seed=1234, lanes=lanes, **kw)
+        N = int(os.environ.get("CPI_MB_SAMPLES", "50"))
+        wl = bench.Workload(eng, name, W, N, seed=1234, lanes=lanes, **kw)
         best = 1e30
         for rep in range(3):
             wall, k_ms = bench.time_steps(wl, steps, 5)
             best = min(best, k_ms * 1e3 / steps)
-        gbs = bench.bytes_per_unit(name, 50) * W / (best * 1e-6) / 1e9
+        gbs = bench.bytes_per_unit(name, N) * W / (best * 1e-6) / 1e9
         print("%-18s %-10s W=%-8d L=%-3d launch_us=%10.2f  units/s=%.4g  GB/s=%.1f  frac=%.3f" % (
             tag, name, W, lanes, best, W / (best * 1e-6), gbs, gbs / 8000.0), flush=True)
         del wl
