@@ -75,6 +75,52 @@ __device__ __forceinline__ M3 shfl_up(const M3 &A, int d, int width) {
         for (int j = 0; j < 3; j++) r.m[i][j] = __shfl_up(A.m[i][j], d, width);
     return r;
 }
+// Shifts inside a 16-lane DPP row (= one model-1 window group of the covariance kernel): v_mov_b32_dpp row_shr / row_shl
+// instead of ds_bpermute -- VALU moves with no LDS round trip to wait for.  Lanes whose source would lie outside the row
+// keep their own value, exactly like __shfl_up / __shfl_down with width 16.  d is a constant after unrolling.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double row16_up(double v, int d) {      // lane j <- lane j - d
+    switch (d) {
+        case 1: return dpp_mov64<0x111>(v);
+        case 2: return dpp_mov64<0x112>(v);
+        case 4: return dpp_mov64<0x114>(v);
+        case 8: return dpp_mov64<0x118>(v);
+        default: return __shfl_up(v, d, 16);
+    }
+}
+__device__ __forceinline__ double row16_down(double v, int d) {    // lane j <- lane j + d
+    switch (d) {
+        case 1: return dpp_mov64<0x101>(v);
+        case 2: return dpp_mov64<0x102>(v);
+        case 4: return dpp_mov64<0x104>(v);
+        case 8: return dpp_mov64<0x108>(v);
+        default: return __shfl_down(v, d, 16);
+    }
+}
+template <int GROUP>
+__device__ __forceinline__ M3 group_up(const M3 &A, int d) {
+    if (GROUP != 16) return shfl_up(A, d, GROUP);
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = row16_up(A.m[i][j], d);
+    return r;
+}
+template <int GROUP>
+__device__ __forceinline__ V3 group_down(V3 v, int d) {
+    if (GROUP != 16) return shfl_down(v, d, GROUP);
+    return mk(row16_down(v.x, d), row16_down(v.y, d), row16_down(v.z, d));
+}
+template <int GROUP>
+__device__ __forceinline__ double group_down(double v, int d) {
+    return (GROUP != 16) ? __shfl_down(v, d, GROUP) : row16_down(v, d);
+}
 template <bool JAC>
 __device__ __forceinline__ MeanState<JAC> shfl_down(const MeanState<JAC> &s, int d) {
     MeanState<JAC> r;
@@ -394,10 +440,10 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
             M3 inc = r.Rstep;   // inclusive prefix product (later factors on the left), Hillis-Steele
 #pragma unroll
             for (int d = 1; d < CH; d <<= 1) {
-                const M3 t = shfl_up(inc, d, GROUP);
+                const M3 t = group_up<GROUP>(inc, d);
                 if (j >= d) inc = mm(inc, t);
             }
-            M3 pre = shfl_up(inc, 1, GROUP);
+            M3 pre = group_up<GROUP>(inc, 1);
             if (j == 0) pre = eye();
             const M3 Rc = rec_mat(gs, GS_R);                       // rotation carried in from the previous chunk
             double *irw = irs + (g * CH + min(j, CH - 1)) * IRD;
@@ -407,8 +453,8 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
 #pragma unroll
             for (int d = 1; d < CH; d <<= 1) {                     // ordered reduction: lane j <- j (earlier) o j+d (later)
                 MeanInc o;
-                o.beta = shfl_down(mi.beta, d, GROUP); o.alpha = shfl_down(mi.alpha, d, GROUP);
-                o.dt = __shfl_down(mi.dt, d, GROUP);
+                o.beta = group_down<GROUP>(mi.beta, d); o.alpha = group_down<GROUP>(mi.alpha, d);
+                o.dt = group_down<GROUP>(mi.dt, d);
                 mi = inc_combine(mi, o);
             }
             wave_lds_fence();   // every lane has read the carried rotation
