@@ -102,6 +102,27 @@ __device__ __forceinline__ double row16_down(double v, int d) {    // lane j <- 
         default: return __shfl_down(v, d, 16);
     }
 }
+__device__ __forceinline__ M3 row16_up_m3(const M3 &A, int d) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = row16_up(A.m[i][j], d);
+    return r;
+}
+// Lane 15 of DPP rows 0 and 2 -> every lane of rows 1 and 3 (row_bcast:15, row_mask 0b1010); rows 0 and 2 keep their value.
+__device__ __forceinline__ M3 row_bcast15_to_odd_rows(const M3 &A) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int lo = __double2loint(A.m[i][j]), hi = __double2hiint(A.m[i][j]);
+            r.m[i][j] = __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x142, 0xa, 0xf, false),
+                                         __builtin_amdgcn_update_dpp(lo, lo, 0x142, 0xa, 0xf, false));
+        }
+    return r;
+}
 template <int GROUP>
 __device__ __forceinline__ M3 group_up(const M3 &A, int d) {
     if (GROUP != 16) return shfl_up(A, d, GROUP);
@@ -438,24 +459,54 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                 r.f1 = r.f2 = r.f3 = r.f4 = 0; r.Rstep = eye(); r.Rhalf = eye();
             }
             M3 inc = r.Rstep;   // inclusive prefix product (later factors on the left), Hillis-Steele
+            M3 pre;
+            if constexpr (GROUP == 32) {
+                // two DPP rows per group: scan each row with row_shr moves, then fold row 0's total (its lane 15,
+                // handed to the next row by row_bcast:15) into row 1 -- no ds_bpermute, no LDS round trips to wait for
+                const int jr = j & 15;
 #pragma unroll
-            for (int d = 1; d < CH; d <<= 1) {
-                const M3 t = group_up<GROUP>(inc, d);
-                if (j >= d) inc = mm(inc, t);
+                for (int d = 1; d < 16; d <<= 1) {
+                    const M3 t = row16_up_m3(inc, d);
+                    if (jr >= d) inc = mm(inc, t);
+                }
+                const M3 T0 = row_bcast15_to_odd_rows(inc);
+                if (j >= 16) inc = mm(inc, T0);
+                pre = row16_up_m3(inc, 1);
+                if (j == 16) pre = T0;
+            } else {
+#pragma unroll
+                for (int d = 1; d < CH; d <<= 1) {
+                    const M3 t = group_up<GROUP>(inc, d);
+                    if (j >= d) inc = mm(inc, t);
+                }
+                pre = group_up<GROUP>(inc, 1);
             }
-            M3 pre = group_up<GROUP>(inc, 1);
             if (j == 0) pre = eye();
             const M3 Rc = rec_mat(gs, GS_R);                       // rotation carried in from the previous chunk
             double *irw = irs + (g * CH + min(j, CH - 1)) * IRD;
             MeanInc mi;
             if (part) mi = finish_interval<MODEL, AVG>(r, mm(pre, Rc), gk, irw);
             else { mi.alpha = mk(0, 0, 0); mi.beta = mk(0, 0, 0); mi.dt = 0; }
+            if constexpr (GROUP == 32) {
 #pragma unroll
-            for (int d = 1; d < CH; d <<= 1) {                     // ordered reduction: lane j <- j (earlier) o j+d (later)
-                MeanInc o;
-                o.beta = group_down<GROUP>(mi.beta, d); o.alpha = group_down<GROUP>(mi.alpha, d);
-                o.dt = group_down<GROUP>(mi.dt, d);
+                for (int d = 1; d < 16; d <<= 1) {                 // in-row: lane j <- j (earlier) o j+d (later)
+                    MeanInc o;
+                    o.beta = group_down<16>(mi.beta, d); o.alpha = group_down<16>(mi.alpha, d);
+                    o.dt = group_down<16>(mi.dt, d);
+                    if ((j & 15) + d < 16) mi = inc_combine(mi, o);
+                }
+                MeanInc o;                                         // row 0's total o row 1's total (one LDS shuffle)
+                o.beta = shfl_down(mi.beta, 16, GROUP); o.alpha = shfl_down(mi.alpha, 16, GROUP);
+                o.dt = __shfl_down(mi.dt, 16, GROUP);
                 mi = inc_combine(mi, o);
+            } else {
+#pragma unroll
+                for (int d = 1; d < CH; d <<= 1) {                 // ordered reduction: lane j <- j (earlier) o j+d (later)
+                    MeanInc o;
+                    o.beta = group_down<GROUP>(mi.beta, d); o.alpha = group_down<GROUP>(mi.alpha, d);
+                    o.dt = group_down<GROUP>(mi.dt, d);
+                    mi = inc_combine(mi, o);
+                }
             }
             wave_lds_fence();   // every lane has read the carried rotation
             if (j == 0) gs_apply_inc(gs, mi);
