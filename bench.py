@@ -48,8 +48,8 @@ MALL_BYTES = 256 << 20
 # bench.py cannot collect PMC counters itself (that needs the rocprofv3 wrapper), so the figure is only reported for
 # the exact (workload, size) it was measured on; any other configuration reports null.
 PMC_TRAFFIC_KIB = {("v1_mean", 10000, 50): (15662.8, 906.25), ("v1_mean", 1000000, 50): (1803690.0, 85947.2),
-                   ("v1_full", 100000, 50): (145089.0 + 190644.0, 184375.0 + 48136.5),   # covariance + Jacobian kernels
-                   ("v2_full", 100000, 50): (196204.0, 295606.0),
+                   ("v1_full", 100000, 50): (145070.0 + 147758.0, 184375.0 + 35156.7),   # covariance + Jacobian kernels
+                   ("v2_full", 100000, 50): (149088.0, 242188.0),
                    ("factor_v1", 1000000, 50): (351659.0, 3632840.0), ("factor_v2", 1000000, 50): (445426.0, 3632830.0)}
 
 
