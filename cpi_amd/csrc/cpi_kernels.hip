@@ -395,10 +395,10 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     constexpr int GROUP = D::GROUP;   // lanes per window
     constexpr int G = 64 / GROUP;     // windows per wavefront
     // intervals per window staged by one phase-A pass: as many as 20 KB of LDS per wavefront (two wavefronts per
-    // SIMD) leave room for -- 12 x 34 doubles (model 1), 20 x 50 doubles (model 2).  A pass costs as much as 2.3-2.5
-    // intervals of phase C (measured: 68 / 114 us per pass at 100 k windows), so fewer passes matter:
-    // 50 samples = 5 instead of 7 passes (model 1), 3 instead of 4 (model 2).
-    constexpr int CH = (MODEL == 1) ? 12 : 20;
+    // SIMD) leave room for -- 16 x 25 doubles (model 1), 24 x 40 doubles (model 2).  A pass used to cost as much as
+    // 2.3-2.5 intervals of phase C (68 / 114 us per pass at 100 k windows with ds_bpermute scans), so fewer passes
+    // matter: 50 samples = 4 instead of 7 passes (model 1), 3 instead of 4 (model 2).
+    constexpr int CH = (MODEL == 1) ? 16 : 24;
     static_assert(CH <= GROUP, "one lane per staged interval");
     constexpr int EP = EXCH_PITCH;
     constexpr int IRD = IrSize<MODEL>::V;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                 }
             }
             wave_lds_fence();   // every lane has read the carried rotation
-            if (j == 0) gs_apply_inc(gs, mi);
+            if (j == 0) { gs_apply_inc(gs, mi); rec_put_mat(gs, GS_R0, Rc); }
             if (j == CH - 1) rec_put_mat(gs, GS_R, mm(inc, Rc));
         }
         wave_lds_fence();
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                 // The stage rotation is read from the record only when it changes: stages 1 and 2 share R_mid, and the
                 // R_new of stage 3 IS the R_old of the next interval's stage 0 (re-read at the start of a pass only).
                 // 10 fewer LDS broadcasts per interval: -5 % (model 1), -3 % (model 2).
-                if (stg == 0) { if (sl == 0) Rs = cov_stage_rotation<MODEL>(ir, 0); }
+                if (stg == 0) { if (sl == 0) Rs = rec_mat(gs, GS_R0); }
                 else if (stg != 2) Rs = cov_stage_rotation<MODEL>(ir, stg);
                 cov_stage_M(Ln, stg, Rs, M);
                 if (jj < D::NPCOL) {

@@ -688,16 +688,19 @@ CPI_HD void put3(double *o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 // once per interval, lane-parallel over intervals; phase C only reads it back as LDS broadcasts.  A small record
 // matters twice: fewer LDS bytes per interval, and more intervals per phase-A pass in the same LDS budget.
 template <int MODEL> struct IrL;
-template <> struct IrL<1> {   // dt, w, a, R_old, R_mid, R_new
-    static const int DT = 0, W = 1, A = 4, ROLD = 7, RMID = 16, RNEW = 25, SIZE = 34;
+// R_old is not stored: it is the previous interval's R_new (phase C carries it in registers), and for the first
+// interval of a pass the rotation carried in from the previous pass (GS_R0 of the group's carry record).
+template <> struct IrL<1> {   // dt, w, a, R_mid, R_new
+    static const int DT = 0, W = 1, A = 4, RMID = 7, RNEW = 16, SIZE = 25;
     static const int GTAU = 0, H = 0, ZERO = 0;   // unused
 };
 template <> struct IrL<2> {   // + g_tau, h_l = R_old (g_k x e_l) for l = 0..2, three zeros
-    static const int DT = 0, W = 1, A = 4, GTAU = 7, ROLD = 10, RMID = 19, RNEW = 28, H = 37, ZERO = 46, SIZE = 50;
+    static const int DT = 0, W = 1, A = 4, GTAU = 7, RMID = 10, RNEW = 19, H = 28, ZERO = 37, SIZE = 40;
 };
 template <int MODEL> struct IrSize { static const int V = IrL<MODEL>::SIZE; };   // doubles per record
 // group-shared carry across chunks: running rotation and means
-static const int GS_R = 0, GS_ALPHA = 10, GS_BETA = 14, GS_DT = 18, GS_GK = 20 /* model 2: R(q_k_lin) g */, GS_DOUBLES = 24;
+static const int GS_R = 0, GS_ALPHA = 10, GS_BETA = 14, GS_DT = 18, GS_GK = 20 /* model 2: R(q_k_lin) g */,
+                 GS_R0 = 24 /* rotation at the start of the current phase-A pass */, GS_DOUBLES = 34;
 CPI_HD void cov_gs_init(double *gs) {
 #pragma unroll
     for (int i = 0; i < GS_DOUBLES; i++) gs[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
@@ -735,14 +738,13 @@ CPI_HD MeanInc finish_interval(const SampleRec &r, const M3 &R_old, V3 gk, doubl
     ir[IR::DT] = r.dt;
     put3(ir + IR::W, r.w);
     put3(ir + IR::A, a);
-    rec_put_mat(ir, IR::ROLD, R_old);
     rec_put_mat(ir, IR::RMID, R_mid);
     rec_put_mat(ir, IR::RNEW, R_new);
     if (MODEL == 2) {
         put3(ir + IR::GTAU, gtau);
 #pragma unroll
         for (int l = 0; l < 3; l++) put3(ir + IR::H + 3 * l, mul(R_old, cross(gk, unit(l))));
-        ir[IR::ZERO] = 0.0; ir[IR::ZERO + 1] = 0.0; ir[IR::ZERO + 2] = 0.0; ir[IR::ZERO + 3] = 0.0;
+        ir[IR::ZERO] = 0.0; ir[IR::ZERO + 1] = 0.0; ir[IR::ZERO + 2] = 0.0;
     }
     return inc;
 }
@@ -859,9 +861,9 @@ CPI_HD void cov_begin(CovLane<MODEL> &L, const double *ir, int hoff) {
 // Classic RK4 stage rotations R_old, R_mid, R_mid, R_new (CpiV1.h:279,300,332) come from the record (Rs).
 // The stage rotation of the record: R_old, R_mid, R_mid, R_new.
 template <int MODEL>
-CPI_HD M3 cov_stage_rotation(const double *ir, int s) {
+CPI_HD M3 cov_stage_rotation(const double *ir, int s) {   // stages 1..3 (stage 0: see IrL)
     typedef IrL<MODEL> IR;
-    return rec_mat(ir, (s == 0) ? IR::ROLD : ((s == 3) ? IR::RNEW : IR::RMID));
+    return rec_mat(ir, (s == 3) ? IR::RNEW : IR::RMID);
 }
 template <int MODEL>
 CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, const M3 &Rs, double M[9]) {

@@ -119,18 +119,20 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
         rec_put_mat(gs, GS_R, mm(inc[CH - 1], Rc));
         // ---- phase C
         const int cnt = std::min(CH, n - base);
+        M3 Rs = Rc;   // stage-0 rotation: the pass-start rotation, then each interval's R_new (as the kernel carries it)
         for (int sl = 0; sl < cnt; sl++) {
             const double *ir = irs.data() + sl * IRD;
             for (int j = 0; j < NL; j++) cov_begin<MODEL>(lane[j], ir, cov_h_offset<MODEL>(colof[j]));
             for (int st = 0; st < 4; st++) {
                 double M[32][9];
                 for (int j = 0; j < NL; j++) {
-                    cov_stage_M(lane[j], st, cov_stage_rotation<MODEL>(ir, st), M[j]);
+                    cov_stage_M(lane[j], st, (st == 0) ? Rs : cov_stage_rotation<MODEL>(ir, st), M[j]);
                     if (colof[j] < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + colof[j]] = M[j][rr];
                 }
                 for (int j = 0; j < NL; j++)
                     cov_stage_finish(lane[j], st, M[j], cov_row_ptr<MODEL>(exch.data(), ex_shared, colof[j]));
             }
+            Rs = cov_stage_rotation<MODEL>(ir, 3);
             for (int j = 0; j < NL; j++) cov_end(lane[j]);
             if (MODEL == 2)   // the masked row_shr:4 DPP move: lanes 4..7 <- lanes 0..3
                 for (int b = 0; b < 4; b++) for (int i = 0; i < D::NR; i++) lane[4 + b].P0[i] = lane[b].P0[i];
