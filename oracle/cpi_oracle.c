@@ -527,8 +527,15 @@ static void state_export(const cpi_state *s, cpi_oracle_out *o) {
     for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) o->P[j * 15 + i] = s->P[i * 15 + j];
 }
 
+void cpi_oracle_rot_2_quat_rm(const double *rot_rowmajor, double *q) { rot_2_quat(rot_rowmajor, q); }
+
 static void run_window(const cpi_oracle_params *prm, int n, const double *knots, const double *lin,
                        const double *q_k_lin, cpi_oracle_out *out, cpi_oracle_out *trace) {
+    if (prm->model == 3) {   /* Forster comparator (forster_oracle.c); trace = the prefix windows */
+        if (trace) for (int i = 0; i < n; i++) cpi_oracle_forster_window(prm, i + 1, knots, lin, trace + i);
+        if (out) cpi_oracle_forster_window(prm, n, knots, lin, out);
+        return;
+    }
     cpi_state *s = (cpi_state *)malloc(sizeof(cpi_state));
     state_init(s, prm, lin, q_k_lin);
     for (int i = 0; i < n; i++) {

@@ -14,6 +14,8 @@
  *     which are not in this image, and stand-in headers are not allowed; the reference has no
  *     tests or golden vectors for them.  They are a line-by-line restatement, cross-checked
  *     by finite differences against JPLNavState::retract semantics (tests/test_factor_oracle.py).
+ *   - cpi_oracle_forster_window (the GTSAM "Forster discrete" comparator): PARITY UNPINNED, GTSAM is absent;
+ *     see the header of forster_oracle.c for what it restates and what the tests pin instead.
  *
  * Storage convention at this API: every 3x3 / 15x15 matrix is COLUMN-MAJOR (Eigen default),
  * quaternions are JPL [x y z w], state/tangent order is [theta b_g v b_a p].
@@ -28,7 +30,7 @@ extern "C" {
 typedef struct {
     double sigma_w, sigma_wb, sigma_a, sigma_ab; /* CpiBase.h:52 */
     double grav[3];                              /* CpiBase.h:118 */
-    int model;                                   /* 1 = CpiV1, 2 = CpiV2 */
+    int model;                                   /* 1 = CpiV1, 2 = CpiV2, 3 = Forster comparator (forster_oracle.c) */
     int imu_avg;                                 /* CpiBase.h:95 */
     int state_transition_jacobians;              /* CpiV2.h:58 (V2 only) */
 } cpi_oracle_params;
@@ -89,6 +91,19 @@ void cpi_oracle_factor_v2(const cpi_oracle_factor *f, const double *xi, const do
 
 /* GraphSolver_IMU.cpp:263-281 (model 1) / 289-307 (model 2). */
 void cpi_oracle_predict(int model, const cpi_oracle_factor *f, const double *xi, double *xj);
+
+/* Forster discrete comparator (GraphSolver::createimufactor_discrete, GraphSolver_IMU.cpp:141-232): GTSAM's
+ * PreintegratedCombinedMeasurements restated (PARITY UNPINNED, see forster_oracle.c), outputs already converted
+ * the way the call site does it (q = rot_2_quat(deltaRij^T), J_q = -delRdelBiasOmega, covariance block-swapped
+ * into [theta b_g v b_a p]).  imu_avg / q_k_lin / grav are not used.  Also reached through cpi_oracle_window /
+ * cpi_oracle_batch with prm->model == 3. */
+void cpi_oracle_forster_window(const cpi_oracle_params *prm, int n, const double *knots, const double *lin,
+                               cpi_oracle_out *out);
+/* gtsam::NavState::retract / ::update restated (test hooks); state15 = {nRb row-major 9, n_t 3, n_v 3};
+ * A 9x9, B 9x3, C 9x3 row-major (any may be NULL). */
+void cpi_oracle_navstate_retract(const double *state15, const double *xi9, double *out15);
+void cpi_oracle_navstate_update(const double *state15, const double *acc, const double *om, double dt,
+                                double *out15, double *A81, double *B27, double *C27);
 
 /* JPLNavState::retract (JPLNavState.cpp:37-71) and localCoordinates (:80-88). */
 void cpi_oracle_retract(const double *x, const double *xi15, double *xout);

@@ -37,7 +37,8 @@ def build(force=False):
     """(Re)build liboracle.so and, when /root/reference is present, _ref/libcpi_ref.so."""
     lib = os.path.join(_HERE, "liboracle.so")
     if force or not os.path.exists(lib) or \
-            os.path.getmtime(lib) < os.path.getmtime(os.path.join(_HERE, "cpi_oracle.c")):
+            os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                        for f in ("cpi_oracle.c", "forster_oracle.c", "cpi_oracle.h")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     ref = os.path.join(_HERE, "_ref", "libcpi_ref.so")
     if os.path.isdir("/root/reference/cpi_compare/src/cpi") and (force or not os.path.exists(ref)):
@@ -118,8 +119,26 @@ class _OracleLib(_Lib):
     def __init__(self, path):
         super().__init__(path, "cpi_oracle")
         for name in ("cpi_oracle_window_trace", "cpi_oracle_stream", "cpi_oracle_factor_v1", "cpi_oracle_factor_v2",
-                     "cpi_oracle_predict", "cpi_oracle_retract", "cpi_oracle_local"):
+                     "cpi_oracle_predict", "cpi_oracle_retract", "cpi_oracle_local", "cpi_oracle_forster_window",
+                     "cpi_oracle_navstate_retract", "cpi_oracle_navstate_update"):
             getattr(self.lib, name).restype = None
+
+    def navstate_retract(self, state15, xi9):
+        """gtsam::NavState::retract restated; state15 = [nRb row-major 9, n_t 3, n_v 3]."""
+        s = np.ascontiguousarray(state15, dtype=np.float64)
+        xi = np.ascontiguousarray(xi9, dtype=np.float64)
+        out = np.zeros(15)
+        self.lib.cpi_oracle_navstate_retract(_dp(s), _dp(xi), _dp(out))
+        return out
+
+    def navstate_update(self, state15, acc, om, dt):
+        """gtsam::NavState::update restated -> (new state15, A 9x9, B 9x3, C 9x3)."""
+        s = np.ascontiguousarray(state15, dtype=np.float64)
+        acc = np.ascontiguousarray(acc, dtype=np.float64)
+        om = np.ascontiguousarray(om, dtype=np.float64)
+        out, A, B, Cm = np.zeros(15), np.zeros((9, 9)), np.zeros((9, 3)), np.zeros((9, 3))
+        self.lib.cpi_oracle_navstate_update(_dp(s), _dp(acc), _dp(om), C.c_double(dt), _dp(out), _dp(A), _dp(B), _dp(Cm))
+        return out, A, B, Cm
 
     def trace(self, prm, knots1, lin1, q1=None):
         knots1 = np.ascontiguousarray(knots1, dtype=np.float64)
