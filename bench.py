@@ -26,6 +26,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernels are VALU-bound
 # Algorithmic HBM bytes per unit: read + write, f64, compulsory traffic only
 BYTES = {"v1_mean": 2856 + 88, "v2_mean": 2888 + 88, "v1_full": 2856 + 2320, "v2_full": 2888 + 2392,
+         "forster_full": 2856 + 2320,   # Forster / GTSAM comparator (CPI_MODEL_FORSTER): same I/O as model 1 full
          "factor_v1": 776 + 3720, "factor_v2": 952 + 3720,
          # packed evaluateError (state-dependent blocks only, include/cpi_amd.h): NOT the dense GTSAM-shaped output
          "factor_v1_packed": 776 + 576, "factor_v2_packed": 952 + 576}
@@ -73,7 +74,8 @@ def parse():
 
 
 def default_size(workload):
-    return {"v1_mean": 10000, "v2_mean": 10000, "v1_full": 100000, "v2_full": 100000, "factor_v1": 1000000, "factor_v2": 1000000,
+    return {"v1_mean": 10000, "v2_mean": 10000, "v1_full": 100000, "v2_full": 100000, "forster_full": 100000,
+            "factor_v1": 1000000, "factor_v2": 1000000,
             "factor_v1_packed": 1000000, "factor_v2_packed": 1000000}[workload]
 
 
@@ -105,7 +107,7 @@ class Workload:
                             "H2": torch.empty((W, 225), dtype=torch.float64, device=dev)}
             self.nbatch = 1   # 4.5 GB per sweep: far beyond the Infinity Cache by itself
             return
-        model = 2 if name.startswith("v2") else 1
+        model = 2 if name.startswith("v2") else (3 if name.startswith("forster") else 1)
         self.model = model
         want = ("mean",) if name.endswith("mean") else ("mean", "jac", "cov")
         self.want = want
@@ -166,6 +168,8 @@ def cpu_baseline(wl, min_seconds=8.0):
     from oracle import oracle_py as op
     ref = op.reference()
     lib, kind = (ref, "reference") if ref is not None else (op.oracle(), "port")
+    if wl.model == 3:   # the Forster comparator lives in GTSAM (absent): only the restatement exists
+        lib, kind = op.oracle(), "port"
     cores = os.cpu_count() or 1
     kn, lin, q = [t.cpu().numpy() for t in wl.batches[0]]
     Wc = min(wl.W, 10000)
@@ -231,7 +235,7 @@ def main():
                      "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_counters.md)",
                      "algorithmic_bytes_per_launch": bpu * W,
                      "kernel": {"v1_mean": "cpi_mean_kernel", "v2_mean": "cpi_mean_kernel", "v1_full": "cpi_cov_kernel<1>", "v2_full": "cpi_cov_kernel<2>",
-                                "factor_v1": "cpi_factor_kernel<1,false,8>", "factor_v2": "cpi_factor_kernel<2,false,8>",
+                                "forster_full": "cpi_forster_kernel", "factor_v1": "cpi_factor_kernel<1,false,8>", "factor_v2": "cpi_factor_kernel<2,false,8>",
                                 "factor_v1_packed": "cpi_factor_packed_kernel<1>",
                                 "factor_v2_packed": "cpi_factor_packed_kernel<2>"}[a.workload],
                      "launch_us": launch_s * 1e6, "algorithmic_bytes_per_unit": bpu},
@@ -243,7 +247,7 @@ def main():
         del wl
         torch.cuda.empty_cache()
         for name, Wx, steps in (("v1_mean", 30000, 1000), ("v1_mean", 100000, 300), ("v1_mean", 1000000, 40),
-                                ("v1_full", 100000, 30), ("v2_full", 100000, 30),
+                                ("v1_full", 100000, 30), ("v2_full", 100000, 30), ("forster_full", 100000, 30),
                                 ("factor_v1", 1000000, 40), ("factor_v2", 1000000, 40),
                                 ("factor_v1_packed", 1000000, 40), ("factor_v2_packed", 1000000, 40)):
             try:

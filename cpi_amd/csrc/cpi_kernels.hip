@@ -586,6 +586,136 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
 }
 
 // ============================================================================================
+// Forster / GTSAM discrete-preintegration comparator kernel (fsd:: in cpi_math.hpp)
+// ============================================================================================
+// Replaces: the PreintegratedCombinedMeasurements loop of GraphSolver::createimufactor_discrete
+// (GraphSolver_IMU.cpp:149-199) and its call-site conversions (:204-225, swapcovariance :240-254).
+// 16 lanes per window, 4 windows per wavefront.  Lane j < 15 owns column j of the 15x15 covariance (already in the
+// block order [theta b_g v b_a p] the call site swaps it into); lanes 0-2 also carry column j of the three gyro-bias
+// Jacobians, lanes 3-5 column j-3 of the two accelerometer-bias Jacobians; every lane carries the means (the SIMD
+// cost is the same as one lane doing it).  P' = F P F^T + G per interval: F x is lane-local (F is sparse), the
+// transposed product arrives through ONE 9-row LDS exchange per interval (the continuous models need four, one per
+// RK4 stage).  F depends on the interval alone, so phase A (one lane per interval: Exp, its right Jacobian) needs no
+// prefix scan.
+__global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
+    constexpr int GROUP = 16, G = 64 / GROUP, CH = 16, EP = EXCH_PITCH, IRD = fsd::IR_SIZE;
+    __shared__ __attribute__((aligned(16))) double irs[G * CH * IRD];                 // interval records, 12 KB
+    __shared__ __attribute__((aligned(16))) double exch[G * EXCH_GROUP_ROWS * EP];    // row exchange, 5 KB
+
+    const int lane = threadIdx.x;
+    const int g = lane / GROUP, j = lane % GROUP;
+    long long w = (long long)blockIdx.x * G + g;
+    const bool valid = w < A.W;
+    if (!valid) w = A.W - 1;
+    const int n = A.count ? A.count[w] : A.N;
+    const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
+    const int nmax = wave_max(n);
+
+    const double q4[4] = { A.q4[0], A.q4[1], A.q4[2], A.q4[3] };
+    const int kind = (j < 3) ? 0 : ((j < 6) ? 1 : 2), jc = (j < 3) ? j : ((j < 6) ? j - 3 : 0);
+    const int er = (j < 15) ? cov_exch_row(j) : -1;     // theta / v / p columns read a row; bias columns keep their own
+    // process noise on this column's own diagonal entry, as one vector per constant-diagonal block
+    const V3 nbg = (j >= 3 && j < 6) ? q4[1] * unit(j - 3) : mk(0, 0, 0);
+    const V3 nv = (j >= 6 && j < 9) ? q4[2] * unit(j - 6) : mk(0, 0, 0);
+    const V3 nba = (j >= 9 && j < 12) ? q4[3] * unit(j - 9) : mk(0, 0, 0);
+    double *ex_g = exch + g * EXCH_GROUP_ROWS * EP;
+    const double *ex_row = ex_g + max(er, 0) * EP;
+    const int jdrow = fsd::IR_JD + 3 * min(j, 2);
+
+    fsd::Mean m;
+    fsd::JacCol J;
+    fsd::mean_init(m);
+    fsd::jac_init(J);
+    double x[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) x[i] = 0.0;
+
+    for (int base = 0; base < nmax; base += CH) {
+        {   // ---- phase A: lane (g, j) builds the record of interval base + j of its window
+            const int s = base + j;
+            long long wq = w;
+            asm volatile("" : "+v"(wq));   // keeps the bias loads inside the loop (registers matter more, see cpi_cov_kernel)
+            fsd::Rec r;
+            if (s < n) {
+                const double *ka = A.knots + (k0 + s) * 7;
+                const V3 bg = ldv3(A.lin + wq * 6), ba = ldv3(A.lin + wq * 6 + 3);
+                double a[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) a[i] = ka[i];
+                r = fsd::make_rec(a[0], a[7], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]), bg, ba, q4[0]);
+            } else {
+                r.dt = 0; r.qs = 0; r.a = mk(0, 0, 0); r.E = eye(); r.JD = zero3();
+            }
+            fsd::put_rec(irs + (g * CH + j) * IRD, r);
+        }
+        wave_lds_fence();
+
+        // ---- phase C: the sequential recursion over the staged intervals
+        const int cnt = min(CH, nmax - base);
+        for (int sl = 0; sl < cnt; ++sl) {
+            const double *ir = irs + (g * CH + sl) * IRD;   // group-uniform address: LDS broadcast
+            const fsd::Rec r = fsd::get_rec(ir);
+            fsd::jac_step(J, m.R, r, kind, jc);             // uses the rotation BEFORE this interval
+            fsd::mean_step(m, r);
+            double y[15];
+            fsd::F_apply(r, x, y);
+            if (j < 15) {
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) ex_g[(b * 3 + i) * EP + j] = y[b * 6 + i];
+            }
+            wave_lds_fence();   // DS instructions of a wave execute in order; this only pins the compiler
+            double z[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) z[i] = ex_row[i];
+            if (er < 0) {
+#pragma unroll
+                for (int i = 0; i < 15; i++) z[i] = x[i];
+            }
+            fsd::F_apply(r, z, x);
+            V3 gth = fsd::theta_noise_col(r, rec_v3(ir, jdrow));
+            if (j >= 3) gth = mk(0, 0, 0);
+            x[0] += gth.x; x[1] += gth.y; x[2] += gth.z;
+            x[3] = fma(r.dt, nbg.x, x[3]); x[4] = fma(r.dt, nbg.y, x[4]); x[5] = fma(r.dt, nbg.z, x[5]);
+            x[6] = fma(r.dt, nv.x, x[6]); x[7] = fma(r.dt, nv.y, x[7]); x[8] = fma(r.dt, nv.z, x[8]);
+            x[9] = fma(r.dt, nba.x, x[9]); x[10] = fma(r.dt, nba.y, x[10]); x[11] = fma(r.dt, nba.z, x[11]);
+            wave_lds_fence();
+        }
+    }
+
+    if (!valid) return;
+    if (A.out.P && j < 15) {
+        double *p = A.out.P + w * 225 + j * 15;
+#pragma unroll
+        for (int i = 0; i < 15; i++) p[i] = x[i];
+    }
+    if (j == 0) {
+        if (A.out.DT) A.out.DT[w] = m.dT;
+        if (A.out.alpha) stv3(A.out.alpha + w * 3, m.p);      // deltaPij (:204)
+        if (A.out.beta) stv3(A.out.beta + w * 3, m.v);        // deltaVij (:205)
+        if (A.out.q) {                                        // rot_2_quat(deltaRij^T) (:206, :229)
+            M3 Rt;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) Rt.m[i][k] = m.R.m[k][i];
+            const Q4 q = rot_2_quat(Rt);
+            double *p = A.out.q + w * 4;
+            p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+        }
+    }
+    if (kind == 0) {
+        if (A.out.J_q) stv3(A.out.J_q + w * 9 + jc * 3, -J.r);   // -delRdelBiasOmega (:210)
+        if (A.out.J_a) stv3(A.out.J_a + w * 9 + jc * 3, J.p);    // delPdelBiasOmega (:212)
+        if (A.out.J_b) stv3(A.out.J_b + w * 9 + jc * 3, J.v);    // delVdelBiasOmega (:214)
+    } else if (kind == 1) {
+        if (A.out.H_a) stv3(A.out.H_a + w * 9 + jc * 3, J.p);    // delPdelBiasAcc (:211)
+        if (A.out.H_b) stv3(A.out.H_b + w * 9 + jc * 3, J.v);    // delVdelBiasAcc (:213)
+    }
+}
+
+// ============================================================================================
 // factor kernels
 // ============================================================================================
 struct FactorArgs {
@@ -1114,8 +1244,8 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
                                       const double *lin, const double *q_k_lin, const cpi_outputs *out) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (!prm || !out) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: prm/out is NULL");
-    if (prm->model != CPI_MODEL_V1 && prm->model != CPI_MODEL_V2)
-        return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: model must be 1 or 2");
+    if (prm->model != CPI_MODEL_V1 && prm->model != CPI_MODEL_V2 && prm->model != CPI_MODEL_FORSTER)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: model must be 1, 2 or 3 (CPI_MODEL_FORSTER)");
     if (W < 0 || N < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: negative size");
     if (W == 0) return CPI_OK;
     if (!knots || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: knots/lin is NULL");
@@ -1141,6 +1271,11 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     a.q4[0] = prm->sigma_w * prm->sigma_w; a.q4[1] = prm->sigma_wb * prm->sigma_wb;
     a.q4[2] = prm->sigma_a * prm->sigma_a; a.q4[3] = prm->sigma_ab * prm->sigma_ab;
     a.out = *out;
+    if (prm->model == CPI_MODEL_FORSTER) {   // one kernel owns everything; imu_avg, q_k_lin, grav play no part
+        hipLaunchKernelGGL(cpi_forster_kernel, dim3((unsigned)((W + 3) / 4)), dim3(64), 0, ctx->stream, a);
+        CPI_HIP(ctx, hipGetLastError());
+        return CPI_OK;
+    }
     const bool avg = prm->imu_avg != 0;
     const bool v2 = prm->model == CPI_MODEL_V2;
     const bool stj = v2 && prm->state_transition_jacobians != 0;

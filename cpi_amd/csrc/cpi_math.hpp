@@ -1092,4 +1092,115 @@ CPI_HD NavState predict_state(const NavState &xi, V3 alpha, V3 beta, Q4 q_KtoK1,
     return o;
 }
 
+// ==========================================================================================
+// Forster / GTSAM discrete preintegration comparator: what
+// GraphSolver::createimufactor_discrete (GraphSolver_IMU.cpp:141-232) obtains from GTSAM's
+// PreintegratedCombinedMeasurements (ManifoldPreintegration; GTSAM is absent from the reference tree --
+// the algorithm is restated from its publication, see oracle/forster_oracle.c: PARITY UNPINNED).
+//
+// Per IMU interval, with w = w_m - b_g, a = a_m - b_a, E = Exp(w dt), Jr = right Jacobian of Exp at w dt:
+//   means (NavState::update)        R' = R E,  p' = p + R (dt R^T v + dt^2/2 a),  v' = v + R (dt a)
+//   bias Jacobians (ManifoldPreintegration::update), column c of each 3x3:
+//       D = -R [a]x delRdelBg ;  delRdelBg' = E^T delRdelBg - Jr dt
+//       delPdelBa += delVdelBa dt - dt^2/2 R ;  delPdelBg += delVdelBg dt + dt^2/2 D
+//       delVdelBa += -R dt ;                    delVdelBg += D dt
+//   covariance (CombinedImuFactor), P' = F P F^T + G, errors of p and v expressed in the body frame
+//   (NavState::retract), written here directly in the order [theta b_g v b_a p] the call site swaps it into:
+//       (F x)_theta = E^T x_theta - Jr dt x_bg
+//       (F x)_v     = E^T (x_v - dt ([a]x x_theta + x_ba))
+//       (F x)_p     = E^T (x_p + dt x_v - dt^2/2 ([a]x x_theta + x_ba))
+//       (F x)_bg = x_bg, (F x)_ba = x_ba
+//       G = diag( (1/dt) (Jr dt) s_w^2 (Jr dt)^T, dt s_wb^2 I, dt s_a^2 I, dt s_ab^2 I, 0 )
+// F does not depend on the running means, so the per-interval records are independent of each other.
+namespace fsd {
+// interval record (doubles): dt, s_w^2/dt, a, -, E (row-major), Jr*dt (row-major)
+static const int IR_DT = 0, IR_QS = 1, IR_A = 2, IR_E = 6, IR_JD = 15, IR_SIZE = 24;
+
+struct Rec { double dt, qs; V3 a; M3 E, JD; };
+
+// One interval: reading (w_m, a_m) held over [t0, t1] (GraphSolver_IMU.cpp:171-180).  dt <= 0 (and NaN) gives the
+// exact no-op record (GTSAM itself would divide by dt == 0; skipped like CpiV1.h:72-74, see forster_oracle.c).
+CPI_HD Rec make_rec(double t0, double t1, V3 wm, V3 am, V3 bg, V3 ba, double wCov) {
+    Rec r;
+    double dt = t1 - t0;
+    const bool live = dt > 0;
+    if (!live) dt = 0;
+    r.dt = dt;
+    r.qs = live ? wCov / dt : 0.0;
+    r.a = live ? am - ba : mk(0, 0, 0);
+    const V3 phi = live ? dt * (wm - bg) : mk(0, 0, 0);
+    double th, ith;
+    mag_and_inverse(dot(phi, phi), th, ith);
+    double s2, c2;
+    sincos_fast(0.5 * th, s2, c2);
+    const double sn = 2.0 * s2 * c2, omc = 2.0 * s2 * s2;   // sin(theta), 1 - cos(theta)
+    const double ith2 = ith * ith;
+    const double k1 = sn * ith, k2 = omc * ith2, k3 = (1.0 - k1) * ith2;
+    r.E = poly_wx(phi, 1.0, k1, k2);            // I + sin/t [phi]x + (1-cos)/t^2 [phi]x^2
+    const M3 Jr = poly_wx(phi, 1.0, -k2, k3);   // I - (1-cos)/t^2 [phi]x + (t - sin)/t^3 [phi]x^2
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.JD.m[i][j] = dt * Jr.m[i][j];
+    return r;
+}
+CPI_HD void put_rec(double *o, const Rec &r) {
+    o[IR_DT] = r.dt; o[IR_QS] = r.qs; put3(o + IR_A, r.a); o[IR_A + 3] = 0.0;
+    rec_put_mat(o, IR_E, r.E); rec_put_mat(o, IR_JD, r.JD);
+}
+CPI_HD Rec get_rec(const double *o) {
+    Rec r;
+    r.dt = o[IR_DT]; r.qs = o[IR_QS]; r.a = rec_v3(o, IR_A);
+    r.E = rec_mat(o, IR_E); r.JD = rec_mat(o, IR_JD);
+    return r;
+}
+
+struct Mean { M3 R; V3 p, v; double dT; };
+CPI_HD void mean_init(Mean &m) { m.R = eye(); m.p = mk(0, 0, 0); m.v = mk(0, 0, 0); m.dT = 0; }
+CPI_HD void mean_step(Mean &m, const Rec &r) {
+    const double dt22 = 0.5 * r.dt * r.dt;
+    const V3 bv = mulT(m.R, m.v);                       // NavState::bodyVelocity
+    m.p = m.p + mul(m.R, axpy(dt22, r.a, r.dt * bv));
+    m.v = m.v + mul(m.R, r.dt * r.a);
+    m.R = mm(m.R, r.E);
+    m.dT += r.dt;
+}
+
+// One column of the bias Jacobians: kind 0 = gyro-bias column c (delRdelBg, delVdelBg, delPdelBg),
+// kind 1 = accelerometer-bias column c (delVdelBa, delPdelBa; r stays 0), anything else = unused lane.
+struct JacCol { V3 r, v, p; };
+CPI_HD void jac_init(JacCol &J) { J.r = mk(0, 0, 0); J.v = mk(0, 0, 0); J.p = mk(0, 0, 0); }
+CPI_HD void jac_step(JacCol &J, const M3 &Rold, const Rec &r, int kind, int c) {
+    const double dt22 = 0.5 * r.dt * r.dt;
+    V3 u = cross(r.a, J.r);
+    const V3 e = unit(c);
+    if (kind == 1) u = e;
+    const V3 d = -mul(Rold, u);                         // column of D_acc_biasOmega, or of -R
+    J.p = axpy(dt22, d, axpy(r.dt, J.v, J.p));
+    J.v = axpy(r.dt, d, J.v);
+    V3 jd = mul(r.JD, e);
+    if (kind != 0) jd = mk(0, 0, 0);
+    J.r = mulT(r.E, J.r) - jd;
+}
+
+// y = F x for one covariance column (order [theta b_g v b_a p]); only the theta / v / p rows change.
+CPI_HD void F_apply(const Rec &r, const double *x, double *y) {
+    const V3 th = mk(x[0], x[1], x[2]), bg = mk(x[3], x[4], x[5]), v = mk(x[6], x[7], x[8]);
+    const V3 ba = mk(x[9], x[10], x[11]), p = mk(x[12], x[13], x[14]);
+    const double dt22 = 0.5 * r.dt * r.dt;
+    const V3 c = cross(r.a, th) + ba;
+    put3(y + 0, mulT(r.E, th) - mul(r.JD, bg));
+    put3(y + 3, bg);
+    put3(y + 6, mulT(r.E, axpy(-r.dt, c, v)));
+    put3(y + 9, ba);
+    put3(y + 12, mulT(r.E, axpy(-dt22, c, axpy(r.dt, v, p))));
+}
+// process-noise variance per unit time on the diagonal of column j (theta has the full block below, p none)
+CPI_HD double diag_noise(int j, const double q4[4]) {
+    return (j >= 3 && j < 6) ? q4[1] : ((j >= 6 && j < 9) ? q4[2] : ((j >= 9 && j < 12) ? q4[3] : 0.0));
+}
+// column j < 3 of G's theta block: (s_w^2/dt) (Jr dt) (Jr dt)^T e_j ; jdrow = row j of Jr dt
+CPI_HD V3 theta_noise_col(const Rec &r, V3 jdrow) { return r.qs * mul(r.JD, jdrow); }
+}  // namespace fsd
+
 }  // namespace cpi

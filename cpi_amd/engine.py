@@ -79,7 +79,7 @@ class Engine:
             grp = "mean" if name in MEAN_FIELDS else ("cov" if name == "P" else "jac")
             if grp not in want:
                 continue
-            if model == 1 and name in ("O_a", "O_b"):
+            if model != 2 and name in ("O_a", "O_b"):
                 continue
             shape = (W,) if n == 1 else (W, n)
             out[name] = torch.empty(shape, dtype=torch.float64, device=self.device)

@@ -34,7 +34,19 @@ extern "C" {
 #define CPI_ABI_VERSION 1
 
 enum { CPI_OK = 0, CPI_ERR_INVALID = 1, CPI_ERR_HIP = 2, CPI_ERR_NO_DEVICE = 3 };
-enum { CPI_MODEL_V1 = 1, CPI_MODEL_V2 = 2 };
+enum {
+    CPI_MODEL_V1 = 1, CPI_MODEL_V2 = 2,
+    /* cpi_preintegrate_batch only: the "Forster discrete" comparator, i.e. what GraphSolver::createimufactor_discrete
+     * (GraphSolver_IMU.cpp:141-232) gets from GTSAM's PreintegratedCombinedMeasurements (manifold preintegration),
+     * already converted the way that call site does it: alpha = deltaPij, beta = deltaVij,
+     * q = rot_2_quat(deltaRij^T), J_q = -delRdelBiasOmega, J_a / J_b = delP / delV delBiasOmega,
+     * H_a / H_b = delP / delV delBiasAcc, P = preintMeasCov with blocks 1 and 4 swapped (swapcovariance :240-254)
+     * = order [theta b_g v b_a p].  Reading i is held over [t_i, t_i+1] (no averaging: imu_avg, q_k_lin, grav,
+     * lanes_per_window are ignored).  The result is the measurement of an ImuFactorCPIv1 (:227-231): evaluate it
+     * with model CPI_MODEL_V1.  GTSAM is not part of the reference tree: parity of this model is UNPINNED
+     * (oracle/forster_oracle.c). */
+    CPI_MODEL_FORSTER = 3
+};
 
 typedef struct cpi_ctx cpi_ctx;
 
@@ -44,7 +56,7 @@ typedef struct cpi_ctx cpi_ctx;
 typedef struct {
     double sigma_w, sigma_wb, sigma_a, sigma_ab;
     double grav[3];
-    int32_t model;                       /* CPI_MODEL_V1 | CPI_MODEL_V2 */
+    int32_t model;                       /* CPI_MODEL_V1 | CPI_MODEL_V2 | CPI_MODEL_FORSTER (preintegration only) */
     int32_t imu_avg;                     /* 0 / 1 */
     int32_t state_transition_jacobians;  /* model 2 only; reference default 1 */
     int32_t lanes_per_window;            /* mean kernel: 0 = auto, else 1,2,3,4,5,6,8,12,16,32,64 (tuning knob;

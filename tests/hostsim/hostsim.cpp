@@ -5,6 +5,7 @@
 #include "../../cpi_amd/csrc/cpi_math.hpp"
 #include <algorithm>
 #include <cstring>
+#include <array>
 #include <vector>
 using namespace cpi;
 
@@ -163,6 +164,77 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
         }
     }
 }
+
+// Forster comparator kernel, lane by lane: 16 lanes per window -- lane j < 15 owns covariance column j, lanes 0-2
+// also a gyro-bias Jacobian column, lanes 3-5 an accelerometer-bias one; every lane carries the means.  The 9-row
+// exchange hands each theta / v / p column the matching ROW of F P (= its column of P F^T).
+void forster_window(int n, const double *kn, const double *lin, const double *sig, double *o) {
+    const V3 bg = ld3(lin), ba = ld3(lin + 3);
+    const double q4[4] = { sig[0] * sig[0], sig[1] * sig[1], sig[2] * sig[2], sig[3] * sig[3] };
+    const int NL = 16, CH = 16;
+    std::vector<double> irs(CH * fsd::IR_SIZE, 0.0), exch(EXCH_GROUP_ROWS * EXCH_PITCH, 0.0);
+    struct LaneS { fsd::Mean m; fsd::JacCol J; double x[15]; };
+    std::vector<LaneS> lane(NL);
+    for (int j = 0; j < NL; j++) { fsd::mean_init(lane[j].m); fsd::jac_init(lane[j].J); for (int i = 0; i < 15; i++) lane[j].x[i] = 0.0; }
+    for (int base = 0; base < n; base += CH) {
+        for (int sl = 0; sl < CH; sl++) {   // phase A: one lane per interval, no dependence between them
+            const int s = base + sl;
+            fsd::Rec r;
+            if (s < n) {
+                const double *k0 = kn + 7 * s, *k1 = kn + 7 * (s + 1);
+                r = fsd::make_rec(k0[0], k1[0], ld3(k0 + 1), ld3(k0 + 4), bg, ba, q4[0]);
+            } else r = fsd::make_rec(0, 0, mk(0, 0, 0), mk(0, 0, 0), bg, ba, q4[0]);
+            fsd::put_rec(irs.data() + sl * fsd::IR_SIZE, r);
+        }
+        const int cnt = std::min(CH, n - base);
+        for (int sl = 0; sl < cnt; sl++) {
+            const double *ir = irs.data() + sl * fsd::IR_SIZE;
+            const fsd::Rec r = fsd::get_rec(ir);
+            std::vector<std::array<double, 15>> y(NL);
+            for (int j = 0; j < NL; j++) {
+                LaneS &Ls = lane[j];
+                const int kind = j < 3 ? 0 : (j < 6 ? 1 : 2), c = j < 3 ? j : (j < 6 ? j - 3 : 0);
+                fsd::jac_step(Ls.J, Ls.m.R, r, kind, c);
+                fsd::mean_step(Ls.m, r);
+                fsd::F_apply(r, Ls.x, y[j].data());
+                if (j < 15) {
+                    static const int rows[9] = { 0, 1, 2, 6, 7, 8, 12, 13, 14 };
+                    for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + j] = y[j][rows[rr]];
+                }
+            }
+            for (int j = 0; j < 15; j++) {
+                LaneS &Ls = lane[j];
+                double z[15];
+                const int er = cov_exch_row(j);
+                for (int i = 0; i < 15; i++) z[i] = (er >= 0) ? exch[er * EXCH_PITCH + i] : Ls.x[i];
+                fsd::F_apply(r, z, Ls.x);
+                if (j < 3) {
+                    const V3 g = fsd::theta_noise_col(r, rec_v3(ir, fsd::IR_JD + 3 * j));
+                    Ls.x[0] += g.x; Ls.x[1] += g.y; Ls.x[2] += g.z;
+                } else Ls.x[j] += r.dt * fsd::diag_noise(j, q4);
+            }
+        }
+    }
+    const fsd::Mean &m = lane[0].m;
+    o[0] = m.dT;
+    o[1] = m.p.x; o[2] = m.p.y; o[3] = m.p.z;
+    o[4] = m.v.x; o[5] = m.v.y; o[6] = m.v.z;
+    M3 Rt;
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) Rt.m[i][k] = m.R.m[k][i];
+    const Q4 q = rot_2_quat(Rt);
+    o[7] = q.x; o[8] = q.y; o[9] = q.z; o[10] = q.w;
+    put_cm(o + 11, Rt);
+    for (int c = 0; c < 3; c++) {
+        const fsd::JacCol &g = lane[c].J, &a = lane[3 + c].J;
+        const double jq[3] = { -g.r.x, -g.r.y, -g.r.z }, ja[3] = { g.p.x, g.p.y, g.p.z }, jb[3] = { g.v.x, g.v.y, g.v.z };
+        const double ha[3] = { a.p.x, a.p.y, a.p.z }, hb[3] = { a.v.x, a.v.y, a.v.z };
+        for (int i = 0; i < 3; i++) {
+            o[20 + c * 3 + i] = jq[i]; o[29 + c * 3 + i] = ja[i]; o[38 + c * 3 + i] = jb[i];
+            o[47 + c * 3 + i] = ha[i]; o[56 + c * 3 + i] = hb[i];
+        }
+    }
+    for (int c = 0; c < 15; c++) for (int i = 0; i < 15; i++) o[83 + c * 15 + i] = lane[c].x[i];
+}
 }  // namespace
 
 extern "C" void hs_mean(int model, int jac, int avg, int L, long W, int n, const double *kn, const double *lin,
@@ -214,4 +286,8 @@ extern "C" void hs_predict(int model, long F, const double *rec, const double *x
         d[4] = o.bg.x; d[5] = o.bg.y; d[6] = o.bg.z; d[7] = o.v.x; d[8] = o.v.y; d[9] = o.v.z;
         d[10] = o.ba.x; d[11] = o.ba.y; d[12] = o.ba.z; d[13] = o.p.x; d[14] = o.p.y; d[15] = o.p.z;
     }
+}
+
+extern "C" void hs_forster(long W, int n, const double *kn, const double *lin, const double *sig, double *out) {
+    for (long w = 0; w < W; w++) forster_window(n, kn + (size_t)w * (n + 1) * 7, lin + w * 6, sig, out + w * OUTD);
 }

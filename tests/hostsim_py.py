@@ -55,3 +55,10 @@ def predict(model, rec, xi):
     xj = np.zeros_like(xi)
     lib().hs_predict(model, C.c_long(rec.shape[0]), dp(rec), dp(xi), dp(xj))
     return xj
+
+
+def forster(kn, lin):
+    W, n1, _ = kn.shape
+    raw = np.zeros((W, 308))
+    lib().hs_forster(C.c_long(W), n1 - 1, dp(kn), dp(lin), dp(SIG), dp(raw))
+    return raw

@@ -1,0 +1,135 @@
+"""GPU tests (-m gpu) of the Forster / GTSAM discrete-preintegration comparator (CPI_MODEL_FORSTER),
+through the C-ABI, against the CPU restatement oracle/forster_oracle.c.  PARITY UNPINNED: GTSAM is absent from the
+reference tree and this image; what pins the restatement itself is in tests/test_forster_oracle.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cpi_amd import synth
+from tests.tol import TOL_FACTOR, check_pre, cov_rel_err
+
+pytestmark = pytest.mark.gpu
+FORSTER = 3
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import cpi_amd
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return cpi_amd.Engine()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle_py as op
+    return op
+
+
+def _dev(a, eng):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+
+
+def _host(out):
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("fname", ["pre_cfg1.npz", "pre_w48.npz"])
+def test_comparator_vs_restatement_on_the_golden_inputs(eng, orc, golden_dir, fname):
+    d = dict(np.load(os.path.join(golden_dir, fname)))
+    out = _host(eng.preintegrate(_dev(d["knots"], eng), _dev(d["lin"], eng), None, eng.make_params(FORSTER)))
+    assert set(out) == {"DT", "alpha", "beta", "q", "J_q", "J_a", "J_b", "H_a", "H_b", "P"}
+    ref = orc.oracle().run(orc.make_params(FORSTER), d["knots"], d["lin"])
+    check_pre(out, ref, label=fname)
+    # same algorithm, different operation order / block order: far inside the gates
+    for k in ("DT", "alpha", "beta", "q", "J_q", "J_a", "J_b", "H_a", "H_b"):
+        assert np.abs(out[k] - ref[k]).max() < 1e-12, k
+    assert cov_rel_err(out["P"], ref["P"]) < 1e-11
+
+
+@pytest.mark.parametrize("W,N", [(1, 1), (3, 16), (5, 17), (257, 50), (64, 100), (7, 333)])
+def test_comparator_vs_restatement_seeded_shapes(eng, orc, W, N):
+    kn, lin, _ = synth.make_windows(W, N, seed=900 + W + N)
+    out = _host(eng.preintegrate(kn.to(eng.device), lin.to(eng.device), None, eng.make_params(FORSTER)))
+    ref = orc.oracle().run(orc.make_params(FORSTER), kn.numpy(), lin.numpy())
+    check_pre(out, ref, label="W%d N%d" % (W, N))
+
+
+def test_partial_outputs_and_other_sigmas(eng, orc):
+    kn, lin, _ = synth.make_windows(33, 50, seed=5150)
+    sig = (0.02, 1e-4, 0.05, 3e-3)
+    prm = eng.make_params(FORSTER, sigmas=sig)
+    ref = orc.oracle().run(orc.make_params(FORSTER, sigmas=dict(zip(("sigma_w", "sigma_wb", "sigma_a", "sigma_ab"), sig))),
+                           kn.numpy(), lin.numpy())
+    for want in (("cov",), ("mean",), ("jac",), ("mean", "cov")):
+        out = _host(eng.preintegrate(kn.to(eng.device), lin.to(eng.device), None, prm, want=want))
+        check_pre(out, ref, what=want, label=str(want))
+
+
+def test_ragged_windows_cut_from_one_stream(eng, orc):
+    rng = np.random.default_rng(12)
+    K = 700
+    kn, _, _ = synth.make_windows(1, K - 1, seed=77, edge_cases=False)
+    stream = kn.numpy()[0]
+    W = 40
+    first = np.sort(rng.integers(0, K - 130, size=W)).astype(np.int64)
+    count = rng.integers(0, 120, size=W).astype(np.int32)
+    count[3] = 0
+    lin = rng.normal(size=(W, 6)) * 0.01
+    out = _host(eng.preintegrate(_dev(stream, eng), _dev(lin, eng), None, eng.make_params(FORSTER),
+                                 first=_dev(first, eng), count=_dev(count, eng), N=int(count.max())))
+    prm = orc.make_params(FORSTER)
+    for w in range(W):
+        ref = orc.oracle().run(prm, stream[None, first[w]:first[w] + count[w] + 1], lin[w:w + 1])
+        one = {k: v[w:w + 1] for k, v in out.items()}
+        check_pre(one, ref, label="window %d" % w)
+    assert out["DT"][3] == 0 and np.all(out["P"][3] == 0) and np.allclose(out["q"][3], [0, 0, 0, 1])
+
+
+def test_non_positive_and_nan_intervals_are_skipped(eng, orc):
+    kn, lin, _ = synth.make_windows(8, 20, seed=31, edge_cases=False)
+    kn = kn.numpy().copy()
+    kn[1, 5, 0] = kn[1, 4, 0]              # dt == 0
+    kn[2, 7, 0] = kn[2, 6, 0] - 0.01       # dt < 0, then a long one
+    kn[3, 9, 0] = np.nan                   # separator knot: both touching intervals are skipped (t1 - t0 is NaN)
+    out = _host(eng.preintegrate(_dev(kn, eng), lin.to(eng.device), None, eng.make_params(FORSTER)))
+    for k, v in out.items():
+        assert np.all(np.isfinite(v)), k
+    ref = orc.oracle().run(orc.make_params(FORSTER), kn, lin.numpy())
+    check_pre(out, ref)
+    assert abs(out["DT"][3] - ((kn[3, 8, 0] - kn[3, 0, 0]) + (kn[3, 20, 0] - kn[3, 10, 0]))) < 1e-12
+
+
+def test_full_size_100k_windows_properties(eng):
+    """BASELINE configs[2] size (100 k windows x 50): size-independent properties.  The rotation is the same
+    piecewise-constant-rate product in both models; DT is the same sum; predicting state j from the measurement
+    and evaluating the CPI-v1 factor the call site wraps it in (GraphSolver_IMU.cpp:227-231) gives a zero
+    residual; the covariance is symmetric and positive semi-definite."""
+    W, N = 100_000, 50
+    kn, lin, _ = synth.make_windows(W, N, seed=2024, device=eng.device)
+    f = eng.preintegrate(kn, lin, None, eng.make_params(FORSTER))
+    c = eng.preintegrate(kn, lin, None, eng.make_params(1), want=("mean",))
+    torch.cuda.synchronize()
+    assert (f["DT"] - c["DT"]).abs().max().item() < 1e-12
+    dq = torch.minimum((f["q"] - c["q"]).abs().max(dim=1).values, (f["q"] + c["q"]).abs().max(dim=1).values)
+    assert dq.max().item() < 1e-12
+    for k, v in f.items():
+        assert torch.isfinite(v).all(), k
+    P = f["P"].view(W, 15, 15)
+    scale = P.diagonal(dim1=1, dim2=2).abs().sqrt()
+    asym = (P - P.transpose(1, 2)).abs() / (scale[:, :, None] * scale[:, None, :]).clamp_min(1e-300)
+    assert asym.max().item() < 1e-9
+    ev = torch.linalg.eigvalsh(0.5 * (P[:2000] + P[:2000].transpose(1, 2)).cpu())
+    assert (ev.min(dim=1).values >= -1e-12 * ev.max(dim=1).values).all()
+    xi = synth.make_states(f["alpha"], f["beta"], f["q"], f["DT"], lin, 1, device=eng.device)[0].contiguous()
+    # biases at the linearisation point: the bias-correction terms vanish and the residual is the prediction error
+    xi[:, 4:7] = lin[:, 0:3]
+    xi[:, 10:13] = lin[:, 3:6]
+    xj = eng.predict(1, f, xi)
+    states = torch.cat([xi, xj], 0).contiguous()
+    idx_i = torch.arange(W, dtype=torch.int32, device=eng.device)
+    out = eng.factor_eval(1, f, lin, None, states, idx_i, idx_i + W, want_H=False)
+    torch.cuda.synchronize()
+    assert out["err"].abs().max().item() < 10 * TOL_FACTOR

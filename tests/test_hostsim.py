@@ -52,3 +52,15 @@ def test_factor_kernel_math(golden_dir, model):
     assert np.abs(H2 - d["v%d_H2" % model]).max() < 1e-12
     xj = hs.predict(model, d["v%d_rec" % model], d["v%d_xi" % model])
     assert np.abs(xj - op.oracle().predict(model, d["v%d_rec" % model], d["v%d_xi" % model])).max() < 1e-12
+
+
+@pytest.mark.parametrize("fname", ["pre_cfg1.npz", "pre_w48.npz"])
+def test_forster_kernel_math(golden_dir, fname):
+    """The comparator kernel's lane algorithm (sparse F in [theta b_g v b_a p] order, row exchange, per-lane bias
+    Jacobian columns) against the dense GTSAM-order restatement (oracle/forster_oracle.c, parity unpinned)."""
+    d = _gold(golden_dir, fname)
+    out = op.split_out(hs.forster(d["knots"], d["lin"]))
+    ref = op.oracle().run(op.make_params(3), d["knots"], d["lin"])
+    check_pre(out, ref, what=("mean", "jac", "cov"))
+    for k in ("alpha", "beta", "q", "J_q", "J_a", "J_b", "H_a", "H_b"):
+        assert np.abs(out[k] - ref[k]).max() < 1e-12, k
