@@ -8,7 +8,7 @@ from ._lib import CpiError, LIB_PATH  # noqa: F401
 
 
 def __getattr__(name):  # lazy: importing the package must not need torch / a GPU
-    if name in ("Engine", "CpiV1", "CpiV2", "ImuFactorCPIv1", "ImuFactorCPIv2", "default_engine", "unpack_factor"):
+    if name in ("Engine", "CpiV1", "CpiV2", "ForsterDiscrete", "ImuFactorCPIv1", "ImuFactorCPIv2", "default_engine", "unpack_factor"):
         from . import engine
         return getattr(engine, name)
     raise AttributeError(name)

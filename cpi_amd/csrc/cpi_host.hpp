@@ -105,6 +105,9 @@ public:
     }
     const std::vector<double> &knots() const { return knots_; }
     int model() const { return model_; }
+    // the model an ImuFactorCPI built from this measurement evaluates: the Forster comparator's result is wrapped in
+    // an ImuFactorCPIv1 by the reference (GraphSolver_IMU.cpp:227-231)
+    int factor_model() const { return model_ == CPI_MODEL_FORSTER ? CPI_MODEL_V1 : model_; }
 
     bool imu_avg = false;
     bool state_transition_jacobians = true;  // CpiV2.h:58
@@ -112,15 +115,16 @@ public:
     Vec4 q_k_lin{};
     Vec3 grav{};
 
-private:
+protected:
     void push(double t, const Vec3 &w, const Vec3 &a) {
         knots_.push_back(t);
         for (int i = 0; i < 3; i++) knots_.push_back(w[i]);
         for (int i = 0; i < 3; i++) knots_.push_back(a[i]);
     }
+    std::vector<double> knots_;
+private:
     int model_;
     double sig_[4];
-    std::vector<double> knots_;
 };
 
 class CpiV1 : public CpiBase {
@@ -132,6 +136,35 @@ class CpiV2 : public CpiBase {
 public:
     CpiV2(double sigma_w, double sigma_wb, double sigma_a, double sigma_ab, bool imu_avg_ = false)
         : CpiBase(CPI_MODEL_V2, sigma_w, sigma_wb, sigma_a, sigma_ab, imu_avg_) {}
+};
+
+// The "Forster discrete" comparator: what GraphSolver::createimufactor_discrete (GraphSolver_IMU.cpp:141-232) builds
+// with gtsam::PreintegratedCombinedMeasurements -- the four covariances of :152-155 are the constructor's sigmas^2, the
+// bias estimate of :162 goes to setLinearizationPoints(bg_K, ba_K), the loop calls integrateMeasurement(acc, omega, dt)
+// (:180, :194; GTSAM's argument order).  After finalize() / CpiBatch::flush() the result members hold what :204-225
+// derive from the GTSAM object (alpha_tau = deltaPij, beta_tau = deltaVij, q_k2tau = rot_2_quat(deltaRij^T),
+// J_q = -delRdelBiasOmega, J_b / J_a = delV / delP delBiasOmega, H_b / H_a = delV / delP delBiasAcc, P_meas = the
+// block-swapped preintMeasCov), ready for ImuFactorCPI (:227-231).  GTSAM is not part of the reference tree: parity
+// of this model is unpinned (oracle/forster_oracle.c).
+class ForsterDiscrete : public CpiBase {
+public:
+    ForsterDiscrete(double sigma_g, double sigma_wg, double sigma_a, double sigma_wa)
+        : CpiBase(CPI_MODEL_FORSTER, sigma_g, sigma_wg, sigma_a, sigma_wa, false) {}
+    // reading (measuredAcc, measuredOmega) held over the next dt seconds; dt <= 0 is ignored (GraphSolver_IMU.cpp:171)
+    void integrateMeasurement(const Vec3 &measuredAcc, const Vec3 &measuredOmega, double dt) {
+        if (!(dt > 0)) return;
+        if (knots_.empty()) push(0.0, measuredOmega, measuredAcc);
+        else {   // the closing knot of the previous interval becomes the opening knot of this one: give it this reading
+            double *k = &knots_[knots_.size() - 7];
+            for (int i = 0; i < 3; i++) { k[1 + i] = measuredOmega[i]; k[4 + i] = measuredAcc[i]; }
+        }
+        // intervals are stored as knot times; t += dt reproduces dt to within one rounding of the running time
+        t_ += dt;
+        push(t_, measuredOmega, measuredAcc);
+    }
+    double deltaTij() const { return DT; }
+private:
+    double t_ = 0.0;
 };
 
 // Collects many recorded windows (same model / flags / gravity) and runs them in ONE launch.
@@ -247,7 +280,7 @@ inline WindowSet assemble_windows(const std::vector<double> &stream, const std::
 class ImuFactorCPI {
 public:
     // built straight from a finished preintegrator, with the field->ctor mapping of GraphSolver_IMU.cpp:74-75,129-130
-    explicit ImuFactorCPI(const CpiBase &cpi) : model_(cpi.model()), m_(cpi), grav_(cpi.grav), qk_(cpi.q_k_lin) {
+    explicit ImuFactorCPI(const CpiBase &cpi) : model_(cpi.factor_model()), m_(cpi), grav_(cpi.grav), qk_(cpi.q_k_lin) {
         for (int i = 0; i < 3; i++) { lin_[i] = cpi.b_w_lin[i]; lin_[3 + i] = cpi.b_a_lin[i]; }
     }
     void evaluateError(const Context &ctx, const double *state_i, const double *state_j, double *error, double *H1 = nullptr,

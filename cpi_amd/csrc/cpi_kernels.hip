@@ -598,9 +598,10 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
 // RK4 stage).  F depends on the interval alone, so phase A (one lane per interval: Exp, its right Jacobian) needs no
 // prefix scan.
 __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
-    constexpr int GROUP = 16, G = 64 / GROUP, CH = 16, EP = EXCH_PITCH, IRD = fsd::IR_SIZE;
-    __shared__ __attribute__((aligned(16))) double irs[G * CH * IRD];                 // interval records, 12 KB
-    __shared__ __attribute__((aligned(16))) double exch[G * EXCH_GROUP_ROWS * EP];    // row exchange, 5 KB
+    // 12 intervals per phase-A pass: 9 KB of records + 8.4 KB of exchange rows per wavefront, two wavefronts per SIMD
+    constexpr int GROUP = 16, G = 64 / GROUP, CH = 12, EP = EXCH_PITCH, IRD = fsd::IR_SIZE, ROWS = 15;
+    __shared__ __attribute__((aligned(16))) double irs[G * CH * IRD];     // interval records
+    __shared__ __attribute__((aligned(16))) double exch[G * ROWS * EP];   // row exchange: (F P) of each window
 
     const int lane = threadIdx.x;
     const int g = lane / GROUP, j = lane % GROUP;
@@ -612,14 +613,20 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
     const int nmax = wave_max(n);
 
     const double q4[4] = { A.q4[0], A.q4[1], A.q4[2], A.q4[3] };
-    const int kind = (j < 3) ? 0 : ((j < 6) ? 1 : 2), jc = (j < 3) ? j : ((j < 6) ? j - 3 : 0);
-    const int er = (j < 15) ? cov_exch_row(j) : -1;     // theta / v / p columns read a row; bias columns keep their own
+    // per-lane constant vectors instead of selects inside the recursion
+    const V3 eg = (j < 3) ? unit(j) : mk(0, 0, 0);                 // gyro-bias Jacobian column j
+    const V3 ek = (j >= 3 && j < 6) ? unit(j - 3) : mk(0, 0, 0);   // accelerometer-bias Jacobian column j - 3
+    const double th_on = (j < 3) ? 1.0 : 0.0;
     // process noise on this column's own diagonal entry, as one vector per constant-diagonal block
     const V3 nbg = (j >= 3 && j < 6) ? q4[1] * unit(j - 3) : mk(0, 0, 0);
     const V3 nv = (j >= 6 && j < 9) ? q4[2] * unit(j - 6) : mk(0, 0, 0);
     const V3 nba = (j >= 9 && j < 12) ? q4[3] * unit(j - 9) : mk(0, 0, 0);
-    double *ex_g = exch + g * EXCH_GROUP_ROWS * EP;
-    const double *ex_row = ex_g + max(er, 0) * EP;
+    double *ex_g = exch + g * ROWS * EP;
+    // Column j of P F^T is ROW j of F P.  The bias rows of F are identity rows, so for a bias column that row is the
+    // lane's own column -- it is still written and read back like the others: 6 more LDS writes per lane cost less
+    // than 30 v_cndmask per interval on the VALU, which is what bounds this kernel.  (Lane 15 owns nothing: it runs
+    // as a shadow of column 0 and never writes.)
+    const double *ex_row = ex_g + (j < 15 ? j : 0) * EP;
     const int jdrow = fsd::IR_JD + 3 * min(j, 2);
 
     fsd::Mean m;
@@ -630,23 +637,33 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
 #pragma unroll
     for (int i = 0; i < 15; i++) x[i] = 0.0;
 
+    // The knots of the NEXT phase-A pass are requested before phase C of the current one and only consumed after
+    // it: with two wavefronts per SIMD an exposed HBM round trip per 12 intervals was a quarter of the kernel's time
+    // (0.78 -> see DESIGN.md).  vmcnt and lgkmcnt are separate counters, so phase C's LDS waits do not drain them.
+    const V3 bgl = ldv3(A.lin + w * 6), bal = ldv3(A.lin + w * 6 + 3);
+    double kn[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) kn[i] = 0.0;
+    if (j < CH && j < n) {
+        const double *ka = A.knots + (k0 + j) * 7;
+#pragma unroll
+        for (int i = 0; i < 8; i++) kn[i] = ka[i];
+    }
     for (int base = 0; base < nmax; base += CH) {
-        {   // ---- phase A: lane (g, j) builds the record of interval base + j of its window
+        if (j < CH) {   // ---- phase A: lane (g, j) builds the record of interval base + j of its window
             const int s = base + j;
-            long long wq = w;
-            asm volatile("" : "+v"(wq));   // keeps the bias loads inside the loop (registers matter more, see cpi_cov_kernel)
             fsd::Rec r;
             if (s < n) {
-                const double *ka = A.knots + (k0 + s) * 7;
-                const V3 bg = ldv3(A.lin + wq * 6), ba = ldv3(A.lin + wq * 6 + 3);
-                double a[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) a[i] = ka[i];
-                r = fsd::make_rec(a[0], a[7], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]), bg, ba, q4[0]);
+                r = fsd::make_rec(kn[0], kn[7], mk(kn[1], kn[2], kn[3]), mk(kn[4], kn[5], kn[6]), bgl, bal, q4[0]);
             } else {
                 r.dt = 0; r.qs = 0; r.a = mk(0, 0, 0); r.E = eye(); r.JD = zero3();
             }
             fsd::put_rec(irs + (g * CH + j) * IRD, r);
+            if (s + CH < n) {
+                const double *ka = A.knots + (k0 + s + CH) * 7;
+#pragma unroll
+                for (int i = 0; i < 8; i++) kn[i] = ka[i];
+            }
         }
         wave_lds_fence();
 
@@ -655,28 +672,20 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
         for (int sl = 0; sl < cnt; ++sl) {
             const double *ir = irs + (g * CH + sl) * IRD;   // group-uniform address: LDS broadcast
             const fsd::Rec r = fsd::get_rec(ir);
-            fsd::jac_step(J, m.R, r, kind, jc);             // uses the rotation BEFORE this interval
+            fsd::jac_step(J, m.R, r, ek, eg);               // uses the rotation BEFORE this interval
             fsd::mean_step(m, r);
             double y[15];
             fsd::F_apply(r, x, y);
             if (j < 15) {
 #pragma unroll
-                for (int b = 0; b < 3; b++)
-#pragma unroll
-                    for (int i = 0; i < 3; i++) ex_g[(b * 3 + i) * EP + j] = y[b * 6 + i];
+                for (int i = 0; i < 15; i++) ex_g[i * EP + j] = y[i];
             }
             wave_lds_fence();   // DS instructions of a wave execute in order; this only pins the compiler
             double z[15];
 #pragma unroll
             for (int i = 0; i < 15; i++) z[i] = ex_row[i];
-            if (er < 0) {
-#pragma unroll
-                for (int i = 0; i < 15; i++) z[i] = x[i];
-            }
             fsd::F_apply(r, z, x);
-            V3 gth = fsd::theta_noise_col(r, rec_v3(ir, jdrow));
-            if (j >= 3) gth = mk(0, 0, 0);
-            x[0] += gth.x; x[1] += gth.y; x[2] += gth.z;
+            fsd::theta_noise_add(x, r, rec_v3(ir, jdrow), th_on);
             x[3] = fma(r.dt, nbg.x, x[3]); x[4] = fma(r.dt, nbg.y, x[4]); x[5] = fma(r.dt, nbg.z, x[5]);
             x[6] = fma(r.dt, nv.x, x[6]); x[7] = fma(r.dt, nv.y, x[7]); x[8] = fma(r.dt, nv.z, x[8]);
             x[9] = fma(r.dt, nba.x, x[9]); x[10] = fma(r.dt, nba.y, x[10]); x[11] = fma(r.dt, nba.z, x[11]);
@@ -684,6 +693,7 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
         }
     }
 
+    const int kind = (j < 3) ? 0 : ((j < 6) ? 1 : 2), jc = (j < 3) ? j : ((j < 6) ? j - 3 : 0);
     if (!valid) return;
     if (A.out.P && j < 15) {
         double *p = A.out.P + w * 225 + j * 15;

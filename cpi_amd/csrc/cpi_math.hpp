@@ -1155,32 +1155,47 @@ CPI_HD Rec get_rec(const double *o) {
     return r;
 }
 
+// A v + c and A^T v + c as pure FMA chains
+CPI_HD V3 mul_acc(const M3 &A, V3 v, V3 c) {
+    return mk(fma(A.m[0][0], v.x, fma(A.m[0][1], v.y, fma(A.m[0][2], v.z, c.x))),
+              fma(A.m[1][0], v.x, fma(A.m[1][1], v.y, fma(A.m[1][2], v.z, c.y))),
+              fma(A.m[2][0], v.x, fma(A.m[2][1], v.y, fma(A.m[2][2], v.z, c.z))));
+}
+CPI_HD V3 mulT_acc(const M3 &A, V3 v, V3 c) {
+    return mk(fma(A.m[0][0], v.x, fma(A.m[1][0], v.y, fma(A.m[2][0], v.z, c.x))),
+              fma(A.m[0][1], v.x, fma(A.m[1][1], v.y, fma(A.m[2][1], v.z, c.y))),
+              fma(A.m[0][2], v.x, fma(A.m[1][2], v.y, fma(A.m[2][2], v.z, c.z))));
+}
+// a x b + c
+CPI_HD V3 cross_acc(V3 a, V3 b, V3 c) {
+    return mk(fma(a.y, b.z, fma(-a.z, b.y, c.x)), fma(a.z, b.x, fma(-a.x, b.z, c.y)), fma(a.x, b.y, fma(-a.y, b.x, c.z)));
+}
+
 struct Mean { M3 R; V3 p, v; double dT; };
 CPI_HD void mean_init(Mean &m) { m.R = eye(); m.p = mk(0, 0, 0); m.v = mk(0, 0, 0); m.dT = 0; }
+// NavState::update forms p' = p + R (dt R^T v + dt^2/2 a); R R^T = I to rounding, so the body-velocity round trip is
+// skipped: p' = p + dt v + dt^2/2 (R a)  (differs from the literal form by O(1e-16 |v| dt); parity is unpinned and
+// the gate is 1e-9).
 CPI_HD void mean_step(Mean &m, const Rec &r) {
     const double dt22 = 0.5 * r.dt * r.dt;
-    const V3 bv = mulT(m.R, m.v);                       // NavState::bodyVelocity
-    m.p = m.p + mul(m.R, axpy(dt22, r.a, r.dt * bv));
-    m.v = m.v + mul(m.R, r.dt * r.a);
+    const V3 Ra = mul(m.R, r.a);
+    m.p = axpy(dt22, Ra, axpy(r.dt, m.v, m.p));
+    m.v = axpy(r.dt, Ra, m.v);
     m.R = mm(m.R, r.E);
     m.dT += r.dt;
 }
 
-// One column of the bias Jacobians: kind 0 = gyro-bias column c (delRdelBg, delVdelBg, delPdelBg),
-// kind 1 = accelerometer-bias column c (delVdelBa, delPdelBa; r stays 0), anything else = unused lane.
+// One column of the bias Jacobians per lane.  ek = e_c on a lane that owns accelerometer-bias column c (delVdelBa,
+// delPdelBa; its r stays 0), eg = e_c on a lane that owns gyro-bias column c (delRdelBg, delVdelBg, delPdelBg);
+// both zero on every other lane -- no selects in the recursion.
 struct JacCol { V3 r, v, p; };
 CPI_HD void jac_init(JacCol &J) { J.r = mk(0, 0, 0); J.v = mk(0, 0, 0); J.p = mk(0, 0, 0); }
-CPI_HD void jac_step(JacCol &J, const M3 &Rold, const Rec &r, int kind, int c) {
+CPI_HD void jac_step(JacCol &J, const M3 &Rold, const Rec &r, V3 ek, V3 eg) {
     const double dt22 = 0.5 * r.dt * r.dt;
-    V3 u = cross(r.a, J.r);
-    const V3 e = unit(c);
-    if (kind == 1) u = e;
-    const V3 d = -mul(Rold, u);                         // column of D_acc_biasOmega, or of -R
-    J.p = axpy(dt22, d, axpy(r.dt, J.v, J.p));
-    J.v = axpy(r.dt, d, J.v);
-    V3 jd = mul(r.JD, e);
-    if (kind != 0) jd = mk(0, 0, 0);
-    J.r = mulT(r.E, J.r) - jd;
+    const V3 Ru = mul(Rold, cross_acc(r.a, J.r, ek));   // minus the column of D_acc_biasOmega, or of -R
+    J.p = axpy(-dt22, Ru, axpy(r.dt, J.v, J.p));
+    J.v = axpy(-r.dt, Ru, J.v);
+    J.r = mulT_acc(r.E, J.r, -mul(r.JD, eg));
 }
 
 // y = F x for one covariance column (order [theta b_g v b_a p]); only the theta / v / p rows change.
@@ -1188,8 +1203,8 @@ CPI_HD void F_apply(const Rec &r, const double *x, double *y) {
     const V3 th = mk(x[0], x[1], x[2]), bg = mk(x[3], x[4], x[5]), v = mk(x[6], x[7], x[8]);
     const V3 ba = mk(x[9], x[10], x[11]), p = mk(x[12], x[13], x[14]);
     const double dt22 = 0.5 * r.dt * r.dt;
-    const V3 c = cross(r.a, th) + ba;
-    put3(y + 0, mulT(r.E, th) - mul(r.JD, bg));
+    const V3 c = cross_acc(r.a, th, ba);
+    put3(y + 0, mulT_acc(r.E, th, -mul(r.JD, bg)));
     put3(y + 3, bg);
     put3(y + 6, mulT(r.E, axpy(-r.dt, c, v)));
     put3(y + 9, ba);
@@ -1199,8 +1214,12 @@ CPI_HD void F_apply(const Rec &r, const double *x, double *y) {
 CPI_HD double diag_noise(int j, const double q4[4]) {
     return (j >= 3 && j < 6) ? q4[1] : ((j >= 6 && j < 9) ? q4[2] : ((j >= 9 && j < 12) ? q4[3] : 0.0));
 }
-// column j < 3 of G's theta block: (s_w^2/dt) (Jr dt) (Jr dt)^T e_j ; jdrow = row j of Jr dt
-CPI_HD V3 theta_noise_col(const Rec &r, V3 jdrow) { return r.qs * mul(r.JD, jdrow); }
+// x_theta += column j < 3 of G's theta block = (s_w^2/dt) (Jr dt) (Jr dt)^T e_j ; jdrow = row j of Jr dt, on = 1 on
+// the lanes j < 3 and 0 elsewhere
+CPI_HD void theta_noise_add(double *x, const Rec &r, V3 jdrow, double on) {
+    const V3 g = mul_acc(r.JD, (r.qs * on) * jdrow, mk(x[0], x[1], x[2]));
+    x[0] = g.x; x[1] = g.y; x[2] = g.z;
+}
 }  // namespace fsd
 
 }  // namespace cpi

@@ -288,6 +288,31 @@ class CpiV2(_CpiBase):
     O_b = property(lambda s: s._m3("O_b"))
 
 
+class ForsterDiscrete(_CpiBase):
+    """The "Forster discrete" comparator as GraphSolver::createimufactor_discrete (GraphSolver_IMU.cpp:141-232) uses
+    it: GTSAM's PreintegratedCombinedMeasurements driven by integrateMeasurement(acc, omega, dt), read back through the
+    call site's conversions (:204-225) into the CpiV1-shaped result fields.  GTSAM is absent from the reference tree:
+    parity of this model is unpinned (oracle/forster_oracle.c)."""
+    _model = 3
+
+    def __init__(self, sigma_g, sigma_wg, sigma_a, sigma_wa, engine=None):
+        super().__init__(sigma_g, sigma_wg, sigma_a, sigma_wa, False, engine)
+        self._t = 0.0
+
+    def integrateMeasurement(self, measuredAcc, measuredOmega, dt):
+        if not dt > 0:
+            return
+        w, a = np.asarray(measuredOmega, float).reshape(3), np.asarray(measuredAcc, float).reshape(3)
+        if self._iv:   # the previous interval's closing knot opens this one: it carries this reading
+            t0, t1, w0, a0, _, _ = self._iv[-1]
+            self._iv[-1] = (t0, t1, w0, a0, w, a)
+        self._iv.append((self._t, self._t + float(dt), w, a, w, a))
+        self._t += float(dt)
+        self._res = None
+
+    deltaTij = property(lambda s: s.DT)
+
+
 class _ImuFactorBase:
     _model = 0
 

@@ -26,14 +26,19 @@ int main(int argc, char **argv) {
         std::vector<CpiBase *> wins;
         CpiBatch batch;
         for (int w = 0; w < W; w++) {
-            CpiBase *cpi = (model == 1) ? (CpiBase *)new CpiV1(0.005, 4e-6, 0.01, 2e-4) : (CpiBase *)new CpiV2(0.005, 4e-6, 0.01, 2e-4);
+            CpiBase *cpi = (model == 1) ? (CpiBase *)new CpiV1(0.005, 4e-6, 0.01, 2e-4)
+                         : (model == 2) ? (CpiBase *)new CpiV2(0.005, 4e-6, 0.01, 2e-4)
+                                        : (CpiBase *)new ForsterDiscrete(0.005, 4e-6, 0.01, 2e-4);
             const double *l = &lin[w * 6], *qq = &q[w * 4];
             cpi->setLinearizationPoints({{l[0], l[1], l[2]}}, {{l[3], l[4], l[5]}}, {{qq[0], qq[1], qq[2], qq[3]}}, {{0, 0, 9.8}});
             cpi->imu_avg = false;
             const double *k = &kn[(size_t)w * (n + 1) * 7];
             for (int i = 0; i < n; i++) {
                 const double *a = k + 7 * i, *b = k + 7 * (i + 1);
-                if (b[0] - a[0] >= 0)  // GraphSolver_IMU.cpp:52
+                if (model == 3) {      // GraphSolver_IMU.cpp:171-180: integrateMeasurement(acc, omega, dt)
+                    if (b[0] - a[0] >= 0)
+                        static_cast<ForsterDiscrete *>(cpi)->integrateMeasurement({{a[4], a[5], a[6]}}, {{a[1], a[2], a[3]}}, b[0] - a[0]);
+                } else if (b[0] - a[0] >= 0)  // GraphSolver_IMU.cpp:52
                     cpi->feed_IMU(a[0], b[0], {{a[1], a[2], a[3]}}, {{a[4], a[5], a[6]}}, {{b[1], b[2], b[3]}}, {{b[4], b[5], b[6]}});
             }
             wins.push_back(cpi);

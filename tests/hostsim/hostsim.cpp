@@ -171,8 +171,8 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
 void forster_window(int n, const double *kn, const double *lin, const double *sig, double *o) {
     const V3 bg = ld3(lin), ba = ld3(lin + 3);
     const double q4[4] = { sig[0] * sig[0], sig[1] * sig[1], sig[2] * sig[2], sig[3] * sig[3] };
-    const int NL = 16, CH = 16;
-    std::vector<double> irs(CH * fsd::IR_SIZE, 0.0), exch(EXCH_GROUP_ROWS * EXCH_PITCH, 0.0);
+    const int NL = 16, CH = 12, ROWS = 15;
+    std::vector<double> irs(CH * fsd::IR_SIZE, 0.0), exch(ROWS * EXCH_PITCH, 0.0);
     struct LaneS { fsd::Mean m; fsd::JacCol J; double x[15]; };
     std::vector<LaneS> lane(NL);
     for (int j = 0; j < NL; j++) { fsd::mean_init(lane[j].m); fsd::jac_init(lane[j].J); for (int i = 0; i < 15; i++) lane[j].x[i] = 0.0; }
@@ -190,28 +190,27 @@ void forster_window(int n, const double *kn, const double *lin, const double *si
         for (int sl = 0; sl < cnt; sl++) {
             const double *ir = irs.data() + sl * fsd::IR_SIZE;
             const fsd::Rec r = fsd::get_rec(ir);
-            std::vector<std::array<double, 15>> y(NL);
             for (int j = 0; j < NL; j++) {
                 LaneS &Ls = lane[j];
-                const int kind = j < 3 ? 0 : (j < 6 ? 1 : 2), c = j < 3 ? j : (j < 6 ? j - 3 : 0);
-                fsd::jac_step(Ls.J, Ls.m.R, r, kind, c);
+                const V3 eg = (j < 3) ? unit(j) : mk(0, 0, 0), ek = (j >= 3 && j < 6) ? unit(j - 3) : mk(0, 0, 0);
+                fsd::jac_step(Ls.J, Ls.m.R, r, ek, eg);
                 fsd::mean_step(Ls.m, r);
-                fsd::F_apply(r, Ls.x, y[j].data());
-                if (j < 15) {
-                    static const int rows[9] = { 0, 1, 2, 6, 7, 8, 12, 13, 14 };
-                    for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + j] = y[j][rows[rr]];
-                }
+                double y[15];
+                fsd::F_apply(r, Ls.x, y);
+                if (j < 15) for (int i = 0; i < 15; i++) exch[i * EXCH_PITCH + j] = y[i];
             }
-            for (int j = 0; j < 15; j++) {
+            for (int j = 0; j < NL; j++) {
                 LaneS &Ls = lane[j];
                 double z[15];
-                const int er = cov_exch_row(j);
-                for (int i = 0; i < 15; i++) z[i] = (er >= 0) ? exch[er * EXCH_PITCH + i] : Ls.x[i];
+                for (int i = 0; i < 15; i++) z[i] = exch[(j < 15 ? j : 0) * EXCH_PITCH + i];
                 fsd::F_apply(r, z, Ls.x);
-                if (j < 3) {
-                    const V3 g = fsd::theta_noise_col(r, rec_v3(ir, fsd::IR_JD + 3 * j));
-                    Ls.x[0] += g.x; Ls.x[1] += g.y; Ls.x[2] += g.z;
-                } else Ls.x[j] += r.dt * fsd::diag_noise(j, q4);
+                fsd::theta_noise_add(Ls.x, r, rec_v3(ir, fsd::IR_JD + 3 * std::min(j, 2)), j < 3 ? 1.0 : 0.0);
+                const V3 nbg = (j >= 3 && j < 6) ? q4[1] * unit(j - 3) : mk(0, 0, 0);
+                const V3 nv = (j >= 6 && j < 9) ? q4[2] * unit(j - 6) : mk(0, 0, 0);
+                const V3 nba = (j >= 9 && j < 12) ? q4[3] * unit(j - 9) : mk(0, 0, 0);
+                Ls.x[3] += r.dt * nbg.x; Ls.x[4] += r.dt * nbg.y; Ls.x[5] += r.dt * nbg.z;
+                Ls.x[6] += r.dt * nv.x; Ls.x[7] += r.dt * nv.y; Ls.x[8] += r.dt * nv.z;
+                Ls.x[9] += r.dt * nba.x; Ls.x[10] += r.dt * nba.y; Ls.x[11] += r.dt * nba.z;
             }
         }
     }

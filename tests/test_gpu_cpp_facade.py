@@ -49,3 +49,30 @@ def test_cpp_facade_vs_golden(exe, golden_dir, model):
     check_pre(out, ref, v2=(model == 2), label="c++ facade m%d" % model)
     err = np.array([float(x) for x in lines[W].split()[1:]])
     assert err.shape == (15,) and np.abs(err[3:6]).max() == 0 and np.abs(err[9:12]).max() == 0
+
+
+def test_cpp_forster_facade_vs_restatement(exe, golden_dir):
+    """ForsterDiscrete (integrateMeasurement(acc, omega, dt), as GraphSolver_IMU.cpp:171-180 drives GTSAM) against the
+    restatement oracle/forster_oracle.c (parity unpinned); the measurement then goes through ImuFactorCPI as model 1."""
+    from oracle import oracle_py as op
+    d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
+    kn, lin, q = d["knots"], d["lin"], d["q_k_lin"]
+    W, n1, _ = kn.shape
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        np.array([W, n1 - 1], dtype=np.float64).tofile(f)
+        kn.tofile(f); lin.tofile(f); q.tofile(f)
+        path = f.name
+    p = subprocess.run([exe, path, "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().split("\n")
+    rows = np.array([[float(x) for x in ln.split()] for ln in lines[:W]])
+    names = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9), ("H_a", 9), ("H_b", 9),
+             ("O_a", 9), ("O_b", 9), ("P", 225)]
+    out, o = {}, 0
+    for name, n in names:
+        out[name] = rows[:, o] if n == 1 else rows[:, o:o + n]
+        o += n
+    ref = op.oracle().run(op.make_params(3), kn, lin)
+    check_pre(out, ref, label="c++ Forster facade")
+    err = np.array([float(x) for x in lines[W].split()[1:]])
+    assert err.shape == (15,) and np.all(np.isfinite(err)) and np.abs(err[3:6]).max() == 0

@@ -133,3 +133,25 @@ def test_full_size_100k_windows_properties(eng):
     out = eng.factor_eval(1, f, lin, None, states, idx_i, idx_i + W, want_H=False)
     torch.cuda.synchronize()
     assert out["err"].abs().max().item() < 10 * TOL_FACTOR
+
+
+def test_python_mirror_integrateMeasurement(eng, orc):
+    """cpi_amd.ForsterDiscrete driven like GraphSolver_IMU.cpp:171-199 drives GTSAM, then wrapped in the CPI-v1 factor."""
+    import cpi_amd
+    kn, lin, _ = synth.make_windows(1, 37, seed=606, edge_cases=False)
+    kn, lin = kn.numpy()[0], lin.numpy()[0]
+    pre = cpi_amd.ForsterDiscrete(0.005, 4e-6, 0.01, 2e-4, engine=eng)
+    pre.setLinearizationPoints(lin[:3], lin[3:])
+    for i in range(37):
+        pre.integrateMeasurement(kn[i, 4:7], kn[i, 1:4], kn[i + 1, 0] - kn[i, 0])
+    ref = orc.oracle().run(orc.make_params(FORSTER), kn[None], lin[None])
+    assert abs(pre.deltaTij - ref["DT"][0]) < 1e-12
+    assert np.abs(pre.alpha_tau - ref["alpha"][0]).max() < 1e-9 and np.abs(pre.q_k2tau - ref["q"][0]).max() < 1e-9
+    assert np.abs(pre.J_a - ref["J_a"][0].reshape(3, 3).T).max() < 1e-8
+    assert cov_rel_err(pre.P_meas.T.reshape(1, 225), ref["P"]) < 1e-6
+    fac = cpi_amd.ImuFactorCPIv1(pre.P_meas, pre.DT, (0, 0, 9.8), pre.alpha_tau, pre.beta_tau, pre.q_k2tau, lin[3:], lin[:3],
+                                 pre.J_q, pre.J_b, pre.J_a, pre.H_b, pre.H_a, engine=eng)
+    x = np.concatenate([[0, 0, 0, 1], lin[:3], [0.1, 0.2, 0.3], lin[3:], [1, 2, 3]])
+    e = fac.evaluateError(x, x, want_H=False)
+    e = e[0] if isinstance(e, tuple) else e
+    assert np.all(np.isfinite(e)) and np.abs(np.asarray(e)[3:6]).max() == 0

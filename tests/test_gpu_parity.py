@@ -164,7 +164,10 @@ def test_empty_batch_and_bad_arguments(eng):
     with pytest.raises(cpi_amd.CpiError):                    # model 2 without q_k_lin
         eng.preintegrate(kn, lin, None, eng.make_params(2))
     with pytest.raises(cpi_amd.CpiError):
-        eng.preintegrate(kn, lin, q, eng.make_params(3))
+        eng.preintegrate(kn, lin, q, eng.make_params(4))      # 3 = the Forster comparator (tests/test_gpu_forster.py)
+    meas = eng.preintegrate(kn, lin, q, eng.make_params(3))
+    with pytest.raises(cpi_amd.CpiError):                    # ... whose measurement is evaluated as a model-1 factor
+        eng.factor_eval(3, meas, lin, None, torch.zeros((5, 16), dtype=torch.float64, device=eng.device))
     with pytest.raises(cpi_amd.CpiError):
         eng.preintegrate(kn, lin, q, eng.make_params(1, lanes_per_window=7))
 
