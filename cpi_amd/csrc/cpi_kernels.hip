@@ -398,12 +398,12 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     // SIMD) leave room for -- 16 x 25 doubles (model 1), 24 x 40 doubles (model 2).  A pass used to cost as much as
     // 2.3-2.5 intervals of phase C (68 / 114 us per pass at 100 k windows with ds_bpermute scans), so fewer passes
     // matter: 50 samples = 4 instead of 7 passes (model 1), 3 instead of 4 (model 2).
-    constexpr int CH = (MODEL == 1) ? 16 : 24;
+    constexpr int CH = (MODEL == 1) ? 15 : 23;
     static_assert(CH <= GROUP, "one lane per staged interval");
     constexpr int EP = EXCH_PITCH;
-    constexpr int IRD = IrSize<MODEL>::V;
+    constexpr int IRD = IrPitch<MODEL>::V;
     __shared__ __attribute__((aligned(16))) double irs[G * CH * IRD];          // interval records (phase A -> C)
-    __shared__ __attribute__((aligned(16))) double exch[(G * EXCH_GROUP_ROWS + EXCH_SHARED_ROWS) * EP];   // transpose exchange
+    __shared__ __attribute__((aligned(256))) double exch[exch_doubles(G)];   // transpose exchange (bank-conflict-free placement, cpi_math.hpp)
     __shared__ __attribute__((aligned(16))) double gsh[G * GS_DOUBLES];        // carried rotation / means per window
 
     const int lane = threadIdx.x;
@@ -420,18 +420,18 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     const int jj = cov_col_of_lane<MODEL>(j);  // column owned by this lane; idle lanes (NCOL) run as a harmless zero transition column
     CovLane<MODEL> Ln;
     cov_init(Ln, jj, q4);
-    double *ex_g = exch + g * EXCH_GROUP_ROWS * EP;
-    double *ex_shared = exch + G * EXCH_GROUP_ROWS * EP;
-    const double *ex_row = cov_row_ptr<MODEL>(ex_g, ex_shared, jj);
+    double *ex_g = exch + g * EXCH_WIN;
+    // every row starts on a 16-B boundary; said explicitly, or the row reads degrade from ds_read_b128 to ds_read_b64
+    const double *ex_row = exch + (cov_row_off<MODEL>(G, g, jj) & ~1);   // (the offset is even; the mask lets the compiler see it)
     const int hoff = cov_h_offset<MODEL>(jj);
     double *gs = gsh + g * GS_DOUBLES;
-    for (int i = lane; i < (G * EXCH_GROUP_ROWS + EXCH_SHARED_ROWS) * EP; i += 64) exch[i] = 0.0;
+    for (int i = lane; i < exch_doubles(G); i += 64) exch[i] = 0.0;
     if (j == 0) {
         cov_gs_init(gs);
         if (MODEL == 2) put3(gs + GS_GK, mul(quat_2_Rot(ldq4(A.qk + w * 4)), mk(A.grav[0], A.grav[1], A.grav[2])));
     }
     __syncthreads();
-    cov_exch_init<MODEL>(ex_shared, jj, q4);
+    cov_exch_init<MODEL>(exch, G, jj, q4);
 
     for (int base = 0; base < nmax; base += CH) {
         // ---- phase A: lane (g, j) owns interval base + j of its window: closed forms, then the running rotation
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                 cov_stage_M(Ln, stg, Rs, M);
                 if (jj < D::NPCOL) {
 #pragma unroll
-                    for (int rr = 0; rr < 9; rr++) ex_g[rr * EP + jj] = M[rr];
+                    for (int rr = 0; rr < 9; rr++) ex_g[rr * EP + exch_pos<MODEL>(jj)] = M[rr];
                 }
                 // The exchange is private to this wavefront and a wave's DS instructions execute in issue
                 // order, so the row reads below see the writes above without draining lgkmcnt; only the
@@ -598,10 +598,18 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
 // RK4 stage).  F depends on the interval alone, so phase A (one lane per interval: Exp, its right Jacobian) needs no
 // prefix scan.
 __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
-    // 12 intervals per phase-A pass: 9 KB of records + 8.4 KB of exchange rows per wavefront, two wavefronts per SIMD
-    constexpr int GROUP = 16, G = 64 / GROUP, CH = 12, EP = EXCH_PITCH, IRD = fsd::IR_SIZE, ROWS = 15;
-    __shared__ __attribute__((aligned(16))) double irs[G * CH * IRD];     // interval records
-    __shared__ __attribute__((aligned(16))) double exch[G * ROWS * EP];   // row exchange: (F P) of each window
+    // 12 intervals per phase-A pass: 9.8 KB of records + 9 KB of exchange rows per wavefront, two wavefronts per SIMD.
+    // LDS banking (64 x 4 B; ds_read_b128 serves mixed 16-lane groups of two windows, MI355X_MICROARCH.md "LDS"):
+    //  * records are pitched 26 doubles (208 B), so the 8 lanes of a ds_write_b128 group land on distinct 16-B slots
+    //    in phase A and the four windows' broadcast reads of "their" record (window stride 12 x 208 B = 192 mod 256)
+    //    use different slots -- with the natural 24-double pitch all four windows hit the same banks (2-way conflict
+    //    on every record read);
+    //  * exchange rows are pitched 18 doubles (144 B = 9 slots) and windows 288 doubles (0 mod 256 B): the two
+    //    half-windows a ds_read_b128 lane group mixes then read complementary slot sets.
+    constexpr int GROUP = 16, G = 64 / GROUP, CH = 12, EP = EXCH_PITCH, IRD = 26, ROWS = 15, EXW = 16 * EP;
+    static_assert(IRD >= fsd::IR_SIZE, "record pitch");
+    __shared__ __attribute__((aligned(256))) double irs[G * CH * IRD];   // interval records
+    __shared__ __attribute__((aligned(256))) double exch[G * EXW];       // row exchange: (F P) of each window
 
     const int lane = threadIdx.x;
     const int g = lane / GROUP, j = lane % GROUP;
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
     const V3 nbg = (j >= 3 && j < 6) ? q4[1] * unit(j - 3) : mk(0, 0, 0);
     const V3 nv = (j >= 6 && j < 9) ? q4[2] * unit(j - 6) : mk(0, 0, 0);
     const V3 nba = (j >= 9 && j < 12) ? q4[3] * unit(j - 9) : mk(0, 0, 0);
-    double *ex_g = exch + g * ROWS * EP;
+    double *ex_g = exch + g * EXW;
     // Column j of P F^T is ROW j of F P.  The bias rows of F are identity rows, so for a bias column that row is the
     // lane's own column -- it is still written and read back like the others: 6 more LDS writes per lane cost less
     // than 30 v_cndmask per interval on the VALU, which is what bounds this kernel.  (Lane 15 owns nothing: it runs

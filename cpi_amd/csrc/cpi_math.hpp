@@ -698,6 +698,10 @@ template <> struct IrL<2> {   // + g_tau, h_l = R_old (g_k x e_l) for l = 0..2, 
     static const int DT = 0, W = 1, A = 4, GTAU = 7, RMID = 10, RNEW = 19, H = 28, ZERO = 37, SIZE = 40;
 };
 template <int MODEL> struct IrSize { static const int V = IrL<MODEL>::SIZE; };   // doubles per record
+// LDS pitch of a record.  Phase A writes one record per lane (ds_write_b128: 8 lanes at a time on 32 banks): model 2's
+// natural 40 doubles = 320 B puts every other lane on the same banks (4-way conflicts); 42 doubles = 336 B walks the
+// 8 lanes over 8 distinct 16-B slots.  Model 1's 25 doubles (8-B aligned records, ds_write_b64) are conflict-free.
+template <int MODEL> struct IrPitch { static const int V = (MODEL == 1) ? IrL<1>::SIZE : 42; };
 // group-shared carry across chunks: running rotation and means
 static const int GS_R = 0, GS_ALPHA = 10, GS_BETA = 14, GS_DT = 18, GS_GK = 20 /* model 2: R(q_k_lin) g */,
                  GS_R0 = 24 /* rotation at the start of the current phase-A pass */, GS_DOUBLES = 34;
@@ -761,7 +765,27 @@ CPI_HD void gs_apply_inc(double *gs, const MeanInc &c) {
 // (their only k contribution is the process noise on the diagonal) and row 15 = zeros (columns with no
 // transposed row: clone and transition lanes).
 static const int EXCH_GROUP_ROWS = 9, EXCH_SHARED_ROWS = 7;
-static const int EXCH_PITCH = 18;  // doubles: 16-B aligned rows on distinct LDS bank slots
+static const int EXCH_PITCH = 18;  // doubles: 16-B aligned rows, 9 LDS slots (16 B each) apart -- 9 is coprime to 16
+// Placement against LDS bank conflicts (64 x 4-B banks = 16 slots of 16 B; a ds_read_b128 is served in four groups of
+// 16 lanes, {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32 -- MI355X_MICROARCH.md "LDS"): a lane reads 8
+// consecutive slots of "its" row, so a lane group is conflict-free when its 16 row bases are distinct mod 16 slots (or
+// identical).  With rows 9 slots apart, the theta/v/p rows of a window sit on residues w + {0,9,2,11,4,13,6,15,8} and
+// the shared rows on s + {0,9,2,11,4,13,6}; the lane groups above mix exactly such sets, and they are disjoint for
+// every group iff all windows start on the same residue (window stride = 0 mod 256 B) and s = w + 1.  Hence:
+//   window g at doubles g*192 (1536 B: 9 rows + a 30-double gap); shared row 0 inside window 0's gap (offset 162);
+//   shared rows 1..6 contiguous after the windows at +20 doubles (slot 10 = 1 + 9).
+// Measured (rocprofv3 SQ_LDS_BANK_CONFLICT, 100 k windows x 50): see DESIGN.md 3.2.
+static const int EXCH_WIN = 192;
+// Position of column c inside an exchange row.  Model 2 spreads its 18 columns over lanes 0-2 | 4-6 (clone columns
+// 15-17) | 8-19 (columns 3-14); a ds_write_b64 is served 16 contiguous lanes at a time on 32 banks, so the columns the
+// first 16 lanes own (0-10 and 15-17) must sit on distinct positions mod 16: the clone columns move to 11-13 and
+// columns 11-14 to 14-17.  (With the identity, columns 16 and 17 collide with 0 and 1 on every exchange write.)
+template <int MODEL>
+CPI_HD constexpr int exch_pos(int c) { return (MODEL == 1 || c <= 10) ? c : (c <= 14 ? c + 3 : c - 4); }
+CPI_HD constexpr int exch_doubles(int G) { return G * EXCH_WIN + 20 + (EXCH_SHARED_ROWS - 1) * EXCH_PITCH; }
+CPI_HD int exch_shared_off(int G, int s) {   // offset (doubles) of shared row s = layout row 9 + s
+    return (s == 0) ? EXCH_GROUP_ROWS * EXCH_PITCH : G * EXCH_WIN + 20 + (s - 1) * EXCH_PITCH;
+}
 
 template <int MODEL>
 struct CovLane {
@@ -813,17 +837,18 @@ CPI_HD int cov_h_offset(int j) {
     return (MODEL == 2 && d >= 6 && d < 9) ? IrL<MODEL>::H + 3 * (d - 6) : IrL<MODEL>::ZERO;
 }
 // Initialise the shared constant rows (9..15).  Called by every lane for its own column index (all groups write
-// identical values); the rows must have been zeroed before.
+// identical values); the rows must have been zeroed before.  G = windows per wavefront (layout above).
 template <int MODEL>
-CPI_HD void cov_exch_init(double *ex_shared, int j, const double q4[4]) {   // ex_shared = row 9 of the layout above
-    if (j >= 3 && j < 6) ex_shared[(j - 3) * EXCH_PITCH + j] = q4[1];
-    if (j >= 9 && j < 12) ex_shared[(3 + (j - 9)) * EXCH_PITCH + j] = q4[3];
+CPI_HD void cov_exch_init(double *exch, int G, int j, const double q4[4]) {
+    if (j >= 3 && j < 6) exch[exch_shared_off(G, j - 3) + exch_pos<MODEL>(j)] = q4[1];
+    if (j >= 9 && j < 12) exch[exch_shared_off(G, 3 + (j - 9)) + exch_pos<MODEL>(j)] = q4[3];
 }
-// Pointer to the row a column reads as Mt: its group's exchange rows or one of the shared constant rows.
+// Offset (doubles, always even = 16-B aligned) of the row a column reads as Mt: one of its window's exchange rows or
+// one of the shared constant rows.
 template <int MODEL>
-CPI_HD const double *cov_row_ptr(const double *ex_g, const double *ex_shared, int j) {
+CPI_HD int cov_row_off(int G, int g, int j) {
     const int r = cov_read_row<MODEL>(j);
-    return (r < EXCH_GROUP_ROWS) ? ex_g + r * EXCH_PITCH : ex_shared + (r - EXCH_GROUP_ROWS) * EXCH_PITCH;
+    return (r < EXCH_GROUP_ROWS) ? g * EXCH_WIN + r * EXCH_PITCH : exch_shared_off(G, r - EXCH_GROUP_ROWS);
 }
 
 // j = column index inside the window's lane group: [0,NPCOL) covariance, [NPCOL,NCOL) transition, NCOL = idle.
@@ -895,7 +920,7 @@ CPI_HD void cov_stage_finish(CovLane<MODEL> &L, int s, const double M[9], const 
     const double wgt = (s == 0 || s == 3) ? dt * (1.0 / 6.0) : dt * (1.0 / 3.0);
 #pragma unroll
     for (int i = 0; i < D::NR; i++) {
-        double k = Mt[i];
+        double k = Mt[exch_pos<MODEL>(i)];
         if (i < 3) k += M[i];
         else if (i >= 6 && i < 9) k += M[i - 3];
         else if (i >= 12 && i < 15) k += M[i - 6];

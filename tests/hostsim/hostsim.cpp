@@ -81,13 +81,12 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
     const int NL = D::GROUP;   // all lanes of the group, idle ones included (as in the kernel)
     const int CH = D::GROUP;   // intervals per phase-A pass
     std::vector<CovLane<MODEL>> lane(NL);
-    const int IRD = IrSize<MODEL>::V;
-    std::vector<double> exch((EXCH_GROUP_ROWS + EXCH_SHARED_ROWS) * EXCH_PITCH, 0.0), irs(CH * IRD, 0.0);
-    double *ex_shared = exch.data() + EXCH_GROUP_ROWS * EXCH_PITCH;
+    const int IRD = IrPitch<MODEL>::V;
+    std::vector<double> exch(exch_doubles(1), 0.0), irs(CH * IRD, 0.0);
     double gs[GS_DOUBLES];
     cov_gs_init(gs);
     std::vector<int> colof(NL);
-    for (int j = 0; j < NL; j++) { colof[j] = cov_col_of_lane<MODEL>(j); cov_init(lane[j], colof[j], q4); cov_exch_init<MODEL>(ex_shared, colof[j], q4); }
+    for (int j = 0; j < NL; j++) { colof[j] = cov_col_of_lane<MODEL>(j); cov_init(lane[j], colof[j], q4); cov_exch_init<MODEL>(exch.data(), 1, colof[j], q4); }
     for (int base = 0; base < n; base += CH) {
         // ---- phase A, as the kernel does it: per-lane closed forms, Hillis-Steele prefix product of the step
         // rotations, finish_interval, ordered tree reduction of the mean increments
@@ -128,10 +127,10 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
                 double M[32][9];
                 for (int j = 0; j < NL; j++) {
                     cov_stage_M(lane[j], st, (st == 0) ? Rs : cov_stage_rotation<MODEL>(ir, st), M[j]);
-                    if (colof[j] < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + colof[j]] = M[j][rr];
+                    if (colof[j] < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + exch_pos<MODEL>(colof[j])] = M[j][rr];
                 }
                 for (int j = 0; j < NL; j++)
-                    cov_stage_finish(lane[j], st, M[j], cov_row_ptr<MODEL>(exch.data(), ex_shared, colof[j]));
+                    cov_stage_finish(lane[j], st, M[j], exch.data() + cov_row_off<MODEL>(1, 0, colof[j]));
             }
             Rs = cov_stage_rotation<MODEL>(ir, 3);
             for (int j = 0; j < NL; j++) cov_end(lane[j]);
