@@ -945,6 +945,10 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
             if (pass == 1 && A.H1) wave_lds_fence();   // in-order DS: the H1 flush reads complete before these writes land
 #pragma unroll
             for (int k = 0; k < CPL; k++) {
+                // (Measured: giving lane q the ADJACENT columns CPL*q + k instead removes the 2-way LDS bank conflict of
+                // these column writes -- a 16-lane ds_write_b64 group holds two factors one 8-byte slot apart --
+                // SQ_LDS_BANK_CONFLICT -83 %, but the sweep is HBM-write bound and gets no faster: A/B on one box
+                // 0.88 / 0.89-0.92 ms vs 0.85-0.89 / 0.90-0.91 ms per 1 M factors (model 1 / 2).  Kept interleaved.)
                 const int c = q + LPF * k;
                 if (c < 15) {
                     double h[15];
