@@ -395,10 +395,10 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     constexpr int GROUP = D::GROUP;   // lanes per window
     constexpr int G = 64 / GROUP;     // windows per wavefront
     // intervals per window staged by one phase-A pass: as many as 20 KB of LDS per wavefront (two wavefronts per
-    // SIMD) leave room for -- 16 x 25 doubles (model 1), 24 x 40 doubles (model 2).  A pass used to cost as much as
-    // 2.3-2.5 intervals of phase C (68 / 114 us per pass at 100 k windows with ds_bpermute scans), so fewer passes
-    // matter: 50 samples = 4 instead of 7 passes (model 1), 3 instead of 4 (model 2).
-    constexpr int CH = (MODEL == 1) ? 15 : 23;
+    // SIMD) leave room for next to the bank-conflict-free exchange area -- 14 records pitched 26 doubles (model 1),
+    // 23 pitched 42 (model 2).  A pass used to cost as much as 2.3-2.5 intervals of phase C (68 / 114 us per pass at
+    // 100 k windows with ds_bpermute scans), so fewer passes matter: 50 samples = 4 passes (model 1), 3 (model 2).
+    constexpr int CH = (MODEL == 1) ? 14 : 23;
     static_assert(CH <= GROUP, "one lane per staged interval");
     constexpr int EP = EXCH_PITCH;
     constexpr int IRD = IrPitch<MODEL>::V;

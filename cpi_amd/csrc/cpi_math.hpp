@@ -698,10 +698,12 @@ template <> struct IrL<2> {   // + g_tau, h_l = R_old (g_k x e_l) for l = 0..2, 
     static const int DT = 0, W = 1, A = 4, GTAU = 7, RMID = 10, RNEW = 19, H = 28, ZERO = 37, SIZE = 40;
 };
 template <int MODEL> struct IrSize { static const int V = IrL<MODEL>::SIZE; };   // doubles per record
-// LDS pitch of a record.  Phase A writes one record per lane (ds_write_b128: 8 lanes at a time on 32 banks): model 2's
-// natural 40 doubles = 320 B puts every other lane on the same banks (4-way conflicts); 42 doubles = 336 B walks the
-// 8 lanes over 8 distinct 16-B slots.  Model 1's 25 doubles (8-B aligned records, ds_write_b64) are conflict-free.
-template <int MODEL> struct IrPitch { static const int V = (MODEL == 1) ? IrL<1>::SIZE : 42; };
+// LDS pitch of a record.  Both pitches keep every record on a 16-B boundary so that phase C's broadcast reads are
+// ds_read_b128 (4 LDS cycles per two doubles; the ds_read2_b64 pairs an 8-B aligned record is read with cost 8), and
+// both walk the lanes of a phase-A ds_write_b128 group (8 lanes on 32 banks) over distinct 16-B slots: model 1 26
+// doubles (25 used; 1.436 -> 1.410 ms per 100 k x 50 against the 25-double pitch), model 2 42 (40 used; 40 = 320 B
+// puts every other lane on the same banks).
+template <int MODEL> struct IrPitch { static const int V = (MODEL == 1) ? 26 : 42; };
 // group-shared carry across chunks: running rotation and means
 static const int GS_R = 0, GS_ALPHA = 10, GS_BETA = 14, GS_DT = 18, GS_GK = 20 /* model 2: R(q_k_lin) g */,
                  GS_R0 = 24 /* rotation at the start of the current phase-A pass */, GS_DOUBLES = 34;
