@@ -48,9 +48,10 @@ MALL_BYTES = 256 << 20
 # KiB and gfx950's FETCH_SIZE reports half of a streaming read -> bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.
 # bench.py cannot collect PMC counters itself (that needs the rocprofv3 wrapper), so the figure is only reported for
 # the exact (workload, size) it was measured on; any other configuration reports null.
-PMC_TRAFFIC_KIB = {("v1_mean", 10000, 50): (15662.8, 906.25), ("v1_mean", 1000000, 50): (1803690.0, 85947.2),
-                   ("v1_full", 100000, 50): (145070.0 + 147758.0, 184375.0 + 35156.7),   # covariance + Jacobian kernels
-                   ("v2_full", 100000, 50): (149088.0, 242188.0),
+PMC_TRAFFIC_KIB = {("v1_mean", 10000, 50): (15620.2, 906.25), ("v1_mean", 1000000, 50): (1803690.0, 85947.2),
+                   ("v1_full", 100000, 50): (144556.0 + 147757.0, 184375.0 + 35156.6),   # covariance + Jacobian kernels
+                   ("v2_full", 100000, 50): (149170.0, 242188.0),
+                   ("forster_full", 100000, 50): (144690.0, 219531.0),
                    ("factor_v1", 1000000, 50): (351659.0, 3632840.0), ("factor_v2", 1000000, 50): (445426.0, 3632830.0)}
 
 
