@@ -1237,10 +1237,6 @@ CPI_HD void F_apply(const Rec &r, const double *x, double *y) {
     put3(y + 9, ba);
     put3(y + 12, mulT(r.E, axpy(-dt22, c, axpy(r.dt, v, p))));
 }
-// process-noise variance per unit time on the diagonal of column j (theta has the full block below, p none)
-CPI_HD double diag_noise(int j, const double q4[4]) {
-    return (j >= 3 && j < 6) ? q4[1] : ((j >= 6 && j < 9) ? q4[2] : ((j >= 9 && j < 12) ? q4[3] : 0.0));
-}
 // x_theta += column j < 3 of G's theta block = (s_w^2/dt) (Jr dt) (Jr dt)^T e_j ; jdrow = row j of Jr dt, on = 1 on
 // the lanes j < 3 and 0 elsewhere
 CPI_HD void theta_noise_add(double *x, const Rec &r, V3 jdrow, double on) {
