@@ -163,6 +163,27 @@ def time_steps(wl, steps, warmup, dist_on=False):
     return wall, kern_ms
 
 
+def usable_cpus():
+    """Threads worth starting: the affinity mask capped by the cgroup CPU quota.  (The GPU boxes of this pool show 256
+    logical CPUs but run the container under cpu.max = 16 CPUs; with 256 threads the same code is 2x SLOWER than with
+    16 -- measured with tools/cpu_scale.py: 42 k windows/s at 16 threads, 20 k at 256.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                quota, period = int(f.read()), int(g.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(wl, min_seconds=8.0):
     """The reference's own CpiV1/CpiV2 (oracle/_ref, kind 'reference') or the C restatement (kind
     'port') timed on this box's host cores on a bounded sample of the SAME windows."""
@@ -171,15 +192,18 @@ def cpu_baseline(wl, min_seconds=8.0):
     lib, kind = (ref, "reference") if ref is not None else (op.oracle(), "port")
     if wl.model == 3:   # the Forster comparator lives in GTSAM (absent): only the restatement exists
         lib, kind = op.oracle(), "port"
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     kn, lin, q = [t.cpu().numpy() for t in wl.batches[0]]
     Wc = min(wl.W, 10000)
     kn, lin, q = kn[:Wc], lin[:Wc], q[:Wc]
     prm = op.make_params(wl.model, 0, 1)
+    import numpy as np
+    from oracle.oracle_py import OUT_DOUBLES
+    raw = np.ones((Wc, OUT_DOUBLES))                               # reused, already touched output buffer
     lib.run(prm, kn[:256], lin[:256], q[:256], nthreads=cores)     # warm
     t0, done = time.perf_counter(), 0
     while True:
-        lib.run(prm, kn, lin, q, nthreads=cores)
+        lib.run(prm, kn, lin, q, nthreads=cores, raw=raw)
         done += Wc
         el = time.perf_counter() - t0
         if el >= min_seconds:
@@ -189,9 +213,10 @@ def cpu_baseline(wl, min_seconds=8.0):
     t1 = time.perf_counter(); lib.run(prm, kn[:ws], lin[:ws], q[:ws], nthreads=1); t1 = time.perf_counter() - t1
     return {"value": done / el, "unit": "windows/s", "cores": cores, "kind": kind,
             "single_core_value": ws / t1,
-            "sample": "%d passes over %d of the workload's %d-sample windows, %d threads; the reference feed_IMU "
-                      "always integrates means + bias Jacobians + covariance (it has no mean-only mode)"
-                      % (done // Wc, Wc, wl.N, cores)}
+            "sample": "%d passes over %d of the workload's %d-sample windows, %d threads (= usable CPUs: affinity mask "
+                      "capped by the cgroup quota; %d logical CPUs visible); the reference feed_IMU always integrates "
+                      "means + bias Jacobians + covariance (it has no mean-only mode)"
+                      % (done // Wc, Wc, wl.N, cores, os.cpu_count() or 1)}
 
 
 def main():

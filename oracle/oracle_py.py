@@ -78,7 +78,9 @@ class _Lib:
         for f in (self.batch, self.batch_mt):
             f.restype = None
 
-    def run(self, prm, knots, lin, q_k_lin=None, nthreads=1):
+    def run(self, prm, knots, lin, q_k_lin=None, nthreads=1, raw=None):
+        """raw: optional preallocated (and already touched) [W, 308] output buffer -- timing loops reuse it so that
+        page-faulting a fresh 25 MB array under hundreds of threads is not what gets measured."""
         knots = np.ascontiguousarray(knots, dtype=np.float64)
         lin = np.ascontiguousarray(lin, dtype=np.float64)
         W, n1, seven = knots.shape
@@ -86,7 +88,9 @@ class _Lib:
         if q_k_lin is not None:
             q_k_lin = np.ascontiguousarray(q_k_lin, dtype=np.float64)
             assert q_k_lin.shape == (W, 4)
-        raw = np.zeros((W, OUT_DOUBLES), dtype=np.float64)
+        if raw is None:
+            raw = np.zeros((W, OUT_DOUBLES), dtype=np.float64)
+        assert raw.shape == (W, OUT_DOUBLES) and raw.dtype == np.float64 and raw.flags.c_contiguous
         args = [C.byref(prm), C.c_long(W), C.c_int(n1 - 1), _dp(knots), _dp(lin), _dp(q_k_lin), _dp(raw)]
         if nthreads > 1:
             self.batch_mt(*args, C.c_int(nthreads))
