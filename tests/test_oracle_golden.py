@@ -94,3 +94,29 @@ def test_mean_composition_v1():
     assert np.abs(R - Rw).max() < 1e-14
     assert np.abs(beta - whole["beta"]).max() < 1e-14
     assert np.abs(alpha - whole["alpha"]).max() < 1e-14
+
+
+@pytest.mark.parametrize("dt_scale,w_scale,a_scale", [(4.0, 1.0, 1.0), (0.02, 1.0, 1.0), (1.0, 40.0, 1.0), (1.0, 1.0, 50.0),
+                                                     (0.5, 10.0, 10.0), (1.0, 1e-4, 1.0)])
+def test_restatement_matches_compiled_reference_over_the_dynamic_range(dt_scale, w_scale, a_scale):
+    """The scales tests/test_gpu_parity.py::test_dynamic_range_stress checks the HIP path on (50 Hz - 10 kHz, rates up
+    to ~20 rad/s and down to the Taylor branch below 0.0087 rad/s, specific forces up to ~500 m/s^2): the restatement
+    the GPU is compared with there is itself pinned to the compiled reference on the same inputs."""
+    ref = op.reference()
+    if ref is None:
+        pytest.skip("oracle/_ref/libcpi_ref.so not present")
+    kn, lin, q = synth.make_windows(64, 50, seed=31337, edge_cases=False)
+    kn, lin, q = kn.numpy().copy(), lin.numpy().copy(), q.numpy()
+    t0 = kn[:, :1, 0].copy()
+    kn[:, :, 0] = t0 + (kn[:, :, 0] - t0) * dt_scale
+    kn[:, :, 1:4] *= w_scale
+    kn[:, :, 4:7] *= a_scale
+    lin[:, 0:3] *= w_scale
+    lin[:, 3:6] *= a_scale
+    for mode in [(1, 0, 1), (1, 1, 1), (2, 0, 1), (2, 1, 0)]:
+        prm = op.make_params(*mode)
+        a, b = op.oracle().run(prm, kn, lin, q), ref.run(prm, kn, lin, q)
+        for k in ("DT", "alpha", "beta", "q", "J_q", "J_a", "J_b", "H_a", "H_b", "O_a", "O_b"):
+            scale = max(1.0, float(np.abs(b[k]).max()))
+            assert np.abs(a[k] - b[k]).max() <= 1e-11 * scale, (mode, k)
+        assert cov_rel_err(a["P"], b["P"]) < 1e-10, mode
