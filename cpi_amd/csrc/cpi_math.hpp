@@ -350,6 +350,13 @@ CPI_HD StepCoef step_coef(V3 w, double dt) {
     }
     return k;
 }
+// (Tried and rejected: power series in (|w| dt)^2 for s1, s2, f1..f4 on the mean-only path -- no square root, no
+// reciprocal, no sin / cos, ~20 fewer FP64 instructions per interval.  They are MORE accurate than the reference's
+// closed forms, and that is the problem: just above its 0.0087 rad/s Taylor threshold the reference's f2 =
+// (x^2 - 2 cos x - 2 x sin x + 2) / (2 |w|^4) is cancellation noise of order 1e-16 / |w|^4, which the closed forms
+// above reproduce (same expressions, parity 2e-15) and a series does not: alpha moved by 6e-11 on the golden windows
+// with |w| ~ 0.01 rad/s and would pass the 1e-9 gate's margin with larger specific forces or longer windows.
+// Parity with the reference, noise included, comes first.)
 CPI_HD M3 R_step_of(V3 w, const StepCoef &k) { return poly_wx(w, 1.0, -k.s1, k.s2); }
 // rotation over the first half of the interval (CpiV1.h:267-268 / CpiV2.h:315-322)
 CPI_HD M3 R_half_of(V3 w, const StepCoef &k) {
