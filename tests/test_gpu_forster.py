@@ -155,3 +155,38 @@ def test_python_mirror_integrateMeasurement(eng, orc):
     e = fac.evaluateError(x, x, want_H=False)
     e = e[0] if isinstance(e, tuple) else e
     assert np.all(np.isfinite(e)) and np.abs(np.asarray(e)[3:6]).max() == 0
+
+
+def test_fuzz_random_shapes_dense_and_ragged(eng, orc):
+    """20 random (W, N, dense | ragged, requested outputs) combinations against the restatement."""
+    rng = np.random.default_rng(777)
+    oprm = orc.make_params(FORSTER)
+    prm = eng.make_params(FORSTER)
+    for case in range(20):
+        W = int(rng.integers(1, 200))
+        N = int(rng.integers(1, 70))
+        want = [("mean", "jac", "cov"), ("cov",), ("mean", "jac")][case % 3]
+        if case % 2 == 0:
+            kn, lin, _ = synth.make_windows(W, N, seed=8100 + case)
+            kn, lin = kn.numpy(), lin.numpy()
+            ref = orc.oracle().run(oprm, kn, lin)
+            out = _host(eng.preintegrate(_dev(kn, eng), _dev(lin, eng), None, prm, want=want))
+        else:
+            lens = rng.integers(0, N + 1, W).astype(np.int32)
+            lens[rng.integers(0, W)] = N
+            K = int(lens.sum()) + 1
+            kn1, _, _ = synth.make_windows(1, max(K - 1, 1), seed=8200 + case, edge_cases=False)
+            stream = kn1.numpy()[0][:K]
+            first = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            lin = rng.normal(size=(W, 6)) * 0.01
+            out = _host(eng.preintegrate(_dev(stream, eng), _dev(lin, eng), None, prm, want=want,
+                                         first=_dev(first, eng), count=_dev(lens, eng), N=N))
+            ref = None
+            for w in range(W):
+                n = int(lens[w])
+                r = orc.oracle().run(oprm, stream[first[w]:first[w] + n + 1][None], lin[w:w + 1])
+                if ref is None:
+                    ref = {k: np.zeros((W,) + v.shape[1:]) for k, v in r.items()}
+                for k in ref:
+                    ref[k][w] = r[k][0]
+        check_pre(out, ref, what=want, label="case %d W%d N%d %s" % (case, W, N, "dense" if case % 2 == 0 else "ragged"))
