@@ -176,10 +176,17 @@ __device__ __forceinline__ double dpp_clone_shr4(double v) {
     const int nhi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0x5, 0x2, false);
     return __hiloint2double(nhi, nlo);
 }
+// Maximum over the wavefront, wave-uniform result.  DPP reduction (row_shr 1/2/4/8 -> lane 15 of each row holds the row
+// maximum; row_bcast:15 / row_bcast:31 carry it across rows; lane 63 holds the total) instead of six dependent
+// ds_bpermute round trips: it sits on the critical path of every wavefront's start-up.
 __device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 struct PreArgs {
@@ -265,6 +272,9 @@ __global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_
     int tofs[SEGD];
     const double *blk0 = A.knots + (long long)blockIdx.x * WPB * (long long)(A.N + 1) * 7;   // wave-uniform
     {
+        // (Issuing all SEGD descriptor reads before using the first -- one LDS round trip instead of SEGD dependent ones,
+        // which hipcc keeps in program order with an s_waitcnt after each -- was measured: 12.55 vs 12.33 us per launch
+        // at 10 k windows, i.e. slower; the wavefronts wait for the first HBM burst either way and start less staggered.)
         int seg = lane / SEGD, off = lane - seg * SEGD;
 #pragma unroll
         for (int e = 0; e < SEGD; ++e) {
