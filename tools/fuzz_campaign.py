@@ -1,0 +1,107 @@
+"""Randomised parity campaign on the GPU (development tool, not part of the test-suite): random shapes, layouts,
+models (1, 2, Forster comparator), flags, lane splits and output subsets against the CPU oracle; then random factor
+sweeps (dense, packed, whitened) against the oracle.   python tools/fuzz_campaign.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import cpi_amd  # noqa: E402
+from cpi_amd import synth  # noqa: E402
+from oracle import oracle_py as op  # noqa: E402
+from tests.tol import check_pre  # noqa: E402
+
+
+def dev(a, eng):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+
+
+def host(out):
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    eng = cpi_amd.Engine(device=0)
+    lanes_all = [0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64]
+    wants = [("mean",), ("mean", "jac"), ("mean", "jac", "cov"), ("cov",), ("jac",), ("mean", "cov")]
+    fails = 0
+    for case in range(cases):
+        W = int(rng.integers(1, 700))
+        N = int(rng.integers(1, 130))
+        model = int(rng.integers(1, 4))
+        avg = int(rng.integers(0, 2)) if model < 3 else 0
+        stj = int(rng.integers(0, 2)) if model == 2 else 1
+        ragged = bool(rng.integers(0, 2))
+        lanes = int(rng.choice(lanes_all))
+        want = wants[int(rng.integers(0, len(wants)))]
+        label = "case %d W%d N%d m%d avg%d stj%d %s L%d %s" % (case, W, N, model, avg, stj, "ragged" if ragged else "dense", lanes, want)
+        oprm = op.make_params(model, avg, stj)
+        prm = eng.make_params(model, avg, stj, lanes_per_window=lanes)
+        try:
+            if not ragged:
+                kn, lin, q = synth.make_windows(W, N, seed=seed * 100000 + case)
+                kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
+                ref = op.oracle().run(oprm, kn, lin, q, nthreads=8)
+                out = host(eng.preintegrate(dev(kn, eng), dev(lin, eng), dev(q, eng), prm, want=want))
+            else:
+                lens = rng.integers(0, N + 1, W).astype(np.int32)
+                lens[rng.integers(0, W)] = N
+                K = int(lens.sum()) + 1
+                kn1, _, _ = synth.make_windows(1, max(K - 1, 1), seed=seed * 100000 + 50000 + case, edge_cases=False)
+                stream = kn1.numpy()[0][:K]
+                first = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+                _, lin, q = synth.make_windows(W, 4, seed=seed * 100000 + 70000 + case)
+                lin, q = lin.numpy(), q.numpy()
+                out = host(eng.preintegrate(dev(stream, eng), dev(lin, eng), dev(q, eng), prm, want=want,
+                                            first=dev(first, eng), count=dev(lens, eng), N=N))
+                ref = None
+                for w in range(W):
+                    n = int(lens[w])
+                    r = op.oracle().run(oprm, stream[first[w]:first[w] + n + 1][None], lin[w:w + 1], q[w:w + 1])
+                    if ref is None:
+                        ref = {k: np.zeros((W,) + v.shape[1:]) for k, v in r.items()}
+                    for k in ref:
+                        ref[k][w] = r[k][0]
+            check_pre(out, ref, what=want, v2=(model == 2), label=label)
+        except AssertionError as ex:
+            fails += 1
+            print("FAIL", label, ex, flush=True)
+    # factor sweeps
+    for case in range(max(4, cases // 10)):
+        F = int(rng.integers(1, 3000))
+        model = int(rng.integers(1, 3))
+        kn, lin, q = synth.make_windows(F, 20, seed=seed * 1000 + case, device=eng.device)
+        meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac", "cov"))
+        xi, xj = synth.make_states(meas["alpha"], meas["beta"], meas["q"], meas["DT"], lin, model, device=eng.device,
+                                   seed=seed * 31 + case)
+        states = torch.cat([xi, xj], 0).contiguous()
+        ii = torch.arange(F, dtype=torch.int32, device=eng.device)
+        qq = q if model == 2 else None
+        dense = eng.factor_eval(model, meas, lin, qq, states, ii, ii + F)
+        packed = eng.factor_eval_packed(model, meas, lin, qq, states, ii, ii + F)
+        torch.cuda.synchronize()
+        m = {k: v.cpu().numpy() for k, v in meas.items()}
+        rec = op.factor_records(m, lin.cpu().numpy(), q.cpu().numpy() if model == 2 else None)
+        st = states.cpu().numpy()
+        err, H1, H2 = op.oracle().factor(model, rec, st[:F], st[F:])
+        ok = all(np.abs(g.cpu().numpy() - w).max() <= 1e-9 * max(1.0, np.abs(w).max())
+                 for g, w in ((dense["err"], err), (dense["H1"], H1), (dense["H2"], H2)))
+        e2, H12, H22 = cpi_amd.unpack_factor(packed, meas)
+        ok = ok and torch.equal(e2, dense["err"]) and (H12 - dense["H1"]).abs().max().item() == 0.0 \
+            and (H22 - dense["H2"]).abs().max().item() == 0.0
+        if not ok:
+            fails += 1
+            print("FAIL factor case", case, F, model, flush=True)
+    print("campaign seed %d: %d preintegration cases, %d failures" % (seed, cases, fails), flush=True)
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
