@@ -211,7 +211,7 @@ struct PreArgs {
 #define CPI_MEAN_WPS 1
 #endif
 template <int MODEL, bool JAC, bool AVG, int L>
-__global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
+__global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) && L == 1 ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
     constexpr int WPB = 64 / L;       // windows per wavefront
     // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has several intervals (L <= 8; 20 k x 50 with
     // L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us, 15 k with L = 4: 16.0 -> 15.3 us, 10 k with L = 6:
@@ -260,6 +260,36 @@ __global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_
     if (GSEG) grav_init(ga);
     __syncthreads();
 
+    // Analytic-Jacobian variant of model 1, one lane per window (large batches): the recursion is bound by registers
+    // (61 doubles of state + the per-interval 3x3 temporaries), not by HBM, so it streams its knots straight into
+    // registers, one interval ahead, instead of through the coalescing LDS stage -- that frees the stage's address /
+    // staging registers and lets two wavefronts share a SIMD (256 registers + 36 B of scratch each).  Measured inside
+    // "V1 full" (covariance kernel + this one): 1.405 -> 1.376 ms per 100 k windows, 13.25 -> 13.10 ms per 1 M.  With
+    // several lanes per window (small, latency-bound batches) it loses (10 k windows: 192 -> 205 us), so those keep the stage.
+    constexpr bool DIRECT = JAC && (MODEL == 1) && (L == 1);
+    if constexpr (DIRECT) {
+        const double *kp = A.knots + (k0 + s0) * 7;
+        double nx[7];
+        {
+            const double *kb = kp + 7 * min(1, len);
+#pragma unroll
+            for (int i = 0; i < 7; i++) nx[i] = kb[i];
+        }
+        for (int sidx = 0; sidx < maxlen; ++sidx) {
+            double q[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) q[i] = nx[i];
+            {
+                const double *kb = kp + 7 * min(sidx + 2, len);   // knot s0 + len is the window segment's last: always valid
+#pragma unroll
+                for (int i = 0; i < 7; i++) nx[i] = kb[i];
+            }
+            mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                       mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, sidx < len);
+#pragma unroll
+            for (int i = 0; i < 7; i++) pk[i] = q[i];
+        }
+    } else {
     // Tile element idx = e*64 + lane belongs to segment idx / SEGD at offset idx % SEGD, so consecutive
     // lanes read consecutive doubles of (mostly) one segment: coalesced.  Everything that does not depend
     // on the chunk index is hoisted: per staged element a lane keeps one pointer and the last chunk for
@@ -346,6 +376,8 @@ __global__ __launch_bounds__(64, ((MODEL == 2 && !JAC && L == 1) ? 2 : CPI_MEAN_
         }
         __syncthreads();
     }
+
+    }   // !DIRECT
 
     // order-preserving composition tree over the L lanes of a window (earlier = lower lane)
 #pragma unroll
