@@ -166,7 +166,7 @@ def time_steps(wl, steps, warmup, dist_on=False):
 def usable_cpus():
     """Threads worth starting: the affinity mask capped by the cgroup CPU quota.  (The GPU boxes of this pool show 256
     logical CPUs but run the container under cpu.max = 16 CPUs; with 256 threads the same code is 2x SLOWER than with
-    16 -- measured with tools/cpu_scale.py: 42 k windows/s at 16 threads, 20 k at 256.)"""
+    16 -- measured with tests/tools/cpu_scale.py: 42 k windows/s at 16 threads, 20 k at 256.)"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:

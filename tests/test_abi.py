@@ -48,10 +48,11 @@ def test_no_cpu_fallback():
 
 
 def test_product_never_imports_oracle():
-    """The product package must not reference the oracle (test infrastructure)."""
-    pkg = os.path.join(ROOT, "cpi_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
-                txt = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "oracle_py" not in txt and "liboracle" not in txt and "cpi_oracle" not in txt, f
+    """Neither the product package nor its development tools nor the C-ABI header may reference the oracle (test
+    infrastructure): only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do."""
+    for top in ("cpi_amd", "tools", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".hip", ".hpp", ".h", ".cpp")):
+                    txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "oracle_py" not in txt and "liboracle" not in txt and "cpi_oracle" not in txt, f

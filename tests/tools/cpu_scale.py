@@ -1,12 +1,12 @@
 """CPU baseline thread scaling (development tool): the compiled reference (oracle/_ref) and the C restatement on
-W windows x 50 samples with 1..256 threads, output buffer reused.   python tools/cpu_scale.py [W]"""
+W windows x 50 samples with 1..256 threads, output buffer reused.   python tests/tools/cpu_scale.py [W]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cpi_amd import synth  # noqa: E402
 from oracle import oracle_py as op  # noqa: E402
 

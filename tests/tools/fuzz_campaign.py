@@ -1,13 +1,13 @@
-"""Randomised parity campaign on the GPU (development tool, not part of the test-suite): random shapes, layouts,
+"""Randomised parity campaign on the GPU (test infrastructure -- it uses the oracle, so it lives under tests/; not collected by pytest): random shapes, layouts,
 models (1, 2, Forster comparator), flags, lane splits and output subsets against the CPU oracle; then random factor
-sweeps (dense, packed, whitened) against the oracle.   python tools/fuzz_campaign.py [cases] [seed]"""
+sweeps (dense, packed, whitened) against the oracle.   python tests/tools/fuzz_campaign.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import cpi_amd  # noqa: E402
 from cpi_amd import synth  # noqa: E402
