@@ -263,6 +263,15 @@ def main():
     eng = cpi_amd.Engine(device=local_rank)
     W = a.windows or default_size(a.workload)
     wl = Workload(eng, a.workload, W, a.samples, seed=20190101 + 7919 * rank, lanes=a.lanes)
+    # Untimed clock pre-ramp, separate from the W warm-up steps: an idle MI355X needs tens of milliseconds of load to reach
+    # its steady shader clock, so a short (K, W) would otherwise time the ramp (K = 20: 14.9 us per launch instead of
+    # 12.0).  Reported in config.clock_preramp_ms; the W warm-up steps and the K timed steps follow unchanged.
+    PRERAMP_MS = 60.0
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < PRERAMP_MS:
+        for _ in range(50):
+            wl.step()
+        torch.cuda.synchronize()
     wall, kern_ms = time_steps(wl, a.steps, a.warmup, dist_on)
     if dist_on:
         import torch.distributed as dist
@@ -283,7 +292,7 @@ def main():
         "config": {"workload": "%s: %d %s x %d samples per GPU per step%s" % (
             a.workload, W, "factors" if is_factor else "windows", a.samples,
             ", CPI model 1, mean-only (BASELINE.json configs[1])" if a.workload == "v1_mean" and W == 10000 else ""),
-            "pool_batches": wl.nbatch, "parallelism": "windows sharded over %d GPU(s), final all_gather" % world},
+            "pool_batches": wl.nbatch, "clock_preramp_ms": PRERAMP_MS, "parallelism": "windows sharded over %d GPU(s), final all_gather" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a.workload, W, a.samples),
                      "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_pmc_counters.md)",
