@@ -116,7 +116,8 @@ class Workload:
         batch_bytes = W * (N + 1) * 56
         self.nbatch = max(1, min(64, -(-pool_bytes // batch_bytes)))
         self.batches = [synth.make_windows(W, N, seed=seed + 101 * b, device=dev) for b in range(self.nbatch)]
-        self.outs = [eng.alloc_outputs(W, want, model) for _ in range(min(self.nbatch, 4))]
+        # one flat buffer per output set: a rank's outputs are one contiguous slab, so the multi-GPU gather is ONE collective
+        self.outs = [eng.alloc_outputs(W, want, model, packed=True) for _ in range(min(self.nbatch, 4))]
         self.i = 0
 
     def step(self):
@@ -133,12 +134,26 @@ class Workload:
         return out
 
 
+def final_gather(out, W_local):
+    """All ranks' outputs of the last step on every rank: one all_gather of the packed per-rank slabs when the outputs
+    are views of one flat buffer (preintegration workloads), else one all_gather per field."""
+    import torch.distributed as dist
+    from cpi_amd.dist import gather_outputs, gather_packed
+    if "_flat" in out:
+        return gather_packed(out["_flat"], out["_fields"], W_local)
+    return gather_outputs({k: v for k, v in out.items() if not k.startswith("_")}, W_local * dist.get_world_size())
+
+
 def time_steps(wl, steps, warmup, dist_on=False):
     import torch.distributed as dist
+    out = None
     for _ in range(warmup):
-        wl.step()
+        out = wl.step()
     torch.cuda.synchronize()
     if dist_on:
+        if out is not None:
+            final_gather(out, wl.W)              # untimed: first use of the collective (RCCL channel set-up, buffers)
+            torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -150,9 +165,7 @@ def time_steps(wl, steps, warmup, dist_on=False):
     e1.record()                                  # HIP events on the launch stream: kernel time only
     gathered = None
     if dist_on:                                  # the one exchange step: final gather of the output slabs
-        from cpi_amd.dist import gather_outputs
-        world = dist.get_world_size()
-        gathered = gather_outputs({k: v for k, v in out.items()}, wl.W * world)
+        gathered = final_gather(out, wl.W)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()

@@ -41,3 +41,27 @@ def gather_outputs(local, W_total, group=None, dst=None):
             dist.gather(pad, parts, dst=dst, group=group)
             out[name] = torch.cat(parts, dim=0)[:W_total] if rank == dst else None
     return out
+
+
+def pack_layout(fields, W):
+    """Field-major layout of one rank's outputs inside ONE flat buffer: [name -> (offset, n)] in doubles, total size.
+    fields = [(name, n)], every field [W, n] (n = 1 for [W])."""
+    lay, off = {}, 0
+    for name, n in fields:
+        lay[name] = (off, n)
+        off += n * W
+    return lay, off
+
+
+def gather_packed(flat, fields, W_local, group=None):
+    """The final gather as ONE collective: every rank's outputs live in one flat buffer (pack_layout; the engine can
+    write into views of it directly, Engine.alloc_outputs(..., packed=True)), so the exchange step is a single
+    all_gather_into_tensor of equal slabs instead of one per field -- with small batches the per-collective launch
+    cost is what the gather costs.  Returns name -> tensor [world, W_local, n] (views of the gathered buffer; rank r's
+    block is [r]).  Equal W_local on all ranks (weak scaling / padded blocks)."""
+    world = dist.get_world_size(group)
+    lay, total = pack_layout(fields, W_local)
+    assert flat.numel() == total and flat.is_contiguous()
+    full = torch.empty((world, total), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(full.view(-1), flat, group=group)
+    return {name: full[:, off:off + n * W_local].view(world, W_local, n) for name, (off, n) in lay.items()}

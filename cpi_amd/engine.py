@@ -73,14 +73,30 @@ class Engine:
         p.lanes_per_window = int(lanes_per_window)
         return p
 
-    def alloc_outputs(self, W, want=("mean", "jac", "cov"), model=1):
-        out = {}
+    def alloc_outputs(self, W, want=("mean", "jac", "cov"), model=1, packed=False):
+        """packed=True: all fields are views of ONE flat buffer (field-major, cpi_amd.dist.pack_layout), returned under
+        the extra key "_flat" together with "_fields" -- a rank's whole output is then one contiguous slab and the
+        multi-GPU gather one collective (cpi_amd.dist.gather_packed)."""
+        names = []
         for name, n in OUT_FIELDS:
             grp = "mean" if name in MEAN_FIELDS else ("cov" if name == "P" else "jac")
             if grp not in want:
                 continue
             if model != 2 and name in ("O_a", "O_b"):
                 continue
+            names.append((name, n))
+        out = {}
+        if packed:
+            from .dist import pack_layout
+            lay, total = pack_layout(names, W)
+            flat = torch.empty((total,), dtype=torch.float64, device=self.device)
+            for name, n in names:
+                off = lay[name][0]
+                v = flat[off:off + n * W]
+                out[name] = v if n == 1 else v.view(W, n)
+            out["_flat"], out["_fields"] = flat, names
+            return out
+        for name, n in names:
             shape = (W,) if n == 1 else (W, n)
             out[name] = torch.empty(shape, dtype=torch.float64, device=self.device)
         return out

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cpi_amd.dist import gather_outputs, shard_bounds
+from cpi_amd.dist import gather_outputs, gather_packed, pack_layout, shard_bounds
 
 
 def test_shard_bounds_cover_exactly():
@@ -40,6 +40,19 @@ def _worker(rank, world, port, W, q):
             ok = ok and torch.equal(root["alpha"][:, 1], 2 * g)
         else:
             ok = ok and root["alpha"] is None
+        # the one-collective flavour: the rank's outputs are views of one flat buffer
+        Wl = 37
+        fields = [("DT", 1), ("alpha", 3), ("q", 4)]
+        lay, total = pack_layout(fields, Wl)
+        flat = torch.zeros(total, dtype=torch.float64)
+        gi = torch.arange(rank * Wl, (rank + 1) * Wl, dtype=torch.float64)
+        flat[lay["DT"][0]:lay["DT"][0] + Wl] = gi
+        flat[lay["alpha"][0]:lay["alpha"][0] + 3 * Wl].view(Wl, 3)[:] = gi[:, None] * torch.tensor([1.0, 2.0, 3.0])
+        flat[lay["q"][0]:lay["q"][0] + 4 * Wl].view(Wl, 4)[:] = gi[:, None] + torch.arange(4.0)
+        gp = gather_packed(flat, fields, Wl)
+        gg = torch.arange(world * Wl, dtype=torch.float64)
+        ok = ok and torch.equal(gp["DT"].reshape(-1), gg) and torch.equal(gp["alpha"].reshape(-1, 3)[:, 2], 3 * gg) \
+            and torch.equal(gp["q"].reshape(-1, 4)[:, 3], gg + 3)
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
