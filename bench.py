@@ -234,29 +234,30 @@ def cpu_baseline(wl, min_seconds=8.0):
 
 def overlapped_rate(W, N, nctx, steps):
     """Whole-job rate when independent batches are issued round-robin through nctx engine contexts (one HIP stream
-    each), so that consecutive launches overlap.  Reported as an `extra` row only: with overlapping launches the
-    duration of one launch is no longer the inverse of the throughput, which is what the roofline line is defined on."""
+    each, cpi_amd.EnginePool), so that consecutive launches overlap.  Reported as an `extra` row only: with overlapping
+    launches the duration of one launch is no longer the inverse of the throughput, which is what the roofline line
+    is defined on."""
     import cpi_amd
     from cpi_amd import synth
     dev = torch.device("cuda", torch.cuda.current_device())
-    engs = [cpi_amd.Engine(device=dev.index, stream=torch.cuda.Stream(device=dev)) for _ in range(nctx)]
+    pool = cpi_amd.EnginePool(nctx, device=dev)
     nb = max(nctx, -(-(MALL_BYTES * 5 // 4) // (W * (N + 1) * 56)))
     batches = [synth.make_windows(W, N, seed=977 + b, device=dev) for b in range(nb)]
-    outs = [engs[0].alloc_outputs(W, ("mean",), 1) for _ in range(2 * nctx)]
-    prm = engs[0].make_params(1)
+    outs = [pool.engines[0].alloc_outputs(W, ("mean",), 1) for _ in range(2 * nctx)]
+    prm = pool.engines[0].make_params(1)
 
     def go(k):
         for i in range(k):
             kn, lin, q = batches[i % nb]
-            engs[i % nctx].preintegrate(kn, lin, q, prm, want=("mean",), out=outs[i % len(outs)])
+            pool.engines[i % nctx].preintegrate(kn, lin, q, prm, want=("mean",), out=outs[i % len(outs)])
+    torch.cuda.synchronize()
     go(max(50, steps // 10))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     go(steps)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    for e in engs:
-        e.close()
+    pool.close()
     return wall / steps
 
 

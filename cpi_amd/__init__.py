@@ -11,4 +11,7 @@ def __getattr__(name):  # lazy: importing the package must not need torch / a GP
     if name in ("Engine", "CpiV1", "CpiV2", "ForsterDiscrete", "ImuFactorCPIv1", "ImuFactorCPIv2", "default_engine", "unpack_factor"):
         from . import engine
         return getattr(engine, name)
+    if name == "EnginePool":
+        from .pool import EnginePool
+        return EnginePool
     raise AttributeError(name)
