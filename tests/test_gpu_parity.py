@@ -584,3 +584,32 @@ def test_engine_pool_overlapping_contexts_give_the_same_results(eng):
             assert torch.equal(got[k], ref[k]), (b, k)
     pool.synchronize()
     pool.close()
+
+
+@pytest.mark.parametrize("model", [1, 2, 3])
+def test_maximum_window_length(eng, orc, model):
+    """N = 65535 intervals per window is the documented maximum (16-bit segment lengths in the mean kernel): three
+    such windows, mean-only with one and with 64 lanes per window, and the full recursion; N = 65536 is refused."""
+    import cpi_amd
+    N = 65535
+    kn, lin, q = synth.make_windows(3, N, seed=99, edge_cases=False)
+    kn = kn.clone()
+    kn[:, :, 1:4] *= 0.05                      # keep the 5-minute windows' rotation and drift moderate
+    knn, linn, qn = kn.numpy(), lin.numpy(), q.numpy()
+    oprm = orc.make_params(model, 0, 1)
+    ref = orc.oracle().run(oprm, knn, linn, qn, nthreads=3)
+    # means grow with a t^2 / 2 over 328 s: gate relative to the magnitude, as the stress test does
+    def close(out, what):
+        for k in what:
+            scale = max(1.0, float(np.abs(ref[k]).max()))
+            assert np.abs(out[k] - ref[k]).max() <= 1e-9 * scale, (model, k, np.abs(out[k] - ref[k]).max(), scale)
+    for lanes in ((1, 64) if model < 3 else (0,)):
+        prm = eng.make_params(model, lanes_per_window=lanes)
+        out = _host(eng.preintegrate(kn.to(eng.device), lin.to(eng.device), q.to(eng.device), prm, want=("mean",)))
+        close(out, ("DT", "alpha", "beta", "q"))
+    out = _host(eng.preintegrate(kn.to(eng.device), lin.to(eng.device), q.to(eng.device), eng.make_params(model)))
+    close(out, ("DT", "alpha", "beta", "q"))
+    assert cov_rel_err(out["P"], ref["P"]) <= TOL_COV
+    big = torch.zeros((1, 65537, 7), dtype=torch.float64, device=eng.device)
+    with pytest.raises(cpi_amd.CpiError):
+        eng.preintegrate(big, lin[:1].to(eng.device), q[:1].to(eng.device), eng.make_params(1), want=("mean",))
