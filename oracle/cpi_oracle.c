@@ -529,6 +529,22 @@ static void state_export(const cpi_state *s, cpi_oracle_out *o) {
 
 void cpi_oracle_rot_2_quat_rm(const double *rot_rowmajor, double *q) { rot_2_quat(rot_rowmajor, q); }
 
+/* Test hook: the restated quat_ops.h helpers, same interface as cpi_ref_quat_ops (ref_shim.cpp); matrices ROW-major. */
+int cpi_oracle_quat_ops(int op, long n, const double *in, double *out) {
+    for (long k = 0; k < n; k++) {
+        switch (op) {
+            case 0: rot_2_quat(in + 9 * k, out + 4 * k); break;
+            case 1: skew_x(in + 3 * k, out + 9 * k); break;
+            case 2: quat_2_Rot(in + 4 * k, out + 9 * k); break;
+            case 3: quat_multiply(in + 8 * k, in + 8 * k + 4, out + 4 * k); break;
+            case 4: Exp_so3(in + 3 * k, out + 9 * k); break;
+            case 5: quat_inv(in + 4 * k, out + 4 * k); break;
+            default: return 1;
+        }
+    }
+    return 0;
+}
+
 static void run_window(const cpi_oracle_params *prm, int n, const double *knots, const double *lin,
                        const double *q_k_lin, cpi_oracle_out *out, cpi_oracle_out *trace) {
     if (prm->model == 3) {   /* Forster comparator (forster_oracle.c); trace = the prefix windows */

@@ -105,6 +105,12 @@ void cpi_oracle_navstate_retract(const double *state15, const double *xi9, doubl
 void cpi_oracle_navstate_update(const double *state15, const double *acc, const double *om, double dt,
                                 double *out15, double *A81, double *B27, double *C27);
 
+/* The restated quat_ops.h helpers (quat_ops.h:45-197), one call per item; matrices ROW-major at this interface.
+ *   op 0 rot_2_quat in 9 -> out 4 | 1 skew_x in 3 -> out 9 | 2 quat_2_Rot in 4 -> out 9 | 3 quat_multiply in 4+4 -> out 4
+ *   op 4 Exp in 3 -> out 9 | 5 Inv in 4 -> out 4.      PINNED: equal to the reference's own functions (compiled into
+ * oracle/_ref by ref_shim.cpp: cpi_ref_quat_ops) on tests/golden/quat_ops.npz.  Returns 0, or 1 for an unknown op. */
+int cpi_oracle_quat_ops(int op, long n, const double *in, double *out);
+
 /* JPLNavState::retract (JPLNavState.cpp:37-71) and localCoordinates (:80-88). */
 void cpi_oracle_retract(const double *x, const double *xi15, double *xout);
 void cpi_oracle_local(const double *x, const double *other, double *xi15);

@@ -9,7 +9,11 @@
  * The output lives in oracle/_ref/ (git-ignored, never committed).
  *
  * The factors (ImuFactorCPIv1/v2.cpp) need GTSAM + Boost, absent from this image, and are NOT
- * built here: no stand-in headers are written for them (their parity stays unpinned).
+ * built here: no stand-in headers are written for them.  What CAN be pinned of evaluateError / predict / retract
+ * is: every non-trivial primitive those bodies call lives in utils/quat_ops.h (rot_2_quat :45, skew_x :92,
+ * quat_2_Rot :104, quat_multiply :115, Exp :145, Inv :190), header-only on the vendored Eigen -- cpi_ref_quat_ops()
+ * below exposes the reference's OWN functions so that the restatement's helpers and the device helpers are checked
+ * against them (tests/golden/quat_ops.npz, tests/test_quat_ops.py, tests/test_gpu_quat_ops.py).
  */
 #include "cpi/CpiV1.h"
 #include "cpi/CpiV2.h"
@@ -90,4 +94,47 @@ extern "C" void cpi_ref_batch_mt(const cpi_oracle_params *prm, long W, int n, co
         });
     }
     for (auto &t : th) t.join();
+}
+
+/* The reference's own quat_ops.h helpers, one call per item.  Matrices cross this interface ROW-major.
+ *   op 0 rot_2_quat    in 9  -> out 4      op 1 skew_x         in 3 -> out 9      op 2 quat_2_Rot  in 4 -> out 9
+ *   op 3 quat_multiply in 4+4 -> out 4     op 4 Exp            in 3 -> out 9      op 5 Inv         in 4 -> out 4 */
+extern "C" int cpi_ref_quat_ops(int op, long n, const double *in, double *out) {
+    typedef Eigen::Matrix<double, 3, 3, Eigen::RowMajor> M3r;
+    for (long k = 0; k < n; k++) {
+        switch (op) {
+            case 0: {
+                Eigen::MatrixXd R = Eigen::Map<const M3r>(in + 9 * k);
+                V4 q = rot_2_quat(R);
+                for (int i = 0; i < 4; i++) out[4 * k + i] = q(i);
+            } break;
+            case 1: {
+                Eigen::MatrixXd S = skew_x(V3(in[3 * k], in[3 * k + 1], in[3 * k + 2]));
+                Eigen::Map<M3r>(out + 9 * k) = S;
+            } break;
+            case 2: {
+                V4 q; q << in[4 * k], in[4 * k + 1], in[4 * k + 2], in[4 * k + 3];
+                Eigen::MatrixXd R = quat_2_Rot(q);
+                Eigen::Map<M3r>(out + 9 * k) = R;
+            } break;
+            case 3: {
+                V4 q, p;
+                q << in[8 * k], in[8 * k + 1], in[8 * k + 2], in[8 * k + 3];
+                p << in[8 * k + 4], in[8 * k + 5], in[8 * k + 6], in[8 * k + 7];
+                V4 r = quat_multiply(q, p);
+                for (int i = 0; i < 4; i++) out[4 * k + i] = r(i);
+            } break;
+            case 4: {
+                Eigen::Matrix<double, 3, 3> R = Exp(V3(in[3 * k], in[3 * k + 1], in[3 * k + 2]));
+                Eigen::Map<M3r>(out + 9 * k) = R;
+            } break;
+            case 5: {
+                V4 q; q << in[4 * k], in[4 * k + 1], in[4 * k + 2], in[4 * k + 3];
+                V4 r = Inv(q);
+                for (int i = 0; i < 4; i++) out[4 * k + i] = r(i);
+            } break;
+            default: return 1;
+        }
+    }
+    return 0;
 }

@@ -289,3 +289,23 @@ extern "C" void hs_predict(int model, long F, const double *rec, const double *x
 extern "C" void hs_forster(long W, int n, const double *kn, const double *lin, const double *sig, double *out) {
     for (long w = 0; w < W; w++) forster_window(n, kn + (size_t)w * (n + 1) * 7, lin + w * 6, sig, out + w * OUTD);
 }
+
+// The SO(3) / quaternion helpers of cpi_math.hpp by themselves (same interface as cpi_test_quat_ops / cpi_ref_quat_ops;
+// matrices row-major): host emulation of the kernel helpers' LOGIC -- the device instruction sequences (v_rsq_f64 +
+// Newton, single-FMA Horner steps) are exercised by tests/test_gpu_quat_ops.py through the real library.
+extern "C" int hs_quat_ops(int op, long n, const double *in, double *out) {
+    auto put_rm = [](double *o, const M3 &A) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) o[i * 3 + j] = A.m[i][j]; };
+    auto put_q = [](double *o, Q4 q) { o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; };
+    for (long k = 0; k < n; k++) {
+        switch (op) {
+            case 0: put_q(out + 4 * k, rot_2_quat(rec_mat(in + 9 * k, 0))); break;
+            case 1: put_rm(out + 9 * k, skew(ld3(in + 3 * k))); break;
+            case 2: put_rm(out + 9 * k, quat_2_Rot(ldq(in + 4 * k))); break;
+            case 3: put_q(out + 4 * k, quat_multiply(ldq(in + 8 * k), ldq(in + 8 * k + 4))); break;
+            case 4: put_rm(out + 9 * k, Exp_so3(ld3(in + 3 * k))); break;
+            case 5: put_q(out + 4 * k, quat_inv(ldq(in + 4 * k))); break;
+            default: return 1;
+        }
+    }
+    return 0;
+}
