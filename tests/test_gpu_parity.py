@@ -2,8 +2,11 @@
   (1) the golden vectors the compiled reference produced (tests/golden/),
   (2) the CPU oracle on fresh seeded inputs at sizes it finishes in seconds,
   (3) size-independent properties at BASELINE.json's full sizes.
-Gates (tests/tol.py): 1e-9 on DT/alpha/beta/q, 1e-6 * sqrt(P_ii P_jj) on the covariance,
-1e-8 on the bias Jacobians, 1e-9 on evaluateError."""
+Contractual gates (tests/tol.py): 1e-9 on DT/alpha/beta/q, 1e-6 * sqrt(P_ii P_jj) on the covariance,
+1e-8 on the bias Jacobians, 1e-9 on evaluateError.  Wherever the expected values come from the COMPILED REFERENCE
+(golden fixtures; oracle/_ref/libcpi_ref.so, which travels to the GPU box) on realistic inputs, the regression gates
+apply instead: 100 x the measured floor (2e-13 / 2e-13 relative / 3e-11).  Seeded tests compare with the compiled
+reference directly when it is present (_cpu below) and fall back to the pinned restatement otherwise."""
 import os
 
 import numpy as np
@@ -11,7 +14,7 @@ import pytest
 import torch
 
 from cpi_amd import synth
-from tests.tol import TOL_COV, TOL_FACTOR, TOL_MEAN, check_pre, cov_rel_err
+from tests.tol import REG_FACTOR, TOL_COV, TOL_FACTOR, TOL_MEAN, check_pre, cov_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +43,20 @@ def _host(out):
     return {k: v.cpu().numpy() for k, v in out.items()}
 
 
+def _cpu(orc, mode, kn, lin, q, nthreads=None):
+    """CPU expectation for seeded inputs: the reference's own CpiV1 / CpiV2 (oracle/_ref) when present, else the
+    restatement (pinned to it).  Returns (outputs, from_reference)."""
+    ref = orc.reference()
+    lib = ref if ref is not None else orc.oracle()
+    return lib.run(orc.make_params(*mode), kn, lin, q, nthreads=nthreads or min(16, os.cpu_count() or 1)), ref is not None
+
+
+def _cpu_lib(orc):
+    """The compiled reference when present, else the restatement (same run() interface, models 1 and 2)."""
+    ref = orc.reference()
+    return ref if ref is not None else orc.oracle()
+
+
 def _mode_out(d, m):
     key = "m%d_avg%d_stj%d__" % m
     return {k[len(key):]: v for k, v in d.items() if k.startswith(key)}
@@ -56,7 +73,7 @@ def _run(eng, m, kn, lin, q, want=("mean", "jac", "cov"), lanes=0, **kw):
 def test_full_outputs_vs_reference_golden(eng, golden_dir, fname, mode):
     d = dict(np.load(os.path.join(golden_dir, fname)))
     out = _run(eng, mode, d["knots"], d["lin"], d["q_k_lin"])
-    check_pre(out, _mode_out(d, mode), v2=(mode[0] == 2), label="%s %s" % (fname, mode))
+    check_pre(out, _mode_out(d, mode), v2=(mode[0] == 2), label="%s %s" % (fname, mode), regression=True)
 
 
 @pytest.mark.parametrize("lanes", [0, 1, 2, 3, 5, 6, 8, 12, 16, 64])
@@ -66,7 +83,7 @@ def test_model2_mean_only_segment_form_vs_reference_golden(eng, golden_dir, lane
     response matrices and are composed afterwards (cpi_math.hpp: mean_step_v2seg / grav_combine / grav_apply)."""
     d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
     out = _run(eng, (2, avg, 1), d["knots"], d["lin"], d["q_k_lin"], want=("mean",), lanes=lanes)
-    check_pre(out, _mode_out(d, (2, avg, 1)), what=("mean",))
+    check_pre(out, _mode_out(d, (2, avg, 1)), what=("mean",), regression=True)
 
 
 @pytest.mark.parametrize("lanes", [0, 1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64])
@@ -75,9 +92,9 @@ def test_mean_only_vs_reference_golden_all_lane_splits(eng, golden_dir, lanes, a
     d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
     out = _run(eng, (1, avg, 1), d["knots"], d["lin"], d["q_k_lin"], want=("mean",), lanes=lanes)
     assert set(out) == {"DT", "alpha", "beta", "q"}
-    check_pre(out, _mode_out(d, (1, avg, 1)), what=("mean",))
+    check_pre(out, _mode_out(d, (1, avg, 1)), what=("mean",), regression=True)
     out = _run(eng, (1, avg, 1), d["knots"], d["lin"], d["q_k_lin"], want=("mean", "jac"), lanes=lanes)
-    check_pre(out, _mode_out(d, (1, avg, 1)), what=("mean", "jac"))
+    check_pre(out, _mode_out(d, (1, avg, 1)), what=("mean", "jac"), regression=True)
 
 
 def test_mean_only_model2_vs_golden(eng, golden_dir):
@@ -104,17 +121,17 @@ def test_vs_oracle_seeded(eng, orc, mode):
     W = 1500 if mode[0] == 1 else 700
     kn, lin, q = synth.make_windows(W, 50, seed=777 + 10 * mode[0] + mode[1])
     kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
-    ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=os.cpu_count() or 1)
+    ref, from_ref = _cpu(orc, mode, kn, lin, q)
     out = _run(eng, mode, kn, lin, q)
-    check_pre(out, ref, v2=(mode[0] == 2), label=str(mode))
+    check_pre(out, ref, v2=(mode[0] == 2), label=str(mode), regression=from_ref)
 
 
 def test_window_of_100_samples(eng, orc):
     kn, lin, q = synth.make_windows(333, 100, seed=5)     # W not a multiple of any group size
     kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
     for mode in [(1, 0, 1), (2, 0, 1)]:
-        ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=os.cpu_count() or 1)
-        check_pre(_run(eng, mode, kn, lin, q), ref, v2=(mode[0] == 2))
+        ref, from_ref = _cpu(orc, mode, kn, lin, q)
+        check_pre(_run(eng, mode, kn, lin, q), ref, v2=(mode[0] == 2), regression=from_ref)
 
 
 # --------------------------------------------------------------------------- ragged / shared-knot windows
@@ -141,7 +158,7 @@ def test_ragged_windows_cut_from_one_stream(eng, orc):
         for w in range(W):
             n = int(lens[w])
             kn_w = stream[first[w]:first[w] + n + 1][None]
-            r = orc.oracle().run(oprm, kn_w, lin[w:w + 1], q[w:w + 1])
+            r = _cpu_lib(orc).run(oprm, kn_w, lin[w:w + 1], q[w:w + 1])
             for k in ref:
                 ref[k][w] = r[k][0]
         check_pre(out, ref, v2=(mode[0] == 2), label="ragged %s" % (mode,))
@@ -191,9 +208,9 @@ def test_factor_eval_vs_golden_and_oracle(eng, orc, golden_dir, model):
     out = eng.factor_eval(model, meas, _dev(lin, eng), _dev(cols["q_K_lin"], eng), _dev(states, eng), _dev(idx_i, eng),
                           _dev(idx_j, eng))
     out = _host(out)
-    assert np.abs(out["err"] - d["v%d_err" % model]).max() <= TOL_FACTOR
-    assert np.abs(out["H1"] - d["v%d_H1" % model]).max() <= TOL_FACTOR
-    assert np.abs(out["H2"] - d["v%d_H2" % model]).max() <= TOL_FACTOR
+    for k, key in (("err", "v%d_err"), ("H1", "v%d_H1"), ("H2", "v%d_H2")):
+        e = np.abs(out[k] - d[key % model]).max()
+        assert e <= TOL_FACTOR and e <= REG_FACTOR, (k, e)    # contractual gate, and "nothing moved"
     # error-only call (boost::optional none)
     o2 = _host(eng.factor_eval(model, meas, _dev(lin, eng), _dev(cols["q_K_lin"], eng), _dev(states, eng),
                                _dev(idx_i, eng), _dev(idx_j, eng), want_H=False))
@@ -409,7 +426,7 @@ def test_config5_one_gpu_share_1M_windows_x_100_samples(eng, orc):
         for k in ("DT", "alpha", "beta", "q"):
             assert (o[k] - out[k][sl]).abs().max().item() < 1e-11, (k, lo)
     pick = torch.arange(0, W, 9973, device=eng.device)
-    ref = orc.oracle().run(orc.make_params(1, 0, 1), kn[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
+    ref = _cpu_lib(orc).run(orc.make_params(1, 0, 1), kn[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
     check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, ref, what=("mean",), label="1M x 100 sample")
     again = eng.preintegrate(kn, lin, q, prm, want=("mean",))
     torch.cuda.synchronize()
@@ -425,11 +442,12 @@ def test_edge_sizes(eng, orc, W, N):
     kn, lin, q = synth.make_windows(W, N, seed=1000 + W + N)
     kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
     for mode in [(1, 0, 1), (2, 0, 1), (2, 1, 0)]:
-        ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=min(8, os.cpu_count() or 1))
-        check_pre(_run(eng, mode, kn, lin, q), ref, v2=(mode[0] == 2), label="W%d N%d %s" % (W, N, mode))
+        ref, from_ref = _cpu(orc, mode, kn, lin, q)
+        check_pre(_run(eng, mode, kn, lin, q), ref, v2=(mode[0] == 2), label="W%d N%d %s" % (W, N, mode), regression=from_ref)
     for lanes in (0, 1, 64):
         out = _run(eng, (1, 0, 1), kn, lin, q, want=("mean",), lanes=lanes)
-        check_pre(out, orc.oracle().run(orc.make_params(1, 0, 1), kn, lin, q), what=("mean",))
+        ref, from_ref = _cpu(orc, (1, 0, 1), kn, lin, q)
+        check_pre(out, ref, what=("mean",), regression=from_ref)
 
 
 def test_large_rotation_angles_take_the_reduced_sincos_path(eng, orc):
@@ -439,7 +457,7 @@ def test_large_rotation_angles_take_the_reduced_sincos_path(eng, orc):
     kn, lin, q = kn.numpy().copy(), lin.numpy(), q.numpy()
     kn[:, :, 1:4] *= np.linspace(5.0, 400.0, 96)[:, None, None]        # up to ~1000 rad/s
     for mode in [(1, 0, 1), (2, 0, 1)]:
-        ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=min(8, os.cpu_count() or 1))
+        ref, _ = _cpu(orc, mode, kn, lin, q)
         wdt = np.linalg.norm(kn[:, :-1, 1:4] - lin[:, None, 0:3], axis=2) * np.diff(kn[:, :, 0], axis=1)
         assert wdt.max() > 3.0 and (wdt > 1.0).mean() > 0.3
         out = _run(eng, mode, kn, lin, q)
@@ -512,7 +530,7 @@ def test_fuzz_random_shapes_layouts_and_lane_splits(eng, orc):
         if not ragged:
             kn, lin, q = synth.make_windows(W, N, seed=5000 + case)
             kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
-            ref = orc.oracle().run(oprm, kn, lin, q)
+            ref = _cpu_lib(orc).run(oprm, kn, lin, q)
             out = _host(eng.preintegrate(_dev(kn, eng), _dev(lin, eng), _dev(q, eng), prm, want=want))
         else:
             lens = rng.integers(0, N + 1, W).astype(np.int32)
@@ -528,7 +546,7 @@ def test_fuzz_random_shapes_layouts_and_lane_splits(eng, orc):
             ref = None
             for w in range(W):
                 n = int(lens[w])
-                r = orc.oracle().run(oprm, stream[first[w]:first[w] + n + 1][None], lin[w:w + 1], q[w:w + 1])
+                r = _cpu_lib(orc).run(oprm, stream[first[w]:first[w] + n + 1][None], lin[w:w + 1], q[w:w + 1])
                 if ref is None:
                     ref = {k: np.zeros((W,) + v.shape[1:]) for k, v in r.items()}
                 for k in ref:
@@ -554,7 +572,7 @@ def test_dynamic_range_stress(eng, orc, dt_scale, w_scale, a_scale):
     kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
     assert (np.abs(kn[:, :, 1:4]).max() * np.diff(kn[:, :, 0], axis=1).max()) < 1.3
     for mode in [(1, 0, 1), (2, 0, 1), (1, 1, 1)]:
-        ref = orc.oracle().run(orc.make_params(*mode), kn, lin, q, nthreads=os.cpu_count() or 1)
+        ref, _ = _cpu(orc, mode, kn, lin, q)
         out = _run(eng, mode, kn, lin, q)
         # means: relative to the magnitude of the quantity (alpha grows with a dt^2 N^2)
         for k in ("DT", "alpha", "beta", "q"):
@@ -597,7 +615,7 @@ def test_maximum_window_length(eng, orc, model):
     kn[:, :, 1:4] *= 0.05                      # keep the 5-minute windows' rotation and drift moderate
     knn, linn, qn = kn.numpy(), lin.numpy(), q.numpy()
     oprm = orc.make_params(model, 0, 1)
-    ref = orc.oracle().run(oprm, knn, linn, qn, nthreads=3)
+    ref = (orc.oracle() if model == 3 else _cpu_lib(orc)).run(oprm, knn, linn, qn, nthreads=3)
     # means grow with a t^2 / 2 over 328 s: gate relative to the magnitude, as the stress test does
     def close(out, what):
         for k in what:

@@ -76,3 +76,96 @@ def test_device_helpers_vs_live_reference_large_sample(eng):
         got = run_device(eng, name, x)
         err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
         assert err <= TOL_DEVICE, (name, err)
+
+
+# --------------------------------------------------------------------------- block assembly of evaluateError, on the device
+def _golden_factor_inputs(golden_dir, model, eng):
+    from oracle import oracle_py as op
+    d = dict(np.load(os.path.join(golden_dir, "factor_256.npz")))
+    rec, xi, xj = d["v%d_rec" % model], d["v%d_xi" % model], d["v%d_xj" % model]
+    cols, o = {}, 0
+    for name, n in op.FACTOR_FIELDS:
+        cols[name] = rec[:, o:o + n]; o += n
+    meas = dict(DT=cols["deltatime"][:, 0], alpha=cols["alpha"], beta=cols["beta"], q=cols["q_KtoK1"], J_q=cols["J_q"],
+                J_b=cols["J_beta"], J_a=cols["J_alpha"], H_b=cols["H_beta"], H_a=cols["H_alpha"], O_b=cols["O_beta"],
+                O_a=cols["O_alpha"])
+    lin = np.concatenate([cols["bg_lin"], cols["ba_lin"]], axis=1)
+    return rec, xi, xj, meas, lin, cols["q_K_lin"]
+
+
+def _dev(a, eng):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_device_jacobians_are_the_derivative_of_the_device_residual_under_retract(eng, golden_dir, model):
+    """H1 / H2 of the HIP evaluateError == central finite differences of the HIP residual along
+    JPLNavState::retract (JPLNavState.cpp:37-71: dq(theta) (x) q on the quaternion, additive on b_g, v, b_a, p), for all
+    15 + 15 tangent directions of 96 golden cases.  Together with the helper pins above this fixes the block layout,
+    signs and scalings of ImuFactorCPIv1.cpp:109-143,169-185 / ImuFactorCPIv2.cpp:73-119 on the device itself."""
+    from oracle import oracle_py as op
+    rec, xi, xj, meas, lin, qk = _golden_factor_inputs(golden_dir, model, eng)
+    K = 96
+    h = 1e-6
+    o = op.oracle()
+    # states: [0, K) = xi, [K, 2K) = xj, then for every (case, side, direction, sign) one perturbed state
+    pert = []
+    idx_i, idx_j, src = [], [], []
+    for k in range(K):
+        for side in (0, 1):
+            base = xi[k] if side == 0 else xj[k]
+            for c in range(15):
+                for sgn in (+1.0, -1.0):
+                    dx = np.zeros(15); dx[c] = sgn * h
+                    pert.append(o.retract(base, dx))
+                    pid = 2 * K + len(pert) - 1
+                    idx_i.append(pid if side == 0 else k)
+                    idx_j.append(pid if side == 1 else K + k)
+                    src.append(k)
+    states = np.concatenate([xi[:K], xj[:K], np.array(pert)], axis=0)
+    src = np.array(src)
+    m_rep = {kk: _dev(v[src], eng) for kk, v in meas.items()}
+    out = eng.factor_eval(model, m_rep, _dev(lin[src], eng), _dev(qk[src], eng), _dev(states, eng),
+                          _dev(np.array(idx_i, dtype=np.int32), eng), _dev(np.array(idx_j, dtype=np.int32), eng), want_H=False)
+    m0 = {kk: _dev(v[:K], eng) for kk, v in meas.items()}
+    ana = eng.factor_eval(model, m0, _dev(lin[:K], eng), _dev(qk[:K], eng), _dev(states, eng),
+                          _dev(np.arange(K, dtype=np.int32), eng), _dev((np.arange(K) + K).astype(np.int32), eng))
+    torch.cuda.synchronize()
+    e = out["err"].cpu().numpy().reshape(K, 2, 15, 2, 15)          # [case, side, direction, sign, residual row]
+    fd = (e[:, :, :, 0, :] - e[:, :, :, 1, :]) / (2 * h)            # [case, side, direction(col), row]
+    H1 = ana["H1"].cpu().numpy().reshape(K, 15, 15)                 # column-major flat -> [case, col, row]
+    H2 = ana["H2"].cpu().numpy().reshape(K, 15, 15)
+    w1 = np.abs(fd[:, 0] - H1).max()
+    w2 = np.abs(fd[:, 1] - H2).max()
+    print("device FD check model %d: H1 %.2e  H2 %.2e" % (model, w1, w2))
+    # measured 7e-8 / 3e-8 (central differences with h = 1e-6 on O(10) entries: truncation + cancellation noise)
+    assert w1 < 1e-6 and w2 < 1e-6, (w1, w2)
+    # and no structural zero is filled: blocks that ImuFactorCPIv1.cpp leaves zero are exactly zero on the device
+    Z1 = np.ones((15, 15), dtype=bool)
+    for (r, c) in ((0, 0), (0, 3), (3, 3), (6, 0), (6, 3), (6, 6), (6, 9), (9, 9), (12, 0), (12, 3), (12, 6), (12, 9), (12, 12)):
+        Z1[r:r + 3, c:c + 3] = False
+    assert np.all(H1.transpose(0, 2, 1)[:, Z1] == 0.0)
+    Z2 = np.ones((15, 15), dtype=bool)
+    for r in (0, 3, 6, 9, 12):
+        Z2[r:r + 3, r:r + 3] = False
+    assert np.all(H2.transpose(0, 2, 1)[:, Z2] == 0.0)
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_device_residual_vanishes_at_the_device_prediction(eng, golden_dir, model):
+    """cpi_predict_batch (GraphSolver_IMU.cpp:263-307) and cpi_factor_eval_batch are mutually consistent on the device:
+    with the biases on the linearisation point (and, model 2, q_GtoK on q_K_lin) the residual at the predicted state is 0."""
+    rec, xi, xj, meas, lin, qk = _golden_factor_inputs(golden_dir, model, eng)
+    xi = xi.copy()
+    xi[:, 4:7] = lin[:, 0:3]
+    xi[:, 10:13] = lin[:, 3:6]
+    if model == 2:
+        xi[:, 0:4] = qk
+    m = {kk: _dev(v, eng) for kk, v in meas.items()}
+    xjp = eng.predict(model, m, _dev(xi, eng))
+    states = torch.cat([_dev(xi, eng), xjp], dim=0).contiguous()
+    F = xi.shape[0]
+    out = eng.factor_eval(model, m, _dev(lin, eng), _dev(qk, eng), states, _dev(np.arange(F, dtype=np.int32), eng),
+                          _dev((np.arange(F) + F).astype(np.int32), eng), want_H=False)
+    torch.cuda.synchronize()
+    assert out["err"].abs().max().item() < 1e-12

@@ -6,6 +6,17 @@ TOL_COV = 1e-6       # |dP_ij| <= TOL_COV * sqrt(P_ii P_jj)
 TOL_JAC = 1e-8       # bias / orientation Jacobians: max-abs (our choice; north_star is silent)
 TOL_FACTOR = 1e-9    # evaluateError residual and H1/H2 : max-abs
 
+# Regression gates = 100 x the floor measured on MI355X against the COMPILED REFERENCE (means
+# 2e-15, covariance 2e-15 relative, Jacobians 3e-13 -- the last is the reference's own cancellation noise in f2 / df
+# just above its 0.008726646 rad/s threshold).  The contractual gates above say "parity"; these say "nothing moved":
+# a kernel change that shifts a result by 1e-10 passes the former and must not pass silently.  They apply wherever the
+# expected values come from the compiled reference (golden fixtures, oracle/_ref on the GPU box) on realistic inputs;
+# stress tests with scaled inputs keep the contractual gates relative to the magnitude of the quantity.
+REG_MEAN = 2e-13
+REG_COV = 2e-13
+REG_JAC = 3e-11
+REG_FACTOR = 1e-12   # evaluateError on the golden cases vs the restatement (measured floor 2e-14 on O(10) entries)
+
 
 def cov_rel_err(P, Pref):
     """max_ij |P-Pref|_ij / sqrt(Pref_ii Pref_jj) over a batch of column-major 15x15."""
@@ -21,20 +32,23 @@ def cov_rel_err(P, Pref):
     return float(rel.max())
 
 
-def check_pre(out, ref, what=("mean", "jac", "cov"), v2=False, label=""):
+def check_pre(out, ref, what=("mean", "jac", "cov"), v2=False, label="", regression=False):
+    """regression=True: the expected values come from the compiled reference on realistic inputs -- apply the
+    regression gates (100 x the measured floor) instead of the contractual ones."""
+    tol_mean, tol_jac, tol_cov = (REG_MEAN, REG_JAC, REG_COV) if regression else (TOL_MEAN, TOL_JAC, TOL_COV)
     msgs = []
     if "mean" in what:
         for k in ("DT", "alpha", "beta", "q"):
             e = float(np.abs(np.asarray(out[k]) - np.asarray(ref[k])).max())
-            if not e <= TOL_MEAN:
+            if not e <= tol_mean:
                 msgs.append("%s %s err %.3e" % (label, k, e))
     if "jac" in what:
         for k in ("J_q", "J_a", "J_b", "H_a", "H_b") + (("O_a", "O_b") if v2 else ()):
             e = float(np.abs(np.asarray(out[k]) - np.asarray(ref[k])).max())
-            if not e <= TOL_JAC:
+            if not e <= tol_jac:
                 msgs.append("%s %s err %.3e" % (label, k, e))
     if "cov" in what:
         e = cov_rel_err(out["P"], ref["P"])
-        if not e <= TOL_COV:
+        if not e <= tol_cov:
             msgs.append("%s P rel err %.3e" % (label, e))
     assert not msgs, "; ".join(msgs)
