@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPI_AMD_LIB") or os.path.join(_HERE, "libcpi_amd.so")  # env override: kernel-variant A/B runs
 
 CPI_OK, CPI_ERR_INVALID, CPI_ERR_HIP, CPI_ERR_NO_DEVICE = 0, 1, 2, 3
+ABI_VERSION = 2   # include/cpi_amd.h CPI_ABI_VERSION
 OUT_FIELDS = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9),
               ("H_a", 9), ("H_b", 9), ("O_a", 9), ("O_b", 9), ("P", 225)]
 
@@ -46,23 +47,39 @@ def load():
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
     lib.cpi_abi_version.restype = C.c_int
+    lib.cpi_build_id.restype = C.c_char_p
+    lib.cpi_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    lib.cpi_group_destroy.argtypes = [vp]
+    lib.cpi_group_destroy.restype = None
+    lib.cpi_group_size.argtypes = [vp]
+    lib.cpi_group_ctx.argtypes = [vp, C.c_int]
+    lib.cpi_group_ctx.restype = vp
+    lib.cpi_group_last_error.argtypes = [vp]
+    lib.cpi_group_last_error.restype = C.c_char_p
+    lib.cpi_shard_bounds.argtypes = [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    lib.cpi_shard_bounds.restype = None
+    lib.cpi_group_gather.argtypes = [vp, C.c_int, i64, C.POINTER(CpiOutputs), C.POINTER(CpiOutputs)]
+    lib.cpi_group_synchronize.argtypes = [vp]
     lib.cpi_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.cpi_ctx_destroy.argtypes = [vp]
     lib.cpi_ctx_destroy.restype = None
     lib.cpi_last_error.argtypes = [vp]
     lib.cpi_last_error.restype = C.c_char_p
     lib.cpi_ctx_synchronize.argtypes = [vp]
+    lib.cpi_ctx_set_stream.argtypes = [vp, vp]
     lib.cpi_preintegrate_batch.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, vp, dp, dp, C.POINTER(CpiOutputs)]
-    lib.cpi_factor_eval_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, vp, vp, dp, dp, dp]
-    lib.cpi_factor_eval_packed_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, vp, vp, dp]
+    lib.cpi_factor_eval_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp]
+    lib.cpi_factor_eval_packed_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp]
     lib.cpi_sqrt_information_batch.argtypes = [vp, i64, dp, dp]
-    lib.cpi_factor_eval_whitened_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, vp, vp, dp, dp, dp, dp]
-    lib.cpi_predict_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, vp, dp]
+    lib.cpi_factor_eval_whitened_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp, dp]
+    lib.cpi_predict_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, i64, vp, dp]
     lib.cpi_preintegrate_batch_host.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, vp, i64, dp, dp, C.POINTER(CpiOutputs)]
     lib.cpi_factor_eval_batch_host.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp]
     for f in (lib.cpi_ctx_create, lib.cpi_ctx_synchronize, lib.cpi_preintegrate_batch, lib.cpi_factor_eval_batch,
               lib.cpi_sqrt_information_batch, lib.cpi_factor_eval_whitened_batch, lib.cpi_factor_eval_packed_batch,
               lib.cpi_predict_batch, lib.cpi_preintegrate_batch_host, lib.cpi_factor_eval_batch_host):
         f.restype = C.c_int
+    if lib.cpi_abi_version() != ABI_VERSION:
+        raise ImportError("cpi_amd: %s has ABI version %d, this binding expects %d (stale build?)" % (LIB_PATH, lib.cpi_abi_version(), ABI_VERSION))
     _lib = lib
     return lib

@@ -20,6 +20,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Rpass-analysis=kernel-resource-usage"]
 
 
+def source_id():
+    """sha256[:16] over the sources the library is built from -- compiled into it (cpi_build_id()), so that measurement
+    records (profiles/*_pmc.json) can be tied to the exact library that is loaded."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS + [os.path.join(os.path.dirname(HERE), "include", "cpi_amd_test.h")]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     return (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
 
@@ -27,7 +38,7 @@ def stale():
 def build(force=False, report=False):
     if not (force or stale()):
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB, SRC]
+    cmd = [HIPCC] + FLAGS + ['-DCPI_BUILD_ID="%s"' % source_id(), "-o", LIB, SRC]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if p.returncode != 0:
         sys.stderr.write(p.stdout)

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
     const bool valid = (w < A.W) && (grp < WPB);   // L not a power of two leaves 64 - WPB*L idle lanes
     if (grp >= WPB) w = (long long)blockIdx.x * WPB;   // idle lanes shadow the block's first window (stays near the block)
     if (w >= A.W) w = A.W - 1;
-    const int n = A.count ? A.count[w] : A.N;
+    const int n = A.count ? min(max(A.count[w], 0), A.N) : A.N;   // a count outside [0, N] must not corrupt the packed descriptors
     const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
     const int per = (n + L - 1) / L;
     const int s0 = min(n, l * per), s1 = min(n, s0 + per);
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     long long w = (long long)blockIdx.x * G + g;
     const bool valid = w < A.W;
     if (!valid) w = A.W - 1;
-    const int n = A.count ? A.count[w] : A.N;
+    const int n = A.count ? min(max(A.count[w], 0), A.N) : A.N;
     const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
     const int nmax = wave_max(n);
 
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
     long long w = (long long)blockIdx.x * G + g;
     const bool valid = w < A.W;
     if (!valid) w = A.W - 1;
-    const int n = A.count ? A.count[w] : A.N;
+    const int n = A.count ? min(max(A.count[w], 0), A.N) : A.N;
     const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
     const int nmax = wave_max(n);
 
@@ -1064,6 +1064,7 @@ struct FactorArgs {
     const double *lin;
     const double *qk;
     const double *states;
+    long long S;               // number of states: indices are clamped into [0, S) (no out-of-bounds read whatever idx holds)
     const int *idx_i;
     const int *idx_j;
     double *err;
@@ -1124,8 +1125,8 @@ __device__ __forceinline__ void factor_fetch_inputs(const FactorArgs &A, long lo
             // branch-free NULL handling (a valid dummy address is read and discarded) keeps all loads in one block
             const int vi = (A.idx_i ? A.idx_i : reinterpret_cast<const int *>(A.states))[ff];
             const int vj = (A.idx_j ? A.idx_j : reinterpret_cast<const int *>(A.states))[ff];
-            si[r] = A.idx_i ? (long long)vi : ff;
-            sj[r] = A.idx_j ? (long long)vj : ff + 1;
+            si[r] = min(max(A.idx_i ? (long long)vi : ff, 0ll), A.S - 1);
+            sj[r] = min(max(A.idx_j ? (long long)vj : ff + 1, 0ll), A.S - 1);
         }
         FieldFetch<FPW, 3> f_alpha, f_beta; FieldFetch<FPW, 4> f_q, f_qk; FieldFetch<FPW, 6> f_lin;
         FieldFetch<FPW, 9> f_jq, f_jb, f_ja, f_hb, f_ha, f_ob, f_oa; FieldFetch<FPW, 1> f_dt;
@@ -1439,6 +1440,7 @@ struct PredictArgs {
     double grav[3];
     cpi_outputs meas;
     const double *states_i;
+    long long S;
     const int *idx_i;
     double *states_j;
 };
@@ -1446,7 +1448,7 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void cpi_predict_kernel(PredictArgs A) {
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= A.F) return;
-    const long long ii = A.idx_i ? A.idx_i[f] : f;
+    const long long ii = min(max(A.idx_i ? (long long)A.idx_i[f] : f, 0ll), A.S - 1);
     const NavState xi = ld_state(A.states_i + ii * 16);
     const NavState o = predict_state<MODEL>(xi, ldv3(A.meas.alpha + f * 3), ldv3(A.meas.beta + f * 3),
                                             ldq4(A.meas.q + f * 4), A.meas.DT[f], mk(A.grav[0], A.grav[1], A.grav[2]));
@@ -1493,6 +1495,10 @@ struct DeviceGuard {
     } while (0)
 
 extern "C" int cpi_abi_version(void) { return CPI_ABI_VERSION; }
+#ifndef CPI_BUILD_ID
+#define CPI_BUILD_ID "unknown"
+#endif
+extern "C" const char *cpi_build_id(void) { return CPI_BUILD_ID; }
 
 extern "C" int cpi_ctx_create(int device, void *stream, cpi_ctx **out) {
     if (!out) return fail(nullptr, CPI_ERR_INVALID, "cpi_ctx_create: out is NULL");
@@ -1513,6 +1519,11 @@ extern "C" int cpi_ctx_create(int device, void *stream, cpi_ctx **out) {
     return CPI_OK;
 }
 extern "C" void cpi_ctx_destroy(cpi_ctx *ctx) { delete ctx; }
+extern "C" int cpi_ctx_set_stream(cpi_ctx *ctx, void *stream) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    ctx->stream = (hipStream_t)stream;
+    return CPI_OK;
+}
 extern "C" const char *cpi_last_error(const cpi_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" int cpi_ctx_synchronize(cpi_ctx *ctx) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
@@ -1522,6 +1533,8 @@ extern "C" int cpi_ctx_synchronize(cpi_ctx *ctx) {
     return CPI_OK;
 }
 
+// hipLaunchKernelGGL takes 32-bit grid dimensions: a launch is refused rather than silently truncated
+static bool grid_ok(long long nb) { return nb > 0 && nb <= 0x7fffffffLL; }
 static const int kMeanLanes[] = {1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64};
 static bool mean_lanes_supported(int L) {
     for (int c : kMeanLanes) if (c == L) return true;
@@ -1671,7 +1684,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     if (!knots || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: knots/lin is NULL");
     if (prm->model == CPI_MODEL_V2 && !q_k_lin)
         return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: model 2 needs q_k_lin");
-    if (W > ((int64_t)1 << 31) * 4) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: W too large for one launch");
+    if (!grid_ok(W)) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: W exceeds 2^31 - 1 windows per call (32-bit grid)");
     if (N > 65535) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: N (intervals per window) must be <= 65535");
     int L = prm->lanes_per_window;
     if (L != 0 && !mean_lanes_supported(L)) return fail(ctx, CPI_ERR_INVALID, "lanes_per_window must be 0 or one of 1,2,3,4,5,6,8,12,16,32,64");
@@ -1754,18 +1767,18 @@ static int factor_lanes(int64_t F, bool whiten) {
 }
 
 static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F, const cpi_outputs *meas,
-                            const double *lin, const double *q_k_lin, const double *states, const int32_t *idx_i,
+                            const double *lin, const double *q_k_lin, const double *states, int64_t S, const int32_t *idx_i,
                             const int32_t *idx_j, const double *sqrt_info, double *err, double *H1, double *H2);
 
 extern "C" int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                                      const cpi_outputs *meas, const double *lin, const double *q_k_lin,
-                                     const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                     const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                      double *err, double *H1, double *H2) {
-    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, idx_i, idx_j, nullptr, err, H1, H2);
+    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, nullptr, err, H1, H2);
 }
 
 static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F, const cpi_outputs *meas,
-                            const double *lin, const double *q_k_lin, const double *states, const int32_t *idx_i,
+                            const double *lin, const double *q_k_lin, const double *states, int64_t S, const int32_t *idx_i,
                             const int32_t *idx_j, const double *sqrt_info, double *err, double *H1, double *H2) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: model must be 1 or 2");
@@ -1776,14 +1789,16 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
         return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
     if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
         return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: model 2 needs q_k_lin, O_a, O_b");
-    if (F > ((int64_t)1 << 33)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: F too large for one launch");
+    if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: F exceeds 2^31 - 1 factors per call");
+    if (S <= 0 || (!idx_i && S < F) || (!idx_j && S < F + 1))
+        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: S (number of states) must be >= 1, and >= F + 1 when idx_i / idx_j are NULL (chained states f, f + 1)");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
     FactorArgs a;
     memset(&a, 0, sizeof a);
     a.F = F;
     for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
-    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.idx_i = idx_i; a.idx_j = idx_j;
+    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j;
     a.err = err; a.H1 = H1; a.H2 = H2; a.sqrt_info = sqrt_info;
     // lanes per factor: 16 gives the most wavefronts (small sweeps), fewer lanes do less redundant arithmetic
     const int lpf = factor_lanes(F, sqrt_info != nullptr);
@@ -1804,7 +1819,7 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
 
 extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                                             const cpi_outputs *meas, const double *lin, const double *q_k_lin,
-                                            const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                            const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                             double *packed) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: model must be 1 or 2");
@@ -1815,14 +1830,16 @@ extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const d
         return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
     if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
         return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: model 2 needs q_k_lin, O_a, O_b");
-    if (F > ((int64_t)1 << 33)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: F too large for one launch");
+    if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: F exceeds 2^31 - 1 factors per call");
+    if (S <= 0 || (!idx_i && S < F) || (!idx_j && S < F + 1))
+        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: S (number of states) must be >= 1, and >= F + 1 when idx_i / idx_j are NULL");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
     FactorArgs a;
     memset(&a, 0, sizeof a);
     a.F = F;
     for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
-    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.idx_i = idx_i; a.idx_j = idx_j;
+    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j;
     const unsigned nb = (unsigned)((F + 7) / 8);
     if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_packed_kernel<1>), dim3(nb), dim3(64), 0, ctx->stream, a, packed);
     else hipLaunchKernelGGL((cpi_factor_packed_kernel<2>), dim3(nb), dim3(64), 0, ctx->stream, a, packed);
@@ -1845,14 +1862,14 @@ extern "C" int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double 
 
 extern "C" int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                                               const cpi_outputs *meas, const double *lin, const double *q_k_lin,
-                                              const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                              const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                               const double *sqrt_info, double *err, double *H1, double *H2) {
     if (ctx && !sqrt_info) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_whitened_batch: sqrt_info is NULL");
-    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, idx_i, idx_j, sqrt_info, err, H1, H2);
+    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, sqrt_info, err, H1, H2);
 }
 
 extern "C" int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
-                                 const cpi_outputs *meas, const double *states_i, const int32_t *idx_i,
+                                 const cpi_outputs *meas, const double *states_i, int64_t S, const int32_t *idx_i,
                                  double *states_j) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_predict_batch: model must be 1 or 2");
@@ -1860,17 +1877,183 @@ extern "C" int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[
     if (F == 0) return CPI_OK;
     if (!grav || !meas || !states_i || !states_j || !meas->DT || !meas->alpha || !meas->beta || !meas->q)
         return fail(ctx, CPI_ERR_INVALID, "cpi_predict_batch: NULL argument");
+    if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, "cpi_predict_batch: F exceeds 2^31 - 1 factors per call");
+    if (S <= 0 || (!idx_i && S < F)) return fail(ctx, CPI_ERR_INVALID, "cpi_predict_batch: S (number of states) must be >= 1, and >= F when idx_i is NULL");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
     PredictArgs a;
     memset(&a, 0, sizeof a);
     a.F = F;
     for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
-    a.meas = *meas; a.states_i = states_i; a.idx_i = idx_i; a.states_j = states_j;
+    a.meas = *meas; a.states_i = states_i; a.S = S; a.idx_i = idx_i; a.states_j = states_j;
     const long long nb = (F + 255) / 256;
     if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_predict_kernel<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL((cpi_predict_kernel<2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a);
     CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+
+static const int OUT_N[12] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225 };
+static double **out_field(cpi_outputs *o, int k) {
+    double **f[12] = { &o->DT, &o->alpha, &o->beta, &o->q, &o->J_q, &o->J_a, &o->J_b, &o->H_a, &o->H_b, &o->O_a, &o->O_b, &o->P };
+    return f[k];
+}
+
+// -------------------------------------------------------------------------------- device sets
+// Windows shard embarrassingly: rank r of n owns the contiguous block cpi_shard_bounds(W, r, n) and runs the ordinary
+// entries on its own context; the ONE exchange step is the final gather of the output slabs to a root device.  RCCL is
+// bound lazily (dlopen of librccl.so.1 at the first cpi_group_create): single-GPU users never load it, and a process
+// that already carries an RCCL (PyTorch) shares that copy.  One process drives all devices (ncclCommInitAll,
+// rccl/rccl.h:236) -- the reference is a single process too; multi-process hosts (one rank per GPU, torch.distributed)
+// use cpi_amd/dist.py, which issues the same send / recv pattern through ProcessGroupNCCL.
+#include <dlfcn.h>
+#include <vector>
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load() {
+        if (h) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) { err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return false; }
+#define CPI_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(h, name)); if (!field) { err = std::string("dlsym ") + name; h = nullptr; return false; }
+        CPI_SYM(CommInitAll, "ncclCommInitAll") CPI_SYM(CommDestroy, "ncclCommDestroy") CPI_SYM(GroupStart, "ncclGroupStart")
+        CPI_SYM(GroupEnd, "ncclGroupEnd") CPI_SYM(Send, "ncclSend") CPI_SYM(Recv, "ncclRecv") CPI_SYM(GetErrorString, "ncclGetErrorString")
+#undef CPI_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclDouble = 8;   // ncclFloat64 (rccl/rccl.h:467)
+}  // namespace
+
+struct cpi_group {
+    int n = 0;
+    std::vector<cpi_ctx *> ctx;
+    std::vector<hipStream_t> streams;   // owned
+    std::vector<void *> comms;          // ncclComm_t, empty when n == 1
+    std::string err;
+};
+static thread_local std::string g_group_err;
+static int gfail(cpi_group *g, int code, const std::string &msg) { if (g) g->err = msg; else g_group_err = msg; return code; }
+
+extern "C" void cpi_shard_bounds(int64_t W, int rank, int n, int64_t *lo, int64_t *hi) {
+    const int64_t per = n > 0 ? (W + n - 1) / n : W;
+    const int64_t a = std::min<int64_t>(W, (int64_t)rank * per);
+    if (lo) *lo = a;
+    if (hi) *hi = std::min<int64_t>(W, a + per);
+}
+extern "C" const char *cpi_group_last_error(const cpi_group *g) { return g ? g->err.c_str() : g_group_err.c_str(); }
+extern "C" int cpi_group_size(const cpi_group *g) { return g ? g->n : 0; }
+extern "C" cpi_ctx *cpi_group_ctx(cpi_group *g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->ctx[rank] : nullptr; }
+extern "C" void cpi_group_destroy(cpi_group *g) {
+    if (!g) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (int r = 0; r < g->n; r++) {
+        if (r < (int)g->comms.size() && g->comms[r] && g_rccl.CommDestroy) g_rccl.CommDestroy(g->comms[r]);
+        if (r < (int)g->ctx.size() && g->ctx[r]) {
+            (void)hipSetDevice(g->ctx[r]->device);
+            if (r < (int)g->streams.size() && g->streams[r]) (void)hipStreamDestroy(g->streams[r]);
+            cpi_ctx_destroy(g->ctx[r]);
+        }
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    delete g;
+}
+extern "C" int cpi_group_create(int n, const int *devices, cpi_group **out) {
+    if (!out) return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return gfail(nullptr, CPI_ERR_NO_DEVICE, "cpi_group_create: no HIP device available (this library has no CPU fallback)");
+    if (n <= 0 || n > ndev) return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: n must be between 1 and the number of devices");
+    std::vector<int> devs(n);
+    for (int r = 0; r < n; r++) {
+        devs[r] = devices ? devices[r] : r;
+        if (devs[r] < 0 || devs[r] >= ndev) return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: device index out of range");
+        for (int q = 0; q < r; q++) if (devs[q] == devs[r]) return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: duplicate device");
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    cpi_group *g = new cpi_group();
+    g->n = n;
+    g->ctx.assign(n, nullptr); g->streams.assign(n, nullptr);
+    for (int r = 0; r < n; r++) {
+        hipError_t e = hipSetDevice(devs[r]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->streams[r], hipStreamNonBlocking);
+        if (e != hipSuccess || cpi_ctx_create(devs[r], g->streams[r], &g->ctx[r]) != CPI_OK) {
+            const std::string msg = std::string("cpi_group_create: device ") + std::to_string(devs[r]) + ": " + (e != hipSuccess ? hipGetErrorString(e) : cpi_last_error(nullptr));
+            cpi_group_destroy(g);
+            if (prev >= 0) (void)hipSetDevice(prev);
+            return gfail(nullptr, CPI_ERR_HIP, msg);
+        }
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (n > 1) {
+        if (!g_rccl.load()) { const std::string m = "cpi_group_create: " + g_rccl.err; cpi_group_destroy(g); return gfail(nullptr, CPI_ERR_RCCL, m); }
+        g->comms.assign(n, nullptr);
+        const int rc = g_rccl.CommInitAll(g->comms.data(), n, devs.data());
+        if (rc != 0) { const std::string m = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc); cpi_group_destroy(g); return gfail(nullptr, CPI_ERR_RCCL, m); }
+    }
+    *out = g;
+    return CPI_OK;
+}
+extern "C" int cpi_group_synchronize(cpi_group *g) {
+    if (!g) return gfail(nullptr, CPI_ERR_INVALID, "group is NULL");
+    for (int r = 0; r < g->n; r++) {
+        const int rc = cpi_ctx_synchronize(g->ctx[r]);
+        if (rc != CPI_OK) return gfail(g, rc, cpi_last_error(g->ctx[r]));
+    }
+    return CPI_OK;
+}
+extern "C" int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_outputs *local, const cpi_outputs *root_out) {
+    if (!g) return gfail(nullptr, CPI_ERR_INVALID, "group is NULL");
+    if (root < 0 || root >= g->n || W < 0 || !local || !root_out) return gfail(g, CPI_ERR_INVALID, "cpi_group_gather: invalid argument");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore_{prev};
+    int rc = 0;
+    if (g->n > 1) { rc = g_rccl.GroupStart(); if (rc) return gfail(g, CPI_ERR_RCCL, std::string("ncclGroupStart: ") + g_rccl.GetErrorString(rc)); }
+    for (int k = 0; k < 12 && rc == 0; k++) {
+        cpi_outputs ro = *root_out;
+        double *dst = *out_field(&ro, k);
+        if (!dst) continue;
+        for (int r = 0; r < g->n && rc == 0; r++) {
+            int64_t lo, hi;
+            cpi_shard_bounds(W, r, g->n, &lo, &hi);
+            const size_t cnt = (size_t)(hi - lo) * (size_t)OUT_N[k];
+            if (cnt == 0) continue;
+            cpi_outputs lr = local[r];
+            const double *src = *out_field(&lr, k);
+            if (!src) { rc = -1; break; }
+            if (r == root) {   // the root's own block: device-to-device copy on its stream (unless it was computed in place)
+                if (src != dst + (size_t)lo * OUT_N[k]) {
+                    if (hipSetDevice(g->ctx[root]->device) != hipSuccess ||
+                        hipMemcpyAsync(dst + (size_t)lo * OUT_N[k], src, cnt * sizeof(double), hipMemcpyDeviceToDevice, g->streams[root]) != hipSuccess) rc = -2;
+                }
+            } else {           // every peer sends its slab straight to the root: one xGMI link per peer, no ring
+                rc = g_rccl.Recv(dst + (size_t)lo * OUT_N[k], cnt, kNcclDouble, r, g->comms[root], g->streams[root]);
+                if (rc == 0) rc = g_rccl.Send(src, cnt, kNcclDouble, root, g->comms[r], g->streams[r]);
+            }
+        }
+    }
+    int rce = 0;
+    if (g->n > 1) rce = g_rccl.GroupEnd();
+    if (rc == -1) return gfail(g, CPI_ERR_INVALID, "cpi_group_gather: a field wanted at the root is NULL in a rank's local outputs");
+    if (rc == -2) return gfail(g, CPI_ERR_HIP, "cpi_group_gather: device-to-device copy of the root's own block failed");
+    if (rc) return gfail(g, CPI_ERR_RCCL, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(rc));
+    if (rce) return gfail(g, CPI_ERR_RCCL, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(rce));
     return CPI_OK;
 }
 
@@ -1923,11 +2106,6 @@ struct DevBuf {
         }                                                                                 \
     } while (0)
 
-static const int OUT_N[12] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225 };
-static double **out_field(cpi_outputs *o, int k) {
-    double **f[12] = { &o->DT, &o->alpha, &o->beta, &o->q, &o->J_q, &o->J_a, &o->J_b, &o->H_a, &o->H_b, &o->O_a, &o->O_b, &o->P };
-    return f[k];
-}
 
 extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
                                            const double *knots, const int64_t *first, const int32_t *count,
@@ -1968,6 +2146,11 @@ extern "C" int cpi_factor_eval_batch_host(cpi_ctx *ctx, int32_t model, const dou
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (!meas || !lin || !states || !err || !grav) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch_host: NULL argument");
     if (F <= 0) return F == 0 ? CPI_OK : fail(ctx, CPI_ERR_INVALID, "negative size");
+    // host pointers: the indices can be (and are) validated here; the device-pointer entries clamp them instead
+    if (S <= 0 || (!idx_i && S < F) || (!idx_j && S < F + 1)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch_host: too few states");
+    for (int64_t f = 0; f < F; f++)
+        if ((idx_i && (idx_i[f] < 0 || idx_i[f] >= S)) || (idx_j && (idx_j[f] < 0 || idx_j[f] >= S)))
+            return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch_host: state index out of range at factor " + std::to_string(f));
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
     DevBuf dl, dq, ds, di, dj, de, dh1, dh2, dm[11];
@@ -1986,7 +2169,7 @@ extern "C" int cpi_factor_eval_batch_host(cpi_ctx *ctx, int32_t model, const dou
     CPI_HIP(ctx, hipMalloc(&de.p, (size_t)F * 15 * sizeof(double)));
     if (H1) CPI_HIP(ctx, hipMalloc(&dh1.p, (size_t)F * 225 * sizeof(double)));
     if (H2) CPI_HIP(ctx, hipMalloc(&dh2.p, (size_t)F * 225 * sizeof(double)));
-    int rc = cpi_factor_eval_batch(ctx, model, grav, F, &d, (const double *)dl.p, (const double *)dq.p, (const double *)ds.p,
+    int rc = cpi_factor_eval_batch(ctx, model, grav, F, &d, (const double *)dl.p, (const double *)dq.p, (const double *)ds.p, S,
                                    (const int32_t *)di.p, (const int32_t *)dj.p, (double *)de.p, (double *)dh1.p, (double *)dh2.p);
     if (rc != CPI_OK) return rc;
     CPI_HIP(ctx, hipMemcpyAsync(err, de.p, (size_t)F * 15 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

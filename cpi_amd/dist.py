@@ -2,9 +2,12 @@
 
 Windows (and factors) are independent units: rank r owns the contiguous block
 [r*ceil(W/n), (r+1)*ceil(W/n)) and runs the kernels on it with no data-path collective.  The only
-exchange step is the FINAL gather of the equal-sized per-rank output slabs (RCCL all_gather over
-xGMI when the backend is "nccl"; "gloo" in the CPU tests).  Nothing like this exists in the
-reference (single-threaded CPU program); SURVEY.md section 8(e).
+exchange step is the FINAL gather of the per-rank output slabs TO THE ROOT (gather_to_root: ProcessGroupNCCL
+issues one ncclSend per peer and the matching ncclRecvs on the root inside one group, i.e. every peer's slab
+travels its own xGMI link; "gloo" in the CPU tests).  gather_packed / gather_outputs(dst=None) are the
+all-gather forms for callers that need the results on every rank (n times the received bytes and memory).
+Nothing like this exists in the reference (single-threaded CPU program); SURVEY.md section 8(e).  The
+single-process C-ABI equivalent is cpi_group_gather (include/cpi_amd.h).
 """
 import torch
 import torch.distributed as dist
@@ -53,6 +56,18 @@ def pack_layout(fields, W):
     return lay, off
 
 
+def alloc_packed(fields, W, device="cpu", dtype=torch.float64):
+    """One flat buffer + per-field views of it ([W] for n = 1, else [W, n]): the layout Engine.alloc_outputs(packed=True)
+    hands to the kernels, so that a rank's whole output is one contiguous slab.  Returns (flat, {name: view})."""
+    lay, total = pack_layout(fields, W)
+    flat = torch.empty((total,), dtype=dtype, device=device)
+    views = {}
+    for name, n in fields:
+        v = flat[lay[name][0]:lay[name][0] + n * W]
+        views[name] = v if n == 1 else v.view(W, n)
+    return flat, views
+
+
 def gather_packed(flat, fields, W_local, group=None):
     """The final gather as ONE collective: every rank's outputs live in one flat buffer (pack_layout; the engine can
     write into views of it directly, Engine.alloc_outputs(..., packed=True)), so the exchange step is a single
@@ -65,3 +80,27 @@ def gather_packed(flat, fields, W_local, group=None):
     full = torch.empty((world, total), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(full.view(-1), flat, group=group)
     return {name: full[:, off:off + n * W_local].view(world, W_local, n) for name, (off, n) in lay.items()}
+
+
+def gather_to_root(flat, fields, W_local, dst=0, group=None, out=None):
+    """The final gather as SURVEY.md 8(e) asks for it: every rank's packed output slab (pack_layout; the engine writes
+    into views of it, Engine.alloc_outputs(..., packed=True)) goes to rank `dst` only -- one collective, each peer
+    sending straight to the root.  Returns name -> tensor [world, W_local, n] on the root (views of one [world, total]
+    buffer; rank r's block is [r]) and None elsewhere.  `out`: optional preallocated [world, total] buffer on the root
+    (a timed loop reuses it).  Equal W_local on all ranks (padded blocks)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lay, total = pack_layout(fields, W_local)
+    assert flat.numel() == total and flat.is_contiguous()
+    if rank == dst:
+        full = out if out is not None else torch.empty((world, total), dtype=flat.dtype, device=flat.device)
+        assert full.shape == (world, total) and full.is_contiguous()
+        dist.gather(flat, [full[r] for r in range(world)], dst=dst, group=group)
+        return {name: full[:, off:off + n * W_local].view(world, W_local, n) for name, (off, n) in lay.items()}
+    dist.gather(flat, None, dst=dst, group=group)
+    return None
+
+
+def unshard(gathered, W_total):
+    """[world, W_local, n] blocks (gather_to_root / gather_packed) -> [W_total, n] in window order (padding dropped)."""
+    return {name: t.reshape(-1, t.shape[-1])[:W_total] for name, t in gathered.items()}

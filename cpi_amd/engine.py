@@ -28,8 +28,14 @@ def _ptr(t):
 
 
 class Engine:
+    """One C-ABI context.  stream=None: the engine FOLLOWS torch's current stream of its device -- every call is issued
+    on torch.cuda.current_stream() as it is at that call (so inputs produced and outputs allocated under
+    `with torch.cuda.stream(s):` are used on the stream that owns them).  An explicit stream pins the engine to it; the
+    caller then orders that stream against the producers / consumers of the tensors (EnginePool does that bookkeeping)."""
+
     def __init__(self, device=None, stream=None):
         self.lib = _lib.load()
+        self._follow = stream is None
         if device is None:
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
@@ -57,6 +63,14 @@ class Engine:
     def _check(self, rc):
         if rc != 0:
             raise CpiError(rc, (self.lib.cpi_last_error(self.ctx) or b"").decode())
+
+    def _sync_stream(self):
+        """Follow torch's current stream (see the class docstring); one pointer comparison per call."""
+        if self._follow:
+            cur = torch.cuda.current_stream(self.device)
+            if cur.cuda_stream != self.stream.cuda_stream:
+                self._check(self.lib.cpi_ctx_set_stream(self.ctx, C.c_void_p(cur.cuda_stream)))
+                self.stream = cur
 
     def synchronize(self):
         self._check(self.lib.cpi_ctx_synchronize(self.ctx))
@@ -87,13 +101,8 @@ class Engine:
             names.append((name, n))
         out = {}
         if packed:
-            from .dist import pack_layout
-            lay, total = pack_layout(names, W)
-            flat = torch.empty((total,), dtype=torch.float64, device=self.device)
-            for name, n in names:
-                off = lay[name][0]
-                v = flat[off:off + n * W]
-                out[name] = v if n == 1 else v.view(W, n)
+            from .dist import alloc_packed
+            flat, out = alloc_packed(names, W, self.device)
             out["_flat"], out["_fields"] = flat, names
             return out
         for name, n in names:
@@ -127,6 +136,7 @@ class Engine:
         if out is None:
             out = self.alloc_outputs(W, want, params.model)
         o = self._outputs_struct(out)
+        self._sync_stream()
         self._check(self.lib.cpi_preintegrate_batch(self.ctx, C.byref(params), W, N, _ptr(knots), _ptr(first), _ptr(count),
                                                     _ptr(lin), _ptr(q_k_lin), C.byref(o)))
         return out
@@ -136,6 +146,7 @@ class Engine:
         """R = chol_upper(P^-1) per factor (GTSAM noiseModel::Gaussian::Covariance); P [F,225] -> R [F,225]."""
         F = P.shape[0]
         R = torch.empty((F, 225), dtype=torch.float64, device=self.device)
+        self._sync_stream()
         self._check(self.lib.cpi_sqrt_information_batch(self.ctx, F, _ptr(P), _ptr(R)))
         return R
 
@@ -150,15 +161,16 @@ class Engine:
                 out["H2"] = torch.empty((F, 225), dtype=torch.float64, device=self.device)
         m = self._outputs_struct(meas)
         g = (C.c_double * 3)(*grav)
+        self._sync_stream()
         if sqrt_info is None:
             self._check(self.lib.cpi_factor_eval_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin),
-                                                       _ptr(states), _ptr(idx_i), _ptr(idx_j), _ptr(out["err"]),
-                                                       _ptr(out.get("H1")), _ptr(out.get("H2"))))
+                                                       _ptr(states), states.shape[0], _ptr(idx_i), _ptr(idx_j),
+                                                       _ptr(out["err"]), _ptr(out.get("H1")), _ptr(out.get("H2"))))
         else:
             self._check(self.lib.cpi_factor_eval_whitened_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin),
-                                                                _ptr(q_k_lin), _ptr(states), _ptr(idx_i), _ptr(idx_j),
-                                                                _ptr(sqrt_info), _ptr(out["err"]), _ptr(out.get("H1")),
-                                                                _ptr(out.get("H2"))))
+                                                                _ptr(q_k_lin), _ptr(states), states.shape[0], _ptr(idx_i),
+                                                                _ptr(idx_j), _ptr(sqrt_info), _ptr(out["err"]),
+                                                                _ptr(out.get("H1")), _ptr(out.get("H2"))))
         return out
 
     def factor_eval_packed(self, model, meas, lin, q_k_lin, states, idx_i=None, idx_j=None, grav=DEFAULT_GRAV, out=None):
@@ -170,8 +182,9 @@ class Engine:
             out = torch.empty((F, 72), dtype=torch.float64, device=self.device)
         m = self._outputs_struct(meas)
         g = (C.c_double * 3)(*grav)
+        self._sync_stream()
         self._check(self.lib.cpi_factor_eval_packed_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin),
-                                                          _ptr(states), _ptr(idx_i), _ptr(idx_j), _ptr(out)))
+                                                          _ptr(states), states.shape[0], _ptr(idx_i), _ptr(idx_j), _ptr(out)))
         return out
 
     def predict(self, model, meas, states_i, idx_i=None, grav=DEFAULT_GRAV):
@@ -179,7 +192,9 @@ class Engine:
         xj = torch.empty((F, 16), dtype=torch.float64, device=self.device)
         m = self._outputs_struct(meas)
         g = (C.c_double * 3)(*grav)
-        self._check(self.lib.cpi_predict_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(states_i), _ptr(idx_i), _ptr(xj)))
+        self._sync_stream()
+        self._check(self.lib.cpi_predict_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(states_i), states_i.shape[0],
+                                               _ptr(idx_i), _ptr(xj)))
         return xj
 
 

@@ -31,9 +31,9 @@
 extern "C" {
 #endif
 
-#define CPI_ABI_VERSION 1
+#define CPI_ABI_VERSION 2   /* 2: state count S in the factor / predict entries; device-set entries (cpi_group_*) */
 
-enum { CPI_OK = 0, CPI_ERR_INVALID = 1, CPI_ERR_HIP = 2, CPI_ERR_NO_DEVICE = 3 };
+enum { CPI_OK = 0, CPI_ERR_INVALID = 1, CPI_ERR_HIP = 2, CPI_ERR_NO_DEVICE = 3, CPI_ERR_RCCL = 4 };
 enum {
     CPI_MODEL_V1 = 1, CPI_MODEL_V2 = 2,
     /* cpi_preintegrate_batch only: the "Forster discrete" comparator, i.e. what GraphSolver::createimufactor_discrete
@@ -86,8 +86,11 @@ typedef struct {
 /* device < 0: use the current HIP device.  stream: a hipStream_t (NULL = the default stream). */
 int cpi_ctx_create(int device, void *stream, cpi_ctx **out);
 void cpi_ctx_destroy(cpi_ctx *ctx);
+/* Later calls on ctx are issued on `stream` (a hipStream_t of the context's device).  The caller orders the two streams. */
+int cpi_ctx_set_stream(cpi_ctx *ctx, void *stream);
 const char *cpi_last_error(const cpi_ctx *ctx); /* ctx may be NULL: last error of a failed create */
 int cpi_abi_version(void);
+const char *cpi_build_id(void);   /* sha256[:16] of the sources this library was built from (cpi_amd/build.py: source_id) */
 int cpi_ctx_synchronize(cpi_ctx *ctx);
 
 /* Replaces: the per-window loop  CpiV{1,2} cpi(...); cpi.setLinearizationPoints(...);
@@ -99,9 +102,12 @@ int cpi_ctx_synchronize(cpi_ctx *ctx);
  *         A tail interval [t_last, updatetime] is expressed by a final knot
  *         {updatetime, w_last, a_last} (GraphSolver_IMU.cpp:64-69).  A knot whose t is NaN is a
  *         separator: both intervals touching it are skipped, so non-chained feed_IMU calls
- *         (the reference only ever uses t_1 - t_0) can be expressed in one window.
+ *         (the reference only ever uses t_1 - t_0) can be expressed in one window.  Skipped intervals
+ *         are run as dt = 0 (an exact no-op of the arithmetic, no divergence): their READINGS must be
+ *         finite -- the separators the facades emit carry zeros.
  * first   [W] index of each window's first knot, or NULL for the dense layout knots[W][N+1][7].
- * count   [W] number of intervals of each window (<= N), or NULL = every window has N.
+ * count   [W] number of intervals of each window (<= N), or NULL = every window has N.  Values outside
+ *         [0, N] are clamped into it by the kernels (the array lives in HBM and cannot be validated by the call).
  *         Windows may share knots (consecutive windows cut from one stream).
  * N       maximum number of intervals per window.
  * lin     [W][6]  {b_w_lin[3], b_a_lin[3]}  (CpiBase.h:113-114)
@@ -118,12 +124,15 @@ int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32
  * mapping of GraphSolver_IMU.cpp:74-75,129-130: J_b->J_beta, J_a->J_alpha, H_b->H_beta,
  * H_a->H_alpha, O_b->O_beta, O_a->O_alpha), its linearisation biases from lin[f] and, for
  * model 2, q_K_lin from q_k_lin[f].
- * states  [S][16] JPLNavState array; idx_i/idx_j [F] select state_i/state_j (NULL: f and f+1).
+ * states  [S][16] JPLNavState array; idx_i/idx_j [F] select state_i/state_j (NULL: f and f+1, which needs S >= F+1).
+ *         S is the number of states: the device-pointer entries cannot inspect idx (it lives in HBM), so the kernels
+ *         CLAMP every index into [0, S) -- a wrong index yields a wrong factor, never an out-of-bounds read; the
+ *         _host variant validates the indices and returns CPI_ERR_INVALID.
  * err     [F][15] unwhitened residual; H1, H2 [F][225] dense column-major Jacobians wrt the two
  *         states' tangent vectors; H1/H2 may be NULL (the boost::optional<Matrix&> = none case). */
 int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                           const cpi_outputs *meas, const double *lin, const double *q_k_lin,
-                          const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                          const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                           double *err, double *H1, double *H2);
 
 /* Fast path of the same evaluation for callers that assemble their own Hessian blocks (note on
@@ -141,7 +150,7 @@ int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int
  * Same arguments as cpi_factor_eval_batch.  (cpi_amd.unpack_factor in the Python mirror rebuilds the dense pair.) */
 int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                                  const cpi_outputs *meas, const double *lin, const double *q_k_lin,
-                                 const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                 const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                  double *packed);
 
 /* Replaces: gtsam::noiseModel::Gaussian::Covariance(P_meas) in the factor constructors
@@ -157,14 +166,38 @@ int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double *P, double 
  * (Gaussian::WhitenSystem): err <- R err, H1 <- R H1, H2 <- R H2 with R = sqrt_info[f]. */
 int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                                    const cpi_outputs *meas, const double *lin, const double *q_k_lin,
-                                   const double *states, const int32_t *idx_i, const int32_t *idx_j,
+                                   const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                    const double *sqrt_info, double *err, double *H1, double *H2);
 
 /* Replaces: GraphSolver::getpredictedstate_v1 / _v2 (GraphSolver_IMU.cpp:263-281, 289-307):
- * states_j[f] = prediction of X(k+1) from states_i[idx_i[f]] and measurement f. */
+ * states_j[f] = prediction of X(k+1) from states_i[idx_i[f]] and measurement f.  states_i [S][16]; idx_i NULL: state f. */
 int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
-                      const cpi_outputs *meas, const double *states_i, const int32_t *idx_i,
+                      const cpi_outputs *meas, const double *states_i, int64_t S, const int32_t *idx_i,
                       double *states_j);
+
+/* ---- Device sets: the 8-GPU path of a single-process host (nothing in the reference, which is a
+ * single-threaded CPU program).  Windows (and factors) are independent units: rank r of n owns the contiguous block
+ * [lo, hi) = cpi_shard_bounds(W, r, n) (block size ceil(W / n); trailing ranks may be short or empty), runs the ordinary
+ * entries above on cpi_group_ctx(g, r) with pointers into ITS device's memory, and the one exchange step is
+ * cpi_group_gather: every peer sends its output slab straight to the root (ncclSend / ncclRecv inside one
+ * ncclGroupStart / End, rccl/rccl.h:700-722,923-933 -- each peer has its own xGMI link to the root, so a direct gather
+ * is link-parallel where a ring would be per-link bound), the root's own block is a device-to-device copy.
+ * cpi_group_create makes one context + one non-blocking HIP stream per device and, for n > 1, one RCCL communicator per
+ * device (ncclCommInitAll, rccl.h:236; librccl.so.1 is bound at that moment, never before).  devices NULL = 0 .. n-1.
+ * All calls are asynchronous on the group's streams; cpi_group_synchronize waits for every device.
+ * Multi-process hosts (one rank per GPU) use torch.distributed instead: cpi_amd/dist.py issues the same pattern. */
+typedef struct cpi_group cpi_group;
+int cpi_group_create(int n, const int *devices, cpi_group **out);
+void cpi_group_destroy(cpi_group *g);
+int cpi_group_size(const cpi_group *g);
+cpi_ctx *cpi_group_ctx(cpi_group *g, int rank);                 /* borrowed; owned by the group */
+const char *cpi_group_last_error(const cpi_group *g);           /* g may be NULL: last error of a failed create */
+void cpi_shard_bounds(int64_t W, int rank, int n, int64_t *lo, int64_t *hi);
+/* local[r] = the outputs of rank r's block (device pointers on device r, hi - lo windows each); root_out = arrays of W
+ * windows on the root's device: rank r's block lands at window offset lo.  Every field that is non-NULL in root_out
+ * must be non-NULL in every non-empty local[r].  local[root] may already point into root_out (no copy then). */
+int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_outputs *local, const cpi_outputs *root_out);
+int cpi_group_synchronize(cpi_group *g);
 
 /* Convenience for single-window / small host-side callers (the CpiV1-shaped C++ facade in
  * cpi_amd/csrc/cpi_host.hpp): same as cpi_preintegrate_batch but every pointer is a HOST pointer;

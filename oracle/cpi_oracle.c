@@ -758,6 +758,29 @@ void cpi_oracle_factor_v2(const cpi_oracle_factor *f, const double *xi, const do
     factor_eval(1, f, xi, xj, err, H1, H2);
 }
 
+/* F factors (records of 87 doubles, the field order of cpi_oracle_factor), spread over nthreads pthreads: the CPU leg
+ * bench.py times beside the re-linearisation sweep ("port": the reference's factor TUs need GTSAM and cannot be built). */
+typedef struct { int model; long f0, f1; const double *rec, *xi, *xj; double *err, *H1, *H2; } fb_job;
+static void *fb_worker(void *p) {
+    fb_job *j = (fb_job *)p;
+    for (long f = j->f0; f < j->f1; f++)
+        factor_eval(j->model == 2, (const cpi_oracle_factor *)(j->rec + f * 87), j->xi + f * 16, j->xj + f * 16,
+                    j->err + f * 15, j->H1 ? j->H1 + f * 225 : NULL, j->H2 ? j->H2 + f * 225 : NULL);
+    return NULL;
+}
+void cpi_oracle_factor_batch_mt(int model, long F, const double *rec, const double *xi, const double *xj, double *err,
+                                double *H1, double *H2, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    fb_job *jobs = (fb_job *)malloc(sizeof(fb_job) * nthreads);
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (fb_job){ model, F * t / nthreads, F * (t + 1) / nthreads, rec, xi, xj, err, H1, H2 };
+        pthread_create(&th[t], NULL, fb_worker, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+}
+
 /* GraphSolver_IMU.cpp:263-281 / 289-307 */
 void cpi_oracle_predict(int model, const cpi_oracle_factor *f, const double *xi, double *xj) {
     const double *q_GtoK = xi, *bg_K = xi + 4, *v_K = xi + 7, *ba_K = xi + 10, *p_K = xi + 13;

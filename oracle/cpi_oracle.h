@@ -89,6 +89,10 @@ void cpi_oracle_factor_v1(const cpi_oracle_factor *f, const double *xi, const do
 void cpi_oracle_factor_v2(const cpi_oracle_factor *f, const double *xi, const double *xj,
                           double *err, double *H1, double *H2);
 
+/* The same for F factors: rec [F][87] (this struct's fields as consecutive doubles), xi / xj [F][16]; nthreads pthreads. */
+void cpi_oracle_factor_batch_mt(int model, long F, const double *rec, const double *xi, const double *xj, double *err,
+                                double *H1, double *H2, int nthreads);
+
 /* GraphSolver_IMU.cpp:263-281 (model 1) / 289-307 (model 2). */
 void cpi_oracle_predict(int model, const cpi_oracle_factor *f, const double *xi, double *xj);
 

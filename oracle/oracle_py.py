@@ -177,6 +177,19 @@ class _OracleLib(_Lib):
                _dp(H1[k]) if want_H else None, _dp(H2[k]) if want_H else None)
         return err, H1, H2
 
+    def factor_batch(self, model, frec, xi, xj, nthreads=1, out=None):
+        """Batched, multi-threaded evaluateError restatement (timing leg of bench.py).  out = (err, H1, H2) to reuse."""
+        frec = np.ascontiguousarray(frec, dtype=np.float64)
+        xi = np.ascontiguousarray(xi, dtype=np.float64)
+        xj = np.ascontiguousarray(xj, dtype=np.float64)
+        F = frec.shape[0]
+        assert frec.shape[1] == FACTOR_DOUBLES
+        err, H1, H2 = out if out is not None else (np.zeros((F, 15)), np.zeros((F, 225)), np.zeros((F, 225)))
+        self.lib.cpi_oracle_factor_batch_mt.restype = None
+        self.lib.cpi_oracle_factor_batch_mt(C.c_int(model), C.c_long(F), _dp(frec), _dp(xi), _dp(xj), _dp(err), _dp(H1), _dp(H2),
+                                            C.c_int(nthreads))
+        return err, H1, H2
+
     def predict(self, model, frec, xi):
         frec = np.ascontiguousarray(frec, dtype=np.float64)
         xi = np.ascontiguousarray(xi, dtype=np.float64)

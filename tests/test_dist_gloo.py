@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cpi_amd.dist import gather_outputs, gather_packed, pack_layout, shard_bounds
+from cpi_amd.dist import gather_outputs, gather_packed, pack_layout, shard_bounds  # noqa: F401
 
 
 def test_shard_bounds_cover_exactly():
@@ -74,3 +74,83 @@ def test_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# --------------------------------------------------------------------------- bench.py's partition / gather code on engine-shaped outputs
+def _worker_bench(rank, world, port, W, N, q):
+    """What bench.py does at N > 1, with the oracle standing in for the kernels (no GPU here): block partition
+    (cpi_amd.dist.shard_bounds), the rank's outputs written into the views of ONE packed slab (the layout
+    Engine.alloc_outputs(packed=True) hands to the kernels), bench.final_gather to rank 0, max-over-ranks timing.
+    Rank 0 checks the re-assembled result BITWISE against the unsharded run."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from cpi_amd import synth
+        from cpi_amd.dist import alloc_packed, unshard
+        from oracle import oracle_py as op
+        kn, lin, qk = synth.make_windows(W, N, seed=606)
+        kn, lin, qk = kn.numpy(), lin.numpy(), qk.numpy()
+        ok = True
+        for model, want in ((1, ("DT", "alpha", "beta", "q")), (2, ("DT", "alpha", "beta", "q", "J_q", "J_a", "J_b", "H_a", "H_b", "O_a", "O_b", "P"))):
+            fields = [(n, k) for n, k in [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9), ("H_a", 9),
+                                          ("H_b", 9), ("O_a", 9), ("O_b", 9), ("P", 225)] if n in want]
+            lo, hi, per = shard_bounds(W, rank, world)
+            prm = op.make_params(model, 0, 1)
+            loc = op.oracle().run(prm, kn[lo:hi], lin[lo:hi], qk[lo:hi])
+            flat, views = alloc_packed(fields, per)              # padded block: equal slabs on every rank
+            flat.zero_()
+            for name, _ in fields:
+                views[name][: hi - lo] = torch.from_numpy(np.ascontiguousarray(loc[name]))
+            out = dict(views); out["_flat"], out["_fields"] = flat, fields
+            for mode in ("root", "all"):
+                g = bench.final_gather(out, per, mode, dst=0)
+                if mode == "root" and rank != 0:
+                    ok = ok and g is None
+                    continue
+                full = unshard(g, W)
+                ref = op.oracle().run(prm, kn, lin, qk)
+                for name, n in fields:
+                    ok = ok and np.array_equal(full[name].numpy().reshape(W, -1), np.asarray(ref[name]).reshape(W, -1))
+        t = torch.tensor([0.1 * (rank + 1), 7.0 - rank, 0.0], dtype=torch.float64)   # bench.main's (wall, kernel ms, wall w/o gather)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = ok and abs(t[0].item() - 0.1 * world) < 1e-15 and t[1].item() == 7.0
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_partition_and_gather_to_root_bitwise_world2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bench, args=(r, 2, port, 77, 20, q)) for r in range(2)]   # 77: last block short
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_bench_gpus_flag_spawns_the_ranks_itself(monkeypatch):
+    """`python bench.py --gpus N` with no launcher (WORLD_SIZE unset) re-executes under torch.distributed.run with N
+    ranks on 127.0.0.1; under a launcher (WORLD_SIZE set) it does not."""
+    import bench
+    seen = {}
+
+    def fake_execve(exe, cmd, env):
+        seen["cmd"], seen["env"] = cmd, env
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execve", fake_execve)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr("sys.argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    try:
+        bench.main()
+    except SystemExit:
+        pass
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"

@@ -1,0 +1,108 @@
+"""Device-set entries of the C-ABI (cpi_group_*, include/cpi_amd.h): on the 1-GPU test box only a set of ONE device can
+be exercised -- block partition, per-rank contexts / streams, the root's own block landing at its offset through the
+gather entry; n > the number of devices is refused.  (RCCL is not even loaded for n = 1.)  The n > 1 exchange pattern is
+covered on CPU by tests/test_dist_gloo.py through the torch.distributed twin of the same code."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_shard_bounds_match_the_python_partition():
+    from cpi_amd import _lib
+    from cpi_amd.dist import shard_bounds
+    lib = _lib.load()
+    for W in (0, 1, 7, 8, 9, 10000, 8000001):
+        for n in (1, 2, 3, 8):
+            for r in range(n):
+                lo, hi = C.c_int64(), C.c_int64()
+                lib.cpi_shard_bounds(W, r, n, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard_bounds(W, r, n)[:2]
+
+
+def test_group_of_one_device_runs_the_hot_path_and_gathers():
+    import cpi_amd
+    from cpi_amd import _lib, synth
+    from cpi_amd._lib import CpiOutputs
+    lib = _lib.load()
+    g = C.c_void_p()
+    assert lib.cpi_group_create(1, None, C.byref(g)) == 0, lib.cpi_group_last_error(None)
+    try:
+        assert lib.cpi_group_size(g) == 1
+        ctx = lib.cpi_group_ctx(g, 0)
+        assert ctx and lib.cpi_group_ctx(g, 1) is None
+        dev = torch.device("cuda", 0)
+        W, N = 1000, 50
+        kn, lin, q = synth.make_windows(W, N, seed=8, device=dev)
+        eng = cpi_amd.Engine(device=0)
+        ref = eng.preintegrate(kn, lin, q, eng.make_params(1))
+        torch.cuda.synchronize()
+        # the group's context (own stream) computes the block, the gather entry places it in the root arrays
+        loc = eng.alloc_outputs(W, ("mean", "jac", "cov"), 1)
+        root = {k: torch.full_like(v, float("nan")) for k, v in loc.items()}
+        prm = eng.make_params(1)
+        o = eng._outputs_struct(loc)
+        torch.cuda.synchronize()
+        assert lib.cpi_preintegrate_batch(ctx, C.byref(prm), W, N, kn.data_ptr(), None, None, lin.data_ptr(), q.data_ptr(), C.byref(o)) == 0
+        locs = (CpiOutputs * 1)(o)
+        ro = eng._outputs_struct(root)
+        assert lib.cpi_group_gather(g, 0, W, locs, C.byref(ro)) == 0, lib.cpi_group_last_error(g)
+        assert lib.cpi_group_synchronize(g) == 0
+        for k in ref:
+            assert torch.equal(root[k], ref[k]), k
+        # a field wanted at the root but missing locally is an error, not a silent skip
+        o2 = eng._outputs_struct({k: v for k, v in loc.items() if k != "P"})
+        assert lib.cpi_group_gather(g, 0, W, (CpiOutputs * 1)(o2), C.byref(ro)) == _lib.CPI_ERR_INVALID
+    finally:
+        lib.cpi_group_destroy(g)
+
+
+def test_group_larger_than_the_machine_is_refused():
+    from cpi_amd import _lib
+    lib = _lib.load()
+    g = C.c_void_p()
+    n = torch.cuda.device_count() + 1
+    assert lib.cpi_group_create(n, None, C.byref(g)) == _lib.CPI_ERR_INVALID and not g
+    assert b"number of devices" in lib.cpi_group_last_error(None)
+    dup = (C.c_int * 2)(0, 0)
+    if torch.cuda.device_count() >= 2:
+        assert lib.cpi_group_create(2, dup, C.byref(g)) == _lib.CPI_ERR_INVALID
+
+
+def test_factor_indices_are_clamped_on_the_device_and_validated_on_the_host_path():
+    """ABI 2: the factor entries know the number of states.  Out-of-range indices must not read out of bounds (device
+    path: clamped) and are rejected by the host-pointer variant."""
+    import cpi_amd
+    from cpi_amd import _lib, synth
+    eng = cpi_amd.Engine(device=0)
+    F = 64
+    kn, lin, q = synth.make_windows(F, 20, seed=2, device=eng.device)
+    meas = eng.preintegrate(kn, lin, q, eng.make_params(1), want=("mean", "jac"))
+    xi, xj = synth.make_states(meas["alpha"], meas["beta"], meas["q"], meas["DT"], lin, 1, device=eng.device)
+    states = torch.cat([xi, xj[-1:]], dim=0).contiguous()          # S = F + 1
+    S = states.shape[0]
+    good = eng.factor_eval(1, meas, lin, None, states)
+    ii = torch.arange(F, dtype=torch.int32, device=eng.device)
+    jj = ii + 1
+    bad_j = jj.clone(); bad_j[-1] = 2 ** 30                         # far outside: clamped to S - 1 = the right state here
+    bad_i = ii.clone(); bad_i[0] = -5                               # clamped to 0 = the right state here
+    out = eng.factor_eval(1, meas, lin, None, states, bad_i, bad_j)
+    torch.cuda.synchronize()
+    for k in ("err", "H1", "H2"):
+        assert torch.equal(out[k], good[k]), k
+    with pytest.raises(cpi_amd.CpiError):                           # chained (NULL) indices need S >= F + 1
+        eng.factor_eval(1, meas, lin, None, states[:F].contiguous())
+    # host-pointer variant: validates
+    lib = _lib.load()
+    m = {k: v.cpu().numpy() for k, v in meas.items()}
+    ms = eng._outputs_struct({k: torch.from_numpy(v) for k, v in m.items()})
+    linh, sth = lin.cpu().numpy(), states.cpu().numpy()
+    err = np.zeros((F, 15))
+    bi = bad_i.cpu().numpy()
+    gv = (C.c_double * 3)(0.0, 0.0, 9.8)
+    rc = lib.cpi_factor_eval_batch_host(eng.ctx, 1, gv, F, C.byref(ms), linh.ctypes.data, None, sth.ctypes.data, S,
+                                        bi.ctypes.data, None, err.ctypes.data, None, None)
+    assert rc == _lib.CPI_ERR_INVALID and b"out of range" in lib.cpi_last_error(eng.ctx)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage (on the GPU box, through gpurun): tools/pmc_collect.sh <out.json> [row ...]
+# Collects the HBM-traffic and FP64-instruction counters of bench.py's rows with the IN-TREE library, one rocprofv3 --pmc
+# pass per counter group (kernel-trace / stats domains are NOT combined with --pmc), and writes profiles-style JSON stamped
+# with the library's build id.  A row is <workload>:<W>:<N>.
+R=$PWD; OUT=$1; shift
+ROWS=${@:-"v1_mean:10000:50 v1_mean:1000000:50 v1_full:100000:50 v2_full:100000:50 forster_full:100000:50 factor_v1:1000000:50 factor_v2:1000000:50 cfg5_mean:1000000:100"}
+export TMPDIR=/tmp
+D=/tmp/pmc_$$; mkdir -p $D; cd /tmp
+BID=$(python -c "import sys; sys.path.insert(0,'$R'); from cpi_amd import _lib; print(_lib.load().cpi_build_id().decode())")
+SPECS=""
+for row in $ROWS; do
+  wl=${row%%:*}; rest=${row#*:}; W=${rest%%:*}; N=${rest#*:}
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVES" \
+             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS"; do
+    i=$((i+1))
+    CPI_MB_SAMPLES=$N timeout 300 rocprofv3 --pmc $grp -d $D/${wl}_${W}_${N} -o g$i -- python $R/tools/microbench.py $wl:$W:0:3 > /dev/null 2> $D/err_${wl}_$i.txt || tail -3 $D/err_${wl}_$i.txt
+  done
+  SPECS="$SPECS $row=$D/${wl}_${W}_${N}/**/*.db"
+done
+python $R/tools/pmc_summary.py --json $BID $R/$OUT $SPECS
+rm -rf $D

@@ -1,25 +1,74 @@
-"""Summarise a rocprofv3 --pmc rocpd database: per-kernel mean of every collected counter (dev tool)."""
+"""Summarise rocprofv3 --pmc rocpd databases: per-kernel mean of every collected counter (dev tool).
+
+    python tools/pmc_summary.py '/tmp/pmc/**/*.db'                      # text table
+    python tools/pmc_summary.py --json BUILD_ID OUT.json ROW=GLOB ...   # profiles/r02_pmc.json for bench.py
+
+--json: every ROW is "<workload>:<W>:<N>" (bench.py's key) = a glob of the databases of that row's passes.  Per row the
+counters of the row's DOMINANT kernels (all kernels whose name starts with cpi_, summed per launch of the workload --
+"V1 full" is two kernels) are averaged over launches and converted:
+    traffic_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024     MI355X_MICROARCH.md "HBM": the counters are KiB and gfx950's
+                                                             FETCH_SIZE reports half of a wide streaming read
+    fp64_flop     = 64 * (2 * FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64)   wave-level SQ instruction counters x 64 lanes
+"""
 import glob
+import json
 import sqlite3
 import sys
 
 
-def main(pattern, name_filter="cpi_"):
+def rows_of(db):
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    try:
+        return cur.execute("select name, counter_name, avg(counter_value), count(*) from pmc_events "
+                           "group by name, counter_name").fetchall()
+    except Exception:
+        return []
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def main_text(pattern, name_filter="cpi_"):
     for db in sorted(glob.glob(pattern, recursive=True)):
-        con = sqlite3.connect(db)
-        cur = con.cursor()
-        try:
-            rows = cur.execute("select name, counter_name, avg(counter_value), count(*) from pmc_events "
-                               "group by name, counter_name").fetchall()
-        except Exception as ex:
-            cols = [d[0] for d in cur.execute("select * from pmc_events limit 1").description]
-            print(db, "schema:", cols, ex)
-            continue
-        for name, ctr, val, n in rows:
+        for name, ctr, val, n in rows_of(db):
             if name_filter in name:
-                short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-                print("%-28s %-44s %-24s avg=%.6g n=%d" % (db.split("/")[-1][:28], short, ctr, val, n))
+                print("%-28s %-44s %-24s avg=%.6g n=%d" % (db.split("/")[-1][:28], short(name), ctr, val, n))
+
+
+def main_json(build_id, out, specs):
+    res = {"build_id": build_id, "rows": {},
+           "how": "tools/pmc_collect.sh: one rocprofv3 --pmc pass per counter group and row (no trace domains); per-launch "
+                  "means over the timed launches of tools/microbench.py; conversions in tools/pmc_summary.py"}
+    for spec in specs:
+        key, pattern = spec.split("=", 1)
+        acc, kernels = {}, set()
+        for db in sorted(glob.glob(pattern, recursive=True)):
+            for name, ctr, val, n in rows_of(db):
+                if "cpi_" in name and "test" not in name:
+                    # per-dispatch mean; a workload that launches two cpi_ kernels per step sums them
+                    acc.setdefault(ctr, {})[short(name)] = val
+                    kernels.add(short(name))
+        c = {ctr: sum(v.values()) for ctr, v in acc.items()}
+        row = {"kernels": sorted(kernels), "counters": c}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            row["traffic_bytes"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        f = [c.get("SQ_INSTS_VALU_FMA_F64"), c.get("SQ_INSTS_VALU_MUL_F64"), c.get("SQ_INSTS_VALU_ADD_F64")]
+        if all(x is not None for x in f):
+            tr = c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+            row["fp64_insts"] = f[0] + f[1] + f[2] + tr
+            row["fp64_flop"] = 64.0 * (2.0 * f[0] + f[1] + f[2] + tr)
+        if "SQ_INSTS_VALU" in c:
+            row["valu_insts"] = c["SQ_INSTS_VALU"]
+        res["rows"][key] = row
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in res["rows"].items()}, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], *(sys.argv[2:3]))
+    if sys.argv[1] == "--json":
+        main_json(sys.argv[2], sys.argv[3], sys.argv[4:])
+    else:
+        main_text(sys.argv[1], *(sys.argv[2:3]))
