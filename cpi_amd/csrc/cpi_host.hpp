@@ -60,14 +60,27 @@ public:
         b_w_lin = b_w_lin_; b_a_lin = b_a_lin_; q_k_lin = q_k_lin_; grav = grav_;
     }
     // Records interval [t_0, t_1] with readings (w_m_0, a_m_0) at t_0 and (w_m_1, a_m_1) at t_1.
+    // Differences from CpiV1::feed_IMU / CpiV2::feed_IMU (CpiV1.h:62-74):
+    //  * t_1 - t_0 < 0: the reference's feed_IMU integrates the interval with the negative dt (only its caller,
+    //    GraphSolver_IMU.cpp:52, skips it); here -- as in the C-ABI -- such an interval is SKIPPED, like dt == 0.
+    //  * imu_avg == false: the closing reading (w_m_1, a_m_1) takes no part in the arithmetic (CpiV1.h:77-86), and callers
+    //    written like the reference's non-averaging use leave it at its default.  The interval then chains to the previous
+    //    one whenever the TIMES chain (t_0 == previous t_1): the previous closing knot is overwritten with (w_m_0, a_m_0)
+    //    and every interval costs ONE knot (no NaN separator, no 3 knots per interval -- the N <= 65535 limit of a window
+    //    would otherwise be reached after ~21 k calls).  Set imu_avg before the first feed_IMU.
     void feed_IMU(double t_0, double t_1, const Vec3 &w_m_0, const Vec3 &a_m_0, const Vec3 &w_m_1 = Vec3{{0, 0, 0}},
                   const Vec3 &a_m_1 = Vec3{{0, 0, 0}}) {
         const size_t n = knots_.size() / 7;
         bool chained = false;
         if (n) {
-            const double *k = &knots_[(n - 1) * 7];
-            chained = k[0] == t_0 && k[1] == w_m_0[0] && k[2] == w_m_0[1] && k[3] == w_m_0[2] && k[4] == a_m_0[0] &&
-                      k[5] == a_m_0[1] && k[6] == a_m_0[2];
+            double *k = &knots_[(n - 1) * 7];
+            if (!imu_avg && k[0] == t_0) {   // times chain, closing readings unused: this interval's reading opens it
+                for (int i = 0; i < 3; i++) { k[1 + i] = w_m_0[i]; k[4 + i] = a_m_0[i]; }
+                chained = true;
+            } else {
+                chained = k[0] == t_0 && k[1] == w_m_0[0] && k[2] == w_m_0[1] && k[3] == w_m_0[2] && k[4] == a_m_0[0] &&
+                          k[5] == a_m_0[1] && k[6] == a_m_0[2];
+            }
         }
         if (!chained) {
             // The reference's feed_IMU only ever uses t_1 - t_0, so intervals need not chain.  A knot whose

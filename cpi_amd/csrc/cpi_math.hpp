@@ -1142,7 +1142,9 @@ CPI_HD NavState predict_state(const NavState &xi, V3 alpha, V3 beta, Q4 q_KtoK1,
 //   (NavState::retract), written here directly in the order [theta b_g v b_a p] the call site swaps it into:
 //       (F x)_theta = E^T x_theta - Jr dt x_bg
 //       (F x)_v     = E^T (x_v - dt ([a]x x_theta + x_ba))
-//       (F x)_p     = E^T (x_p + dt x_v - dt^2/2 ([a]x x_theta + x_ba))
+//       (F x)_p     = E^T (x_p + dt x_v - dt^2/2 [a]x x_theta)      -- no b_a term: the GTSAM the reference pins (c21186c6, 4.0
+//                     era) sets only theta_H_biasOmega and vel_H_biasAcc in CombinedImuFactor ("TODO: should we not also account
+//                     for bias on position?"); pos_H_biasAcc was added to GTSAM years later (round-2 advisor finding)
 //       (F x)_bg = x_bg, (F x)_ba = x_ba
 //       G = diag( (1/dt) (Jr dt) s_w^2 (Jr dt)^T, dt s_wb^2 I, dt s_a^2 I, dt s_ab^2 I, 0 )
 // F does not depend on the running means, so the per-interval records are independent of each other.
@@ -1237,12 +1239,13 @@ CPI_HD void F_apply(const Rec &r, const double *x, double *y) {
     const V3 th = mk(x[0], x[1], x[2]), bg = mk(x[3], x[4], x[5]), v = mk(x[6], x[7], x[8]);
     const V3 ba = mk(x[9], x[10], x[11]), p = mk(x[12], x[13], x[14]);
     const double dt22 = 0.5 * r.dt * r.dt;
-    const V3 c = cross_acc(r.a, th, ba);
+    const V3 cp = cross(r.a, th);      // position row: NO accelerometer-bias term (see the header comment: F(p, b_a) = 0 at c21186c6)
+    const V3 c = cp + ba;              // velocity row: vel_H_biasAcc
     put3(y + 0, mulT_acc(r.E, th, -mul(r.JD, bg)));
     put3(y + 3, bg);
     put3(y + 6, mulT(r.E, axpy(-r.dt, c, v)));
     put3(y + 9, ba);
-    put3(y + 12, mulT(r.E, axpy(-dt22, c, axpy(r.dt, v, p))));
+    put3(y + 12, mulT(r.E, axpy(-dt22, cp, axpy(r.dt, v, p))));
 }
 // x_theta += column j < 3 of G's theta block = (s_w^2/dt) (Jr dt) (Jr dt)^T e_j ; jdrow = row j of Jr dt, on = 1 on
 // the lanes j < 3 and 0 elsewhere

@@ -237,7 +237,9 @@ def default_engine():
 # ---------------------------------------------------------------------- reference-shaped classes
 class _CpiBase:
     """Mirror of CpiBase (CpiBase.h:40-145).  feed_IMU() records the interval; reading any result
-    field runs the whole window through cpi_preintegrate_batch on the GPU (one window = one batch)."""
+    field runs the whole window through cpi_preintegrate_batch on the GPU (one window = one batch).
+    Unlike the reference's feed_IMU (which integrates a negative dt; only its caller skips it, GraphSolver_IMU.cpp:52),
+    an interval with t_1 - t_0 <= 0 is skipped."""
     _model = 0
 
     def __init__(self, sigma_w, sigma_wb, sigma_a, sigma_ab, imu_avg_=False, engine=None):
@@ -271,6 +273,10 @@ class _CpiBase:
         intervals touching it have a NaN dt and are skipped by the kernels)."""
         rows = []
         for (t0, t1, w0, a0, w1, a1) in self._iv:
+            if rows and not self.imu_avg and rows[-1][0] == t0:
+                # imu_avg == False: closing readings take no part in the arithmetic (CpiV1.h:77-86); when the TIMES chain the
+                # previous closing knot simply takes this interval's opening reading (one knot per interval, as in cpi_host.hpp)
+                rows[-1] = np.concatenate([[t0], w0, a0])
             chained = bool(rows) and rows[-1][0] == t0 and np.array_equal(rows[-1][1:4], w0) and np.array_equal(rows[-1][4:7], a0)
             if not chained:
                 if rows:

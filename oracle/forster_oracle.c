@@ -199,7 +199,12 @@ static void fs_integrate(fs_state *s, const cpi_oracle_params *prm, const double
     memset(F, 0, sizeof F);
     for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) F[i * 15 + j] = A[i * 9 + j];
     set9(F, 15, 0, 12, th_H, 1.0);
-    set9(F, 15, 3, 9, pos_H, 1.0);
+    /* F(p, b_a) stays ZERO.  CombinedImuFactor.cpp of the GTSAM the reference pins (commit c21186c6, GTSAM 4.0 era) sets
+     * only F.block<3,3>(0,12) = theta_H_biasOmega and F.block<3,3>(6,9) = vel_H_biasAcc and carries the comment
+     * "TODO(frank): should we not also account for bias on position?"; pos_H_biasAcc = -B.middleRows<3>(3) entered GTSAM
+     * years later.  (Restated from the publication history -- GTSAM is not in the tree; round-1 had the block, the
+     * round-2 advisor flagged it.  With the block P(p, b_a) and what couples to it differ by ~1/n.) */
+    (void)pos_H;
     set9(F, 15, 6, 9, vel_H, 1.0);
     for (int i = 9; i < 15; i++) F[i * 15 + i] = 1.0;
     memset(G, 0, sizeof G);

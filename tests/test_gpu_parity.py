@@ -631,3 +631,64 @@ def test_maximum_window_length(eng, orc, model):
     big = torch.zeros((1, 65537, 7), dtype=torch.float64, device=eng.device)
     with pytest.raises(cpi_amd.CpiError):
         eng.preintegrate(big, lin[:1].to(eng.device), q[:1].to(eng.device), eng.make_params(1), want=("mean",))
+
+
+# --------------------------------------------------------------------------- NaN-separated (non-chained) feed_IMU sequences
+@pytest.mark.parametrize("mode", MODES)
+def test_nan_separated_non_chained_intervals(eng, orc, mode):
+    """The reference's feed_IMU only ever uses t_1 - t_0, so successive calls need not chain; the facades express such a
+    window with NaN-time separator knots (both intervals touching a separator are skipped).  Mean, analytic-Jacobian and
+    covariance kernels -- every lane split of the mean kernel -- against the reference driven by the same knot array
+    (its caller's `dt >= 0` guard, GraphSolver_IMU.cpp:52, skips the NaN intervals as well)."""
+    W, N = 300, 61
+    kn, lin, q = synth.make_windows(W, N, seed=4321 + mode[0] + 2 * mode[1], edge_cases=False)
+    kn, lin, q = kn.numpy().copy(), lin.numpy(), q.numpy()
+    rng = np.random.default_rng(17)
+    for w in range(W):
+        nsep = int(rng.integers(0, 6))
+        pos = rng.choice(np.arange(1, N), size=nsep, replace=False)
+        kn[w, pos, 0] = np.nan
+        kn[w, pos, 1:] = 0.0                              # separators carry zero readings (what the facades emit)
+        if w % 7 == 0:
+            kn[w, N, 0] = np.nan; kn[w, N, 1:] = 0.0       # a separator as the last knot
+        if w % 11 == 0:
+            kn[w, 0, 0] = np.nan; kn[w, 0, 1:] = 0.0       # ... and as the first
+    ref, from_ref = _cpu(orc, mode, kn, lin, q)
+    assert np.all(np.isfinite(ref["alpha"])) and np.all(np.isfinite(ref["P"]))
+    out = _run(eng, mode, kn, lin, q)
+    check_pre(out, ref, v2=(mode[0] == 2), label="nan-separated %s" % (mode,), regression=from_ref)
+    if mode[2] == 1:
+        for lanes in (1, 2, 5, 8, 16, 64):
+            o2 = _run(eng, mode, kn, lin, q, want=("mean",), lanes=lanes)
+            check_pre(o2, ref, what=("mean",), label="nan-separated mean L%d" % lanes, regression=from_ref)
+
+
+@pytest.mark.parametrize("avg", [False, True])
+def test_facade_feed_imu_with_gaps_between_calls(eng, orc, avg):
+    """cpi_amd.CpiV1 / CpiV2.feed_IMU with calls that do not chain in time (a gap after every third call) and -- with
+    imu_avg -- closing readings that differ from the next opening reading: NaN separators are inserted by the facade.
+    Without imu_avg and with chaining times the closing readings are unused and every call costs exactly one knot."""
+    import cpi_amd
+    rng = np.random.default_rng(5)
+    for cls, model in ((cpi_amd.CpiV1, 1), (cpi_amd.CpiV2, 2)):
+        c = cls(0.005, 4e-6, 0.01, 2e-4, avg, engine=eng)
+        bw, ba = 0.01 * rng.standard_normal(3), 0.05 * rng.standard_normal(3)
+        qk = rng.standard_normal(4); qk /= np.linalg.norm(qk); qk *= np.sign(qk[3])
+        c.setLinearizationPoints(bw, ba, qk, np.array([0, 0, 9.8]))
+        t, calls = 100.0, []
+        for k in range(40):
+            w0, a0 = rng.standard_normal(3), np.array([0, 0, 9.8]) + rng.standard_normal(3)
+            w1, a1 = (rng.standard_normal(3), np.array([0, 0, 9.8]) + rng.standard_normal(3)) if avg else (None, None)
+            calls.append((t, t + 0.005, w0, a0, w1, a1))
+            t += 0.005 + (0.1 if k % 3 == 2 else 0.0)
+        for (t0, t1, w0, a0, w1, a1) in calls:
+            c.feed_IMU(t0, t1, w0, a0, w1, a1)
+        knots = c._knots()
+        if not avg:
+            assert knots.shape[0] == 40 + 1 + 2 * 13      # one knot per call + the first + (separator, opener) per gap
+        ref = _cpu_lib(orc).run(orc.make_params(model, int(avg), 1), knots[None], np.concatenate([bw, ba])[None], qk[None])
+        assert abs(c.DT - 40 * 0.005) < 1e-12
+        assert np.abs(c.alpha_tau - ref["alpha"][0]).max() < 2e-13 and np.abs(c.beta_tau - ref["beta"][0]).max() < 2e-13
+        assert np.abs(c.q_k2tau - ref["q"][0]).max() < 2e-13
+        assert cov_rel_err(c.P_meas.T.reshape(1, 225), ref["P"][0:1]) < 1e-12
+        assert np.abs(c.J_a.T.reshape(9) - ref["J_a"][0]).max() < 3e-11
