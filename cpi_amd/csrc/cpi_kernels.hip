@@ -178,6 +178,12 @@ __device__ __forceinline__ double dpp_clone_shr4(double v) {
     const int nhi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0x5, 0x2, false);
     return __hiloint2double(nhi, nlo);
 }
+// lanes 12..15 of every DPP row <- lanes 6..9 of the same row (row_shr:6, bank_mask 0b1000); all other lanes keep `old`.
+__device__ __forceinline__ double dpp_shr6_bank3(double old, double src) {
+    const int nlo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0x116, 0xf, 0x8, false);
+    const int nhi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x116, 0xf, 0x8, false);
+    return __hiloint2double(nhi, nlo);
+}
 // Maximum over the wavefront, wave-uniform result.  DPP reduction (row_shr 1/2/4/8 -> lane 15 of each row holds the row
 // maximum; row_bcast:15 / row_bcast:31 carry it across rows; lane 63 holds the total) instead of six dependent
 // ds_bpermute round trips: it sits on the critical path of every wavefront's start-up.
@@ -853,13 +859,23 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                 cov_stage_M(Ln, stg, Rs, M);
                 if (jj < D::NPCOL) {
 #pragma unroll
-                    for (int rr = 0; rr < 9; rr++) ex_g[rr * EP + exch_pos<MODEL>(jj)] = M[rr];
+                    for (int rr = 0; rr < CovExchRows<MODEL>::V; rr++) ex_g[rr * EP + exch_pos<MODEL>(jj)] = M[rr];
                 }
                 // The exchange is private to this wavefront and a wave's DS instructions execute in issue
                 // order, so the row reads below see the writes above without draining lgkmcnt; only the
                 // COMPILER must not reorder them (no instruction is emitted here).
                 wave_lds_fence();
-                cov_stage_finish(Ln, stg, M, ex_row);
+                if constexpr (CovPBySymmetry<MODEL>::V) {
+                    // rows p of F X = rows v of X = (symmetry) the columns the v lanes hold: lanes 12-14 take them from
+                    // lanes 6-8 by a masked row_shr:6 instead of through LDS (cpi_math.hpp: CovPBySymmetry)
+                    double mt[D::NR];
+                    const double *Xs = cov_stage_X(Ln, stg);
+#pragma unroll
+                    for (int i = 0; i < D::NR; i++) mt[i] = dpp_shr6_bank3(ex_row[exch_pos<MODEL>(i)], Xs[i]);
+                    cov_stage_finish_regs(Ln, stg, M, mt);
+                } else {
+                    cov_stage_finish(Ln, stg, M, ex_row);
+                }
             }
             cov_end(Ln);
             if (MODEL == 2) {  // column clone: columns 15:18 := columns 0:3 (CpiV2.h:436-441)

@@ -921,6 +921,35 @@ CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, const M3 &Rs, double M[9
 // Finish stage s: k = M (rows theta,v,p) + Mt, then X <- P0 + c k and acc += wgt k.  Mt = the row of the
 // exchange buffer selected by cov_read_row (the transposed F X row, a constant noise row, or zeros), so no
 // per-lane condition is left in the arithmetic.
+// Rows p of F X are rows v of X (F_pv = I), and X is symmetric: the transposed contribution a p column needs --
+// row p_k of F X over all columns -- IS column v_k of X, i.e. the registers of the lane that owns v_k.  Where the lane map
+// puts the p lanes in one 4-lane DPP bank and the v lanes a fixed distance below (model 1: lanes 12-14 <- 6-8), the
+// kernel takes them with masked row_shr DPP moves instead of sending 3 of the 9 exchange rows through LDS (the LDS pipe,
+// shared by the 8 wavefronts of a CU, is what bounds the covariance kernels; the VALU has slack).
+template <int MODEL> struct CovPBySymmetry { static const bool V = (MODEL == 1); };
+template <int MODEL> struct CovExchRows { static const int V = CovPBySymmetry<MODEL>::V ? 6 : 9; };   // rows written per stage
+template <int MODEL>
+CPI_HD const double *cov_stage_X(const CovLane<MODEL> &L, int s) { return (s == 0) ? L.P0 : L.X; }
+
+// mt[i] = the transposed contribution to row i (already picked out of the exchange row / taken by symmetry)
+template <int MODEL>
+CPI_HD void cov_stage_finish_regs(CovLane<MODEL> &L, int s, const double M[9], const double *mt) {
+    typedef CovDims<MODEL> D;
+    const double dt = L.dt;
+    const double c = (s == 2) ? dt : 0.5 * dt;               // X for the next stage
+    const double wgt = (s == 0 || s == 3) ? dt * (1.0 / 6.0) : dt * (1.0 / 3.0);
+#pragma unroll
+    for (int i = 0; i < D::NR; i++) {
+        double k = mt[i];
+        if (i < 3) k += M[i];
+        else if (i >= 6 && i < 9) k += M[i - 3];
+        else if (i >= 12 && i < 15) k += M[i - 6];
+        if (s == 0) L.acc[i] = fma(wgt, k, L.P0[i]);
+        else if (s < 3) L.acc[i] = fma(wgt, k, L.acc[i]);
+        if (s < 3) L.X[i] = fma(c, k, L.P0[i]);
+        else L.P0[i] = fma(wgt, k, L.acc[i]);
+    }
+}
 template <int MODEL>
 CPI_HD void cov_stage_finish(CovLane<MODEL> &L, int s, const double M[9], const double *Mt) {
     typedef CovDims<MODEL> D;

@@ -127,10 +127,23 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
                 double M[32][9];
                 for (int j = 0; j < NL; j++) {
                     cov_stage_M(lane[j], st, (st == 0) ? Rs : cov_stage_rotation<MODEL>(ir, st), M[j]);
-                    if (colof[j] < D::NPCOL) for (int rr = 0; rr < 9; rr++) exch[rr * EXCH_PITCH + exch_pos<MODEL>(colof[j])] = M[j][rr];
+                    if (colof[j] < D::NPCOL)
+                        for (int rr = 0; rr < CovExchRows<MODEL>::V; rr++) exch[rr * EXCH_PITCH + exch_pos<MODEL>(colof[j])] = M[j][rr];
                 }
-                for (int j = 0; j < NL; j++)
-                    cov_stage_finish(lane[j], st, M[j], exch.data() + cov_row_off<MODEL>(1, 0, colof[j]));
+                if (CovPBySymmetry<MODEL>::V) {
+                    // the kernel's masked row_shr:6 DPP move: lanes 12..15 take the stage's X of lanes 6..9 as their row
+                    double mt[32][D::NR];
+                    for (int j = 0; j < NL; j++) {
+                        const double *row = exch.data() + cov_row_off<MODEL>(1, 0, colof[j]);
+                        for (int i = 0; i < D::NR; i++) mt[j][i] = row[exch_pos<MODEL>(i)];
+                    }
+                    for (int j = 12; j < 16 && j < NL; j++)
+                        for (int i = 0; i < D::NR; i++) mt[j][i] = cov_stage_X(lane[j - 6], st)[i];
+                    for (int j = 0; j < NL; j++) cov_stage_finish_regs(lane[j], st, M[j], mt[j]);
+                } else {
+                    for (int j = 0; j < NL; j++)
+                        cov_stage_finish(lane[j], st, M[j], exch.data() + cov_row_off<MODEL>(1, 0, colof[j]));
+                }
             }
             Rs = cov_stage_rotation<MODEL>(ir, 3);
             for (int j = 0; j < NL; j++) cov_end(lane[j]);
