@@ -72,12 +72,14 @@ def load():
     lib.cpi_factor_eval_packed_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp]
     lib.cpi_sqrt_information_batch.argtypes = [vp, i64, dp, dp]
     lib.cpi_factor_eval_whitened_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp, dp]
+    lib.cpi_factor_hessian_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp]
     lib.cpi_predict_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, i64, vp, dp]
     lib.cpi_preintegrate_batch_host.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, vp, i64, dp, dp, C.POINTER(CpiOutputs)]
     lib.cpi_factor_eval_batch_host.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp]
     for f in (lib.cpi_ctx_create, lib.cpi_ctx_synchronize, lib.cpi_preintegrate_batch, lib.cpi_factor_eval_batch,
               lib.cpi_sqrt_information_batch, lib.cpi_factor_eval_whitened_batch, lib.cpi_factor_eval_packed_batch,
-              lib.cpi_predict_batch, lib.cpi_preintegrate_batch_host, lib.cpi_factor_eval_batch_host):
+              lib.cpi_predict_batch, lib.cpi_preintegrate_batch_host, lib.cpi_factor_eval_batch_host, lib.cpi_factor_hessian_batch,
+              lib.cpi_group_create, lib.cpi_group_gather, lib.cpi_group_synchronize, lib.cpi_group_size, lib.cpi_ctx_set_stream):
         f.restype = C.c_int
     if lib.cpi_abi_version() != ABI_VERSION:
         raise ImportError("cpi_amd: %s has ABI version %d, this binding expects %d (stale build?)" % (LIB_PATH, lib.cpi_abi_version(), ABI_VERSION))

@@ -1451,6 +1451,98 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
     }
 }
 
+// Hessian contribution of a factor: what GTSAM's linear solver consumes after
+// NoiseModelFactor::linearize (ImuFactorCPIv1.h:82 -> Gaussian::WhitenSystem -> JacobianFactor [A1 A2 | b] with
+// A1 = R H1, A2 = R H2, b = -R e) when it builds a HessianFactor: the augmented information matrix
+//     [A1 A2 b]^T [A1 A2 b]  =  [ G  g ]      G = A^T A (30x30),  g = A^T b,  f = b^T b
+//                               [ g^T f ]
+// 31x31 symmetric, written as its packed upper triangle (column-major packed, LAPACK 'U': entry (i, d), i <= d, at
+// i + d (d + 1) / 2), 496 doubles per factor.  Fused into the whitened sweep: the 31 whitened columns never leave the
+// chip.  16 lanes per factor: lane q < 15 produces columns q of A1 and of A2 (as cpi_factor_kernel), lane 15 the b column;
+// lane q then owns columns q and 30 - q of the result (lane 15: column 15): every lane forms 32 dot products' worth of
+// useful output from two columns held in registers against the 31 columns broadcast from LDS.
+constexpr int HESS_PACKED = 496;
+template <int MODEL>
+__global__ __launch_bounds__(64, 1) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
+    constexpr int LPF = 16, FPW = 4, IN_D = fin::IN_D, CP = 16;   // CP: LDS pitch of a whitened column (15 used, 16-B aligned)
+    __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];
+    __shared__ __attribute__((aligned(16))) double sR[FPW * 225];
+    __shared__ __attribute__((aligned(16))) double sA[FPW * 31 * CP];   // [factor][column][row]
+    __shared__ __attribute__((aligned(16))) double sP[FPW * HESS_PACKED];   // packed output stage (consecutive 16-byte stores)
+    const int lane = threadIdx.x;
+    const int q = lane % LPF, fl = lane / LPF;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const int nf = (int)min((long long)FPW, A.F - f0);
+    factor_fetch_inputs<MODEL, FPW, true>(A, f0, nf, lane, sIn, sR);
+    __syncthreads();
+    const double *in = sIn + fl * IN_D;
+    const FactorMeas m = factor_meas_of(in, A.grav);
+    const double *Rf = sR + fl * 225;
+    double *Af = sA + fl * 31 * CP;
+    auto whiten_col = [&](double *h) {   // in place: out[i] = sum_{k >= i} R[i][k] h[k]  (R upper triangular, column-major)
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = i; k < 15; k++) acc = fma(Rf[k * 15 + i], h[k], acc);
+            h[i] = acc;
+        }
+    };
+    FactorShared S;
+    {
+        V3 e5[5];
+        factor_shared_core<MODEL>(m, S, e5);
+        if (q == 15) {   // b = -R e
+            double h[15];
+#pragma unroll
+            for (int b = 0; b < 5; b++) { h[3 * b] = -e5[b].x; h[3 * b + 1] = -e5[b].y; h[3 * b + 2] = -e5[b].z; }
+            whiten_col(h);
+#pragma unroll
+            for (int i = 0; i < 15; i++) Af[30 * CP + i] = h[i];
+        }
+    }
+    if (q < 15) {
+        const Q4 qi = ldq(m.xi);
+        double h[15];
+        S.bc = q / 3; S.cc = q - 3 * S.bc;
+        S.u = unit(S.cc);
+        S.rku = qrot(qi, S.u);
+        factor_H1_column<MODEL>(S, m, h);
+        whiten_col(h);
+#pragma unroll
+        for (int i = 0; i < 15; i++) Af[q * CP + i] = h[i];
+        factor_H2_column(S, h);
+        whiten_col(h);
+#pragma unroll
+        for (int i = 0; i < 15; i++) Af[(15 + q) * CP + i] = h[i];
+    }
+    wave_lds_fence();
+    // ---- lane q: columns d1 = q and d2 = 30 - q (lane 15: d1 = d2 = 15) against every column c, broadcast from LDS
+    const int d1 = q, d2 = 30 - q;
+    double c1[15], c2[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) { c1[i] = Af[d1 * CP + i]; c2[i] = Af[d2 * CP + i]; }
+    double *Pf = sP + fl * HESS_PACKED;
+    const int o1 = d1 * (d1 + 1) / 2, o2 = d2 * (d2 + 1) / 2;
+#pragma unroll
+    for (int c = 0; c < 31; c++) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+            const double x = Af[c * CP + i];   // same address for the 16 lanes of a factor: LDS broadcast
+            a1 = fma(x, c1[i], a1);
+            a2 = fma(x, c2[i], a2);
+        }
+        // results go to the packed output stage at once (62 accumulators would not fit the register file)
+        if (c <= d1) Pf[o1 + c] = a1;
+        if (c <= d2 && q != 15) Pf[o2 + c] = a2;
+    }
+    wave_lds_fence();
+    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
+    d2u *dst = reinterpret_cast<d2u *>(hess + f0 * HESS_PACKED);
+    for (int i = lane; i < nf * (HESS_PACKED / 2); i += 64) { d2u v; v.a = sP[2 * i]; v.b = sP[2 * i + 1]; dst[i] = v; }
+}
+
 struct PredictArgs {
     long long F;
     double grav[3];
@@ -1882,6 +1974,36 @@ extern "C" int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const
                                               const double *sqrt_info, double *err, double *H1, double *H2) {
     if (ctx && !sqrt_info) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_whitened_batch: sqrt_info is NULL");
     return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, sqrt_info, err, H1, H2);
+}
+
+extern "C" int cpi_factor_hessian_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                        const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                        const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                                        const double *sqrt_info, double *hess) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: model must be 1 or 2");
+    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: negative size");
+    if (F == 0) return CPI_OK;
+    if (!grav || !meas || !lin || !states || !sqrt_info || !hess) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: NULL argument");
+    if (!meas->DT || !meas->alpha || !meas->beta || !meas->q || !meas->J_q || !meas->J_a || !meas->J_b || !meas->H_a || !meas->H_b)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
+    if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
+        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: model 2 needs q_k_lin, O_a, O_b");
+    if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: F exceeds 2^31 - 1 factors per call");
+    if (S <= 0 || (!idx_i && S < F) || (!idx_j && S < F + 1))
+        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: S (number of states) must be >= 1, and >= F + 1 when idx_i / idx_j are NULL");
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    FactorArgs a;
+    memset(&a, 0, sizeof a);
+    a.F = F;
+    for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
+    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j; a.sqrt_info = sqrt_info;
+    const unsigned nb = (unsigned)((F + 3) / 4);
+    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_hessian_kernel<1>), dim3(nb), dim3(64), 0, ctx->stream, a, hess);
+    else hipLaunchKernelGGL((cpi_factor_hessian_kernel<2>), dim3(nb), dim3(64), 0, ctx->stream, a, hess);
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
 }
 
 extern "C" int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,

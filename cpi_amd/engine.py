@@ -187,6 +187,20 @@ class Engine:
                                                           _ptr(states), states.shape[0], _ptr(idx_i), _ptr(idx_j), _ptr(out)))
         return out
 
+    def factor_hessian(self, model, meas, lin, q_k_lin, states, sqrt_info, idx_i=None, idx_j=None, grav=DEFAULT_GRAV, out=None):
+        """[F, 496]: packed upper triangle of the augmented information matrix [A1 A2 b]^T [A1 A2 b] with A = R H, b = -R e
+        (what a GTSAM HessianFactor built from the linearised factor holds); see include/cpi_amd.h."""
+        F = lin.shape[0]
+        if out is None:
+            out = torch.empty((F, 496), dtype=torch.float64, device=self.device)
+        m = self._outputs_struct(meas)
+        g = (C.c_double * 3)(*grav)
+        self._sync_stream()
+        self._check(self.lib.cpi_factor_hessian_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin),
+                                                      _ptr(states), states.shape[0], _ptr(idx_i), _ptr(idx_j),
+                                                      _ptr(sqrt_info), _ptr(out)))
+        return out
+
     def predict(self, model, meas, states_i, idx_i=None, grav=DEFAULT_GRAV):
         F = meas["DT"].shape[0]
         xj = torch.empty((F, 16), dtype=torch.float64, device=self.device)

@@ -169,6 +169,19 @@ int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const double gra
                                    const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                    const double *sqrt_info, double *err, double *H1, double *H2);
 
+/* The same evaluation carried one step further down GTSAM's pipeline: the factor's
+ * contribution to the normal equations.  NoiseModelFactor::linearize turns (e, H1, H2) into the JacobianFactor
+ * [A1 A2 | b] = [R H1, R H2 | -R e]; a HessianFactor built from it holds the augmented information matrix
+ *     [A1 A2 b]^T [A1 A2 b] = [ G  g ; g^T  f ],   G = A^T A (30 x 30),  g = A^T b (30),  f = b^T b,
+ * over the tangent vectors of (state_i, state_j).  hess [F][496]: its upper triangle, packed column-major
+ * (entry (i, d), i <= d <= 30, at i + d (d + 1) / 2; rows / columns 0-14 state_i, 15-29 state_j, 30 the b column).
+ * The whitened Jacobians never leave the chip.  (GTSAM is not in the reference tree: PARITY UNPINNED, checked against a
+ * numpy restatement of the definition above on the outputs of cpi_factor_eval_whitened_batch.) */
+int cpi_factor_hessian_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                             const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                             const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                             const double *sqrt_info, double *hess);
+
 /* Replaces: GraphSolver::getpredictedstate_v1 / _v2 (GraphSolver_IMU.cpp:263-281, 289-307):
  * states_j[f] = prediction of X(k+1) from states_i[idx_i[f]] and measurement f.  states_i [S][16]; idx_i NULL: state f. */
 int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,

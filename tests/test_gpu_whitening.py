@@ -70,3 +70,39 @@ def test_sqrt_information_well_conditioned_and_not_positive_definite(eng):
     assert np.abs(Rg[ok] - Rn).max() < 1e-13
     assert np.array_equal(Rg[4], np.eye(15))
     assert np.isnan(Rg[6]).any()
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_hessian_blocks_of_the_whitened_factor(eng, model):
+    """cpi_factor_hessian_batch: packed upper triangle of [A1 A2 b]^T [A1 A2 b], A = R H, b = -R e --
+    the augmented information matrix a GTSAM HessianFactor built from the linearised factor holds.  Checked against numpy
+    on the outputs of the whitened sweep (itself checked above), with gathered (non-chained) state indices; G must be
+    symmetric positive semi-definite and f = the Mahalanobis distance."""
+    F = 1001
+    kn, lin, q = synth.make_windows(F, 50, seed=92, device=eng.device, edge_cases=False)
+    meas = eng.preintegrate(kn, lin, q, eng.make_params(model))
+    R = eng.sqrt_information(meas["P"])
+    xi, xj = synth.make_states(meas["alpha"], meas["beta"], meas["q"], meas["DT"], lin, model, device=eng.device)
+    states = torch.cat([xi, xj], dim=0).contiguous()
+    ii = torch.arange(F, dtype=torch.int32, device=eng.device)
+    jj = ii + F
+    qq = q if model == 2 else None
+    white = eng.factor_eval(model, meas, lin, qq, states, ii, jj, sqrt_info=R)
+    hess = eng.factor_hessian(model, meas, lin, qq, states, R, ii, jj)
+    torch.cuda.synchronize()
+    A1 = white["H1"].cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1)
+    A2 = white["H2"].cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1)
+    b = -white["err"].cpu().numpy()
+    Ab = np.concatenate([A1, A2, b[:, :, None]], axis=2)                 # [F, 15, 31]
+    ref = np.einsum("fki,fkj->fij", Ab, Ab)                              # [F, 31, 31]
+    iu = [(i, d) for d in range(31) for i in range(d + 1)]               # packed 'U' order: i + d (d + 1) / 2
+    want = np.stack([ref[:, i, d] for (i, d) in iu], axis=1)
+    got = hess.cpu().numpy()
+    assert got.shape == (F, 496)
+    scale = np.abs(want).max(axis=1, keepdims=True)
+    assert (np.abs(got - want) / scale).max() < 1e-12
+    # f = b^T b = e^T P^-1 e
+    e = eng.factor_eval(model, meas, lin, qq, states, ii, jj, want_H=False)["err"].cpu().numpy()
+    P = meas["P"].cpu().numpy().reshape(F, 15, 15)
+    maha = np.einsum("fi,fij,fj->f", e, np.linalg.inv(P), e)
+    assert np.abs(got[:, 495] - maha).max() <= 1e-6 * max(1.0, maha.max())
