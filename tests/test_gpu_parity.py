@@ -434,6 +434,46 @@ def test_config5_one_gpu_share_1M_windows_x_100_samples(eng, orc):
         assert torch.equal(again[k], out[k]), k
 
 
+def test_config5_one_gpu_share_full_v1_1M_windows_x_100_samples(eng, orc):
+    """The FULL-V1 variant of BASELINE configs[4] at one GPU's share (1 M windows x 100 samples: means + analytic bias
+    Jacobians + 15x15 covariance, 2.25 GB of outputs).  Size-independent checks: the means equal the mean-only kernel's
+    bit for bit over the whole batch, every covariance is exactly symmetric with a positive diagonal, a strided sample of
+    128 windows matches the compiled reference at the regression gates, slices re-run on their own agree (bit for bit
+    where one kernel configuration serves every batch size), and the launch is deterministic."""
+    W, N = 1000000, 100
+    kn, lin, q = synth.make_windows(W, N, seed=89, device=eng.device, edge_cases=True)
+    prm = eng.make_params(1)
+    out = eng.preintegrate(kn, lin, q, prm)
+    torch.cuda.synchronize()
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    P = out["P"].view(W, 15, 15)
+    assert torch.equal(P, P.transpose(1, 2))
+    assert (torch.diagonal(P, dim1=1, dim2=2) > 0).all()
+    pick = torch.arange(0, W, 7873, device=eng.device)[:128]
+    ref, from_ref = _cpu(orc, (1, 0, 1), kn[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
+    check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, ref, label="1M x 100 full V1 sample", regression=from_ref)
+    for lo, n in ((0, 4096), (500001, 3001), (W - 1234, 1234)):
+        sl = slice(lo, lo + n)
+        o = eng.preintegrate(kn[sl].contiguous(), lin[sl].contiguous(), q[sl].contiguous(), prm)
+        torch.cuda.synchronize()
+        for k in o:
+            if k in ("DT", "alpha", "beta", "q", "P"):      # covariance kernel: one lane group per window whatever the batch
+                assert torch.equal(o[k], out[k][sl]), (k, lo)
+            else:                                            # analytic Jacobians: the lane split follows the batch size
+                assert (o[k] - out[k][sl]).abs().max().item() < 1e-11, (k, lo)
+    mean_only = eng.preintegrate(kn, lin, q, eng.make_params(1, lanes_per_window=1), want=("mean",))
+    torch.cuda.synchronize()
+    assert torch.equal(mean_only["DT"], out["DT"])
+    for k in ("alpha", "beta", "q"):     # two kernels, two operation orders (column rotation vs prefix products): round-off apart
+        assert (mean_only[k] - out[k]).abs().max().item() < 1e-11, k
+    del mean_only
+    again = eng.preintegrate(kn, lin, q, prm)
+    torch.cuda.synchronize()
+    for k in out:
+        assert torch.equal(again[k], out[k]), k
+
+
 # --------------------------------------------------------------------------- edge sizes and rare branches
 @pytest.mark.parametrize("W,N", [(1, 1), (1, 50), (3, 2), (63, 7), (65, 33), (130, 129), (17, 257)])
 def test_edge_sizes(eng, orc, W, N):
