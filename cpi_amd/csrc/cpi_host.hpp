@@ -42,6 +42,27 @@ private:
     cpi_ctx *ctx_ = nullptr;
 };
 
+// A set of devices of this process (include/cpi_amd.h "Device sets"): one context + stream + RCCL rank per GPU.
+// Windows shard as contiguous blocks (bounds(W, r)); every rank runs the ordinary entries on ctx(r) with pointers into
+// its own device's memory; gather() is the one exchange step (each peer sends its output slab straight to the root).
+class DeviceGroup {
+public:
+    explicit DeviceGroup(int n, const int *devices = nullptr) {
+        if (cpi_group_create(n, devices, &g_) != CPI_OK) throw std::runtime_error(cpi_group_last_error(nullptr));
+    }
+    ~DeviceGroup() { cpi_group_destroy(g_); }
+    DeviceGroup(const DeviceGroup &) = delete;
+    DeviceGroup &operator=(const DeviceGroup &) = delete;
+    int size() const { return cpi_group_size(g_); }
+    cpi_ctx *ctx(int rank) const { return cpi_group_ctx(g_, rank); }
+    void bounds(int64_t W, int rank, int64_t &lo, int64_t &hi) const { cpi_shard_bounds(W, rank, size(), &lo, &hi); }
+    void check(int rc) const { if (rc != CPI_OK) throw std::runtime_error(cpi_group_last_error(g_)); }
+    void gather(int root, int64_t W, const cpi_outputs *local, const cpi_outputs &root_out) { check(cpi_group_gather(g_, root, W, local, &root_out)); }
+    void synchronize() { check(cpi_group_synchronize(g_)); }
+private:
+    cpi_group *g_ = nullptr;
+};
+
 // Results of one window: the public members of CpiBase / CpiV2.
 struct CpiResult {
     double DT = 0;

@@ -502,7 +502,9 @@ __global__ __launch_bounds__(64, 1) void cpi_mean_dma_kernel(PreArgs A) {
     const int rd_off = (lane / G::WPI) * 1024 + (lane % G::WPI) * (G::PPW * 16) + (int)rshift;   // reader: own window's row
 
     const int nst = (nmax + KC - 1) / KC;
+    const int dbg = A.dbg;   // development: 1 = no arithmetic, 2 = no fetch
     auto issue = [&](int st) {
+        if (dbg & 2) return;
         const char *sb = blk + 56 - 16 + (long long)st * (KC * 56);
         const unsigned dst = ring_base + (unsigned)(st % S) * G::SLOT;
 #pragma unroll
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(64, 1) void cpi_mean_dma_kernel(PreArgs A) {
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const int s = st * KC + c;
-            if (s >= nmax) break;                                    // wave-uniform
+            if (s >= nmax || (dbg & 1)) break;                       // wave-uniform
             const double *nk = reinterpret_cast<const double *>(slot + 56 * c);
             double q[7];
 #pragma unroll
@@ -1843,7 +1845,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
         const int LL = pick_lanes(prm, W, N, mean_jac);
         long long done = 0;
         const int bl = mean_blk_forced();
-        if (bl > 0 && getenv("CPI_AMD_BLK_MODE")) m.dbg = atoi(getenv("CPI_AMD_BLK_MODE"));
+        if (getenv("CPI_AMD_BLK_MODE")) m.dbg = atoi(getenv("CPI_AMD_BLK_MODE"));
         if (!mean_jac && !first && bl > 0 && (size_t)(64 / bl) * (size_t)(N + 1) * 56 <= 65536 && N >= 1) {
             if (v2 ? launch_mean_blk<2>(bl, avg, m, ctx->stream) : launch_mean_blk<1>(bl, avg, m, ctx->stream)) done = W;
         }

@@ -106,3 +106,38 @@ def test_factor_indices_are_clamped_on_the_device_and_validated_on_the_host_path
     rc = lib.cpi_factor_eval_batch_host(eng.ctx, 1, gv, F, C.byref(ms), linh.ctypes.data, None, sth.ctypes.data, S,
                                         bi.ctypes.data, None, err.ctypes.data, None, None)
     assert rc == _lib.CPI_ERR_INVALID and b"out of range" in lib.cpi_last_error(eng.ctx)
+
+
+def test_cpp_host_sharding_a_batch_over_the_device_set(golden_dir):
+    """tests/cpp/test_group.cpp: a single-process C++ host (g++, HIP runtime API only) shards the golden batch over the
+    node's GPUs through cpi_host::DeviceGroup, gathers on GPU 0 and must reproduce the compiled reference's golden
+    outputs.  On the 1-GPU test box the set has one device; on an 8-GPU node the same binary runs 8 ranks + RCCL."""
+    import os
+    import subprocess
+    import tempfile
+    from tests.tol import check_pre
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from cpi_amd import _lib
+    _lib.load()
+    exe = os.path.join(tempfile.mkdtemp(), "test_group")
+    libdir = os.path.join(ROOT, "cpi_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "test_group.cpp"), "-o", exe, "-L" + libdir, "-lcpi_amd",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
+    kn, lin, q = d["knots"], d["lin"], d["q_k_lin"]
+    W, n1, _ = kn.shape
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        np.array([W, n1 - 1], dtype=np.float64).tofile(f)
+        kn.tofile(f); lin.tofile(f); q.tofile(f)
+        path = f.name
+    for model in (1, 2):
+        p = subprocess.run([exe, path, str(model)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        rows = np.array([[float(x) for x in ln.split()] for ln in p.stdout.strip().split("\n")])
+        assert rows.shape == (W, 236)
+        got = {"DT": rows[:, 0], "alpha": rows[:, 1:4], "beta": rows[:, 4:7], "q": rows[:, 7:11], "P": rows[:, 11:]}
+        key = "m%d_avg0_stj1__" % model
+        ref = {k[len(key):]: v for k, v in d.items() if k.startswith(key)}
+        check_pre(got, ref, what=("mean", "cov"), regression=True)
+        assert "gathered on rank 0" in p.stderr

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU experiment: block-resident mean kernel (CPI_AMD_MEAN_BLK=L) -- correctness vs the oracle, then launch times.
-cd $GRAFT_REPO_ROOT 2>/dev/null || true
+cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 OUT=gpurun_out/exp_blk.txt
 : > $OUT

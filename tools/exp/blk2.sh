@@ -1,5 +1,5 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT 2>/dev/null || true
+cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 OUT=gpurun_out/exp_blk2.txt
 : > $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU experiment: LDS-DMA mean kernel variants -- correctness vs the oracle, then launch times (run through gpurun).
-cd $GRAFT_REPO_ROOT 2>/dev/null || true
+cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 OUT=gpurun_out/exp_dma.txt
 : > $OUT

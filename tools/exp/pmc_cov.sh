@@ -1,5 +1,5 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT 2>/dev/null || true
+cd ${GRAFT_REPO_ROOT:-.}
 R=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp

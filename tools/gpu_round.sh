@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU session: tests, default bench, dist path with one rank, cfg5 rows, counter list.
-cd $GRAFT_REPO_ROOT 2>/dev/null || true
+cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r02_pytest_gpu.txt; cat gpurun_out/r02_pytest_gpu.txt
 python bench.py --steps 20 --warmup 5 > gpurun_out/r02_bench_default.json 2> gpurun_out/r02_bench_default.err; tail -c 3000 gpurun_out/r02_bench_default.json; tail -5 gpurun_out/r02_bench_default.err

@@ -4,11 +4,11 @@
 # pass per counter group (kernel-trace / stats domains are NOT combined with --pmc), and writes profiles-style JSON stamped
 # with the library's build id.  A row is <workload>:<W>:<N>.
 R=$PWD; OUT=$1; shift
-ROWS=${@:-"v1_mean:10000:50 v1_mean:1000000:50 v1_full:100000:50 v2_full:100000:50 forster_full:100000:50 factor_v1:1000000:50 factor_v2:1000000:50 cfg5_mean:1000000:100"}
+ROWS=${@:-"v1_mean:10000:50 v1_mean:1000000:50 v1_full:100000:50 v2_full:100000:50 forster_full:100000:50 factor_v1:1000000:50 factor_v2:1000000:50 cfg5_mean:1000000:100 cfg5_full:1000000:100"}
 export TMPDIR=/tmp
 D=/tmp/pmc_$$; mkdir -p $D; cd /tmp
 BID=$(python -c "import sys; sys.path.insert(0,'$R'); from cpi_amd import _lib; print(_lib.load().cpi_build_id().decode())")
-SPECS=""
+SPECS=()
 for row in $ROWS; do
   wl=${row%%:*}; rest=${row#*:}; W=${rest%%:*}; N=${rest#*:}
   i=0
@@ -17,7 +17,17 @@ for row in $ROWS; do
     i=$((i+1))
     CPI_MB_SAMPLES=$N timeout 300 rocprofv3 --pmc $grp -d $D/${wl}_${W}_${N} -o g$i -- python $R/tools/microbench.py $wl:$W:0:3 > /dev/null 2> $D/err_${wl}_$i.txt || tail -3 $D/err_${wl}_$i.txt
   done
-  SPECS="$SPECS $row=$D/${wl}_${W}_${N}/**/*.db"
+  case $wl in
+    v1_mean|cfg5_mean) K="cpi_mean_kernel<1, false";;
+    v2_mean) K="cpi_mean_kernel<2, false";;
+    v1_full|cfg5_full) K="cpi_cov_kernel<1;cpi_mean_kernel<1, true";;
+    v2_full) K="cpi_cov_kernel<2";;
+    forster_full) K="cpi_forster_kernel";;
+    factor_v1) K="cpi_factor_kernel<1";;
+    factor_v2) K="cpi_factor_kernel<2";;
+    *) K="cpi_";;
+  esac
+  SPECS+=("$row|$K=$D/${wl}_${W}_${N}/**/*.db")
 done
-python $R/tools/pmc_summary.py --json $BID $R/$OUT $SPECS
+python $R/tools/pmc_summary.py --json $BID $R/$OUT "${SPECS[@]}"
 rm -rf $D

@@ -1,11 +1,12 @@
 """Summarise rocprofv3 --pmc rocpd databases: per-kernel mean of every collected counter (dev tool).
 
     python tools/pmc_summary.py '/tmp/pmc/**/*.db'                      # text table
-    python tools/pmc_summary.py --json BUILD_ID OUT.json ROW=GLOB ...   # profiles/r02_pmc.json for bench.py
+    python tools/pmc_summary.py --json BUILD_ID OUT.json "ROW|KERNEL,KERNEL=GLOB" ...   # profiles/r02_pmc.json for bench.py
 
---json: every ROW is "<workload>:<W>:<N>" (bench.py's key) = a glob of the databases of that row's passes.  Per row the
-counters of the row's DOMINANT kernels (all kernels whose name starts with cpi_, summed per launch of the workload --
-"V1 full" is two kernels) are averaged over launches and converted:
+--json: every ROW is "<workload>:<W>:<N>" (bench.py's key); KERNEL,... are name prefixes of the kernels one step of that
+workload launches ("V1 full" is two kernels: their per-launch totals are added; kernels that only prepare the inputs of a
+row are not listed); GLOB = the databases of that row's passes.  Counters are per-launch totals (instances summed,
+launches averaged) and converted:
     traffic_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024     MI355X_MICROARCH.md "HBM": the counters are KiB and gfx950's
                                                              FETCH_SIZE reports half of a wide streaming read
     fp64_flop     = 64 * (2 * FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64)   wave-level SQ instruction counters x 64 lanes
@@ -17,13 +18,21 @@ import sys
 
 
 def rows_of(db):
+    """(kernel name, counter, per-dispatch TOTAL averaged over dispatches, dispatches).  rocprofv3 stores one row per counter
+    instance (SQ counters: one per XCD / shader engine = 32 on MI355X): the instances of a dispatch are SUMMED, the
+    dispatches averaged."""
     con = sqlite3.connect(db)
     cur = con.cursor()
     try:
-        return cur.execute("select name, counter_name, avg(counter_value), count(*) from pmc_events "
-                           "group by name, counter_name").fetchall()
+        per = cur.execute("select name, counter_name, dispatch_id, sum(counter_value) from pmc_events "
+                          "group by name, counter_name, dispatch_id").fetchall()
     except Exception:
         return []
+    acc = {}
+    for name, ctr, _, val in per:
+        a = acc.setdefault((name, ctr), [0.0, 0])
+        a[0] += val; a[1] += 1
+    return [(name, ctr, tot / n, n) for (name, ctr), (tot, n) in sorted(acc.items())]
 
 
 def short(name):
@@ -43,13 +52,15 @@ def main_json(build_id, out, specs):
                   "means over the timed launches of tools/microbench.py; conversions in tools/pmc_summary.py"}
     for spec in specs:
         key, pattern = spec.split("=", 1)
+        key, want = key.split("|", 1)
+        want = [w.strip() for w in want.split(";") if w.strip()]
         acc, kernels = {}, set()
         for db in sorted(glob.glob(pattern, recursive=True)):
             for name, ctr, val, n in rows_of(db):
-                if "cpi_" in name and "test" not in name:
-                    # per-dispatch mean; a workload that launches two cpi_ kernels per step sums them
-                    acc.setdefault(ctr, {})[short(name)] = val
-                    kernels.add(short(name))
+                sn = short(name)
+                if any(sn.startswith(w) for w in want):
+                    acc.setdefault(ctr, {})[sn] = val
+                    kernels.add(sn)
         c = {ctr: sum(v.values()) for ctr, v in acc.items()}
         row = {"kernels": sorted(kernels), "counters": c}
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
