@@ -1732,6 +1732,7 @@ template <int MODEL>
 static long long launch_mean_dma(const MeanDmaCfg &c, bool avg, const PreArgs &a, hipStream_t st) {
 #define CPI_DMA_CASE(K, S_, A_) if (c.kc == K && c.s == S_ && c.aligned == A_) return launch_mean_dma_one<MODEL, K, S_, (A_ != 0)>(avg, a, st);
     CPI_DMA_CASE(4, 2, 1) CPI_DMA_CASE(4, 2, 0) CPI_DMA_CASE(2, 3, 0) CPI_DMA_CASE(8, 1, 1)
+    CPI_DMA_CASE(4, 1, 0) CPI_DMA_CASE(4, 1, 1) CPI_DMA_CASE(6, 1, 0) CPI_DMA_CASE(6, 2, 0)
 #undef CPI_DMA_CASE
     return 0;
 }
