@@ -1,7 +1,10 @@
 #!/bin/bash
-# Round-2 measurement artefacts (run through gpurun): PMC counters of bench.py's rows (build-stamped JSON), then the
-# kernel-trace summary of the default bench command.
+# Round-2 measurement artefacts (run through gpurun): GPU tests, PMC counters of bench.py's rows (build-stamped JSON), the
+# default bench command with the counters in place, and its kernel-trace summary.
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
-bash tools/pmc_collect.sh gpurun_out/r02_pmc.json > gpurun_out/r02_pmc_collect.log 2>&1; tail -40 gpurun_out/r02_pmc_collect.log
-bash tools/prof_run.sh gpurun_out/r02_kernel_stats.md --steps 20 --warmup 5 > /dev/null 2>&1; cat gpurun_out/r02_kernel_stats.md | head -40
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/r02_pytest_gpu.txt; cat gpurun_out/r02_pytest_gpu.txt
+bash tools/pmc_collect.sh profiles/r02_pmc.json > gpurun_out/r02_pmc_collect.log 2>&1; tail -5 gpurun_out/r02_pmc_collect.log
+cp profiles/r02_pmc.json gpurun_out/r02_pmc.json
+python bench.py --steps 20 --warmup 5 > gpurun_out/r02_bench_default.json 2> gpurun_out/r02_bench_default.err; tail -c 600 gpurun_out/r02_bench_default.json
+bash tools/prof_run.sh gpurun_out/r02_kernel_stats.md --steps 20 --warmup 5 > /dev/null 2>&1; head -12 gpurun_out/r02_kernel_stats.md | cut -c1-160
