@@ -332,7 +332,10 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
     }
     // Dense layout, not one of the last waves: reading a few knots past a short segment's end stays inside
     // the knot array, so every chunk is "block base + chunk stride (scalar) + constant lane offset".
-    const bool safe_overread = (A.first == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W);
+    // (Not with per-window counts: the knots behind a short window's last interval belong to the caller's dense array and
+    // may never have been written -- a NaN there would reach the state through 0 * NaN on the inactive steps.  The
+    // per-element path below stops at the segment's end and re-reads its last, valid knot instead.)
+    const bool safe_overread = (A.first == nullptr) && (A.count == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W);
     auto issue = [&](int it) {
         if (safe_overread) {
             // scalar base (advanced by SALU) + constant 32-bit lane offsets: no vector arithmetic per element
@@ -1851,7 +1854,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
             if (v2 ? launch_mean_blk<2>(bl, avg, m, ctx->stream) : launch_mean_blk<1>(bl, avg, m, ctx->stream)) done = W;
         }
         const MeanDmaCfg dc = mean_dma_cfg();
-        if (!done && !mean_jac && LL == 1 && !first && dc.kc > 0 && N >= 2 * dc.kc)
+        if (!done && !mean_jac && LL == 1 && !first && !count && dc.kc > 0 && N >= 2 * dc.kc)
             done = v2 ? launch_mean_dma<2>(dc, avg, m, ctx->stream) : launch_mean_dma<1>(dc, avg, m, ctx->stream);
         if (done < W) {
             const PreArgs t = done ? shift_windows(m, done) : m;

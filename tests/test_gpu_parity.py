@@ -732,3 +732,35 @@ def test_facade_feed_imu_with_gaps_between_calls(eng, orc, avg):
         assert np.abs(c.q_k2tau - ref["q"][0]).max() < 2e-13
         assert cov_rel_err(c.P_meas.T.reshape(1, 225), ref["P"][0:1]) < 1e-12
         assert np.abs(c.J_a.T.reshape(9) - ref["J_a"][0]).max() < 3e-11
+
+
+def test_dense_layout_with_counts_ignores_the_unwritten_tail_knots(eng, orc):
+    """Dense layout knots[W][N+1][7] with per-window counts: the knots behind a window's last interval are the caller's
+    to leave unwritten.  NaN / Inf there must not reach any output of any kernel (mean kernel at every lane split, analytic
+    Jacobians, covariance of both models, the Forster comparator)."""
+    W, N = 517, 40
+    kn, lin, q = synth.make_windows(W, N, seed=246, edge_cases=False)
+    kn, lin, q = kn.numpy().copy(), lin.numpy(), q.numpy()
+    rng = np.random.default_rng(8)
+    lens = rng.integers(0, N + 1, W).astype(np.int32)
+    lens[:4] = [0, 1, N, N - 1]
+    for w in range(W):
+        kn[w, lens[w] + 1:, :] = np.nan if w % 2 else np.inf
+    for mode in [(1, 0, 1), (1, 1, 1), (2, 0, 1), (2, 1, 0)]:
+        ref = {}
+        oprm = orc.make_params(*mode)
+        rows = [_cpu_lib(orc).run(oprm, kn[w:w + 1, :lens[w] + 1], lin[w:w + 1], q[w:w + 1]) for w in range(W)]
+        for k in rows[0]:
+            ref[k] = np.concatenate([r[k] for r in rows], axis=0)
+        prm = eng.make_params(*mode)
+        out = _host(eng.preintegrate(_dev(kn, eng), _dev(lin, eng), _dev(q, eng), prm, count=_dev(lens, eng), N=N))
+        for k, v in out.items():
+            assert np.all(np.isfinite(v)), (mode, k)
+        check_pre(out, ref, v2=(mode[0] == 2), label="dense+count %s" % (mode,), regression=orc.reference() is not None)
+        for lanes in (0, 1, 2, 3, 6, 8, 16, 64):
+            prm = eng.make_params(*mode, lanes_per_window=lanes)
+            o2 = _host(eng.preintegrate(_dev(kn, eng), _dev(lin, eng), _dev(q, eng), prm, want=("mean",), count=_dev(lens, eng), N=N))
+            assert all(np.all(np.isfinite(v)) for v in o2.values()), (mode, lanes)
+            check_pre(o2, ref, what=("mean",), label="dense+count mean L%d %s" % (lanes, mode))
+    fo = _host(eng.preintegrate(_dev(kn, eng), _dev(lin, eng), None, eng.make_params(3), count=_dev(lens, eng), N=N))
+    assert all(np.all(np.isfinite(v)) for v in fo.values())
