@@ -123,6 +123,15 @@ class Workload:
         self.outs = [eng.alloc_outputs(W, self.want, self.model, packed=True)
                      for _ in range(1 if out_bytes > (1 << 30) else min(self.nbatch, 4))]
         self.i = 0
+        # every (batch, output set) pair of the walk pre-bound: a step is one foreign call (Engine.bind_preintegrate)
+        import math
+        period = self.nbatch * len(self.outs) // math.gcd(self.nbatch, len(self.outs))
+        self.calls = []
+        for i in range(period):
+            kn, lin, q = self.batches[i % self.nbatch]
+            call, _ = eng.bind_preintegrate(kn, lin, q if self.model != 3 else None, self.prm, want=self.want,
+                                            out=self.outs[i % len(self.outs)])
+            self.calls.append(call)
 
     def step(self):
         if self.is_factor:
@@ -131,10 +140,9 @@ class Workload:
                 return {"packed": self.out}
             self.eng.factor_eval(self.model, self.meas, self.lin, self.q, self.states, out=self.out)
             return self.out
-        kn, lin, q = self.batches[self.i % self.nbatch]
         out = self.outs[self.i % len(self.outs)]
+        self.calls[self.i % len(self.calls)]()
         self.i += 1
-        self.eng.preintegrate(kn, lin, q if self.model != 3 else None, self.prm, want=self.want, out=out)
         return out
 
 

@@ -64,3 +64,30 @@ def test_forster_kernel_math(golden_dir, fname):
     check_pre(out, ref, what=("mean", "jac", "cov"))
     for k in ("alpha", "beta", "q", "J_q", "J_a", "J_b", "H_a", "H_b"):
         assert np.abs(out[k] - ref[k]).max() < 1e-12, k
+
+
+@pytest.mark.parametrize("model,avg", [(1, 0), (1, 1), (2, 0), (2, 1)])
+def test_nan_separated_windows_kernel_math(model, avg):
+    """Non-chained feed_IMU sequences as the facades encode them: NaN-time separator knots carrying zero readings (both
+    intervals touching one are skipped).  Kernel logic of the mean (several lane splits), analytic-Jacobian and covariance
+    paths on the host, against the reference (compiled, when present) driven by the same knot arrays."""
+    from cpi_amd import synth
+    W, N = 40, 37
+    kn, lin, q = synth.make_windows(W, N, seed=9090 + model + 2 * avg, edge_cases=False)
+    kn, lin, q = kn.numpy().copy(), lin.numpy(), q.numpy()
+    rng = np.random.default_rng(3)
+    for w in range(W):
+        pos = rng.choice(np.arange(0, N + 1), size=int(rng.integers(0, 5)), replace=False)
+        kn[w, pos, 0] = np.nan
+        kn[w, pos, 1:] = 0.0
+    lib = op.reference() or op.oracle()
+    ref = lib.run(op.make_params(model, avg, 1), kn, lin, q)
+    assert np.all(np.isfinite(ref["P"]))
+    for L in ((1, 4, 16, 64) if model == 1 else (1, 6)):
+        out = op.split_out(hs.mean(model, 0, avg, L, kn, lin, q))
+        check_pre(out, ref, what=("mean",), label="hostsim mean L%d" % L, regression=True)
+    out = op.split_out(hs.cov(model, avg, kn, lin, q))
+    check_pre(out, ref, what=("mean", "cov", "jac") if model == 2 else ("mean", "cov"), v2=(model == 2), regression=True)
+    if model == 1:
+        out = op.split_out(hs.mean(1, 1, avg, 1, kn, lin, q))
+        check_pre(out, ref, what=("mean", "jac"), regression=True)
