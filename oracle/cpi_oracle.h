@@ -9,11 +9,15 @@
  *   - cpi_oracle_window (CpiV1 / CpiV2 feed_IMU): PINNED against the reference's own headers,
  *     compiled unchanged from /root/reference into oracle/_ref/libcpi_ref.so (see Makefile,
  *     ref_shim.cpp) and against the committed golden vectors in tests/golden/.
+ *   - cpi_oracle_quat_ops (the quat_ops.h helpers every function below is built from: rot_2_quat,
+ *     skew_x, quat_2_Rot, quat_multiply, Exp, Inv): PINNED to the reference's own functions, compiled
+ *     into oracle/_ref (ref_shim.cpp: cpi_ref_quat_ops) and to tests/golden/quat_ops.npz (<= 1e-15).
  *   - cpi_oracle_factor_v1/v2 (ImuFactorCPIv1/v2::evaluateError), cpi_oracle_predict,
- *     cpi_oracle_retract: PARITY UNPINNED.  The reference translation units need GTSAM + Boost,
- *     which are not in this image, and stand-in headers are not allowed; the reference has no
- *     tests or golden vectors for them.  They are a line-by-line restatement, cross-checked
- *     by finite differences against JPLNavState::retract semantics (tests/test_factor_oracle.py).
+ *     cpi_oracle_retract: the BLOCK ASSEMBLY is PARITY UNPINNED.  The reference translation units
+ *     need GTSAM + Boost, which are not in this image, and stand-in headers are not allowed; the
+ *     reference has no tests or golden vectors for them.  They are a line-by-line restatement on top
+ *     of the pinned helpers, cross-checked by finite differences against JPLNavState::retract
+ *     semantics (tests/test_factor_oracle.py; on the device: tests/test_gpu_quat_ops.py).
  *   - cpi_oracle_forster_window (the GTSAM "Forster discrete" comparator): PARITY UNPINNED, GTSAM is absent;
  *     see the header of forster_oracle.c for what it restates and what the tests pin instead.
  *
