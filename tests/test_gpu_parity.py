@@ -764,3 +764,46 @@ def test_dense_layout_with_counts_ignores_the_unwritten_tail_knots(eng, orc):
             check_pre(o2, ref, what=("mean",), label="dense+count mean L%d %s" % (lanes, mode))
     fo = _host(eng.preintegrate(_dev(kn, eng), _dev(lin, eng), None, eng.make_params(3), count=_dev(lens, eng), N=N))
     assert all(np.all(np.isfinite(v)) for v in fo.values())
+
+
+def test_calls_are_capturable_into_a_hip_graph(eng):
+    """The device-pointer entries only enqueue kernels on the context's stream (no allocation, no synchronisation), and the
+    Python engine follows torch's current stream: a caller can capture a re-linearisation round -- preintegration, square-root
+    information, whitened evaluateError -- into ONE HIP graph and replay it.  Replays must reproduce the eager results bit
+    for bit, also after the inputs changed in place."""
+    W = 2000
+    kn, lin, q = synth.make_windows(W, 50, seed=404, device=eng.device)
+    prm = eng.make_params(2)
+    meas = eng.alloc_outputs(W, ("mean", "jac", "cov"), 2)
+    xi = torch.zeros((W + 1, 16), dtype=torch.float64, device=eng.device); xi[:, 3] = 1.0
+    out = {"err": torch.empty((W, 15), dtype=torch.float64, device=eng.device),
+           "H1": torch.empty((W, 225), dtype=torch.float64, device=eng.device),
+           "H2": torch.empty((W, 225), dtype=torch.float64, device=eng.device)}
+    R = torch.empty((W, 225), dtype=torch.float64, device=eng.device)
+
+    def round_():
+        eng.preintegrate(kn, lin, q, prm, out=meas)
+        eng.lib.cpi_sqrt_information_batch(eng.ctx, W, meas["P"].data_ptr(), R.data_ptr())
+        eng.factor_eval(2, meas, lin, q, xi, out=out, sqrt_info=R)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        round_()                                            # warm-up on the side stream, as graph capture requires
+    torch.cuda.synchronize()
+    eager = {k: v.clone() for k, v in out.items()}
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        round_()
+    for v in out.values():
+        v.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in out:
+        assert torch.equal(out[k], eager[k]), k
+    kn[:, :, 1:4] *= 1.01                                   # new measurements in the same buffers
+    g.replay()
+    torch.cuda.synchronize()
+    replayed = {k: v.clone() for k, v in out.items()}
+    round_()
+    torch.cuda.synchronize()
+    for k in out:
+        assert torch.equal(out[k], replayed[k]) and not torch.equal(out[k], eager[k]), k
