@@ -378,10 +378,18 @@ def main():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     if rank == 0 and world != a.gpus:
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d\n" % (a.gpus, world, world))
+    # CPI_BENCH_SINGLE_DEVICE=1: rehearsal of the N-rank flow on a box with ONE GPU (tests/test_gpu_group.py) -- every rank
+    # computes on cuda:0 and the exchange goes through gloo (RCCL refuses two ranks on one device).  Not a measurement.
+    rehearsal = bool(os.environ.get("CPI_BENCH_SINGLE_DEVICE"))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import cpi_amd
     from cpi_amd.dist import shard_bounds
     eng = cpi_amd.Engine(device=local_rank)
@@ -405,7 +413,7 @@ def main():
         wall_ng, _ = time_steps(wl, a.steps, min(a.warmup, 5), dist_on, "none")
     if dist_on:
         import torch.distributed as dist
-        t = torch.tensor([wall, kern_ms, wall_ng or 0.0], dtype=torch.float64, device=eng.device)
+        t = torch.tensor([wall, kern_ms, wall_ng or 0.0], dtype=torch.float64, device="cpu" if rehearsal else eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kern_ms, wall_ng = t[0].item(), t[1].item(), (t[2].item() if wall_ng is not None else None)
     value = total_units * a.steps / wall
@@ -422,7 +430,7 @@ def main():
         "value": value, "unit": unit + "/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
         "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo exchange -- not a measurement)",
         "config": {"workload": "%s: %d %s x %d samples per GPU per step%s" % (a.workload, W, unit, N, cfg_note),
                    "pool_batches": wl.nbatch, "clock_preramp_ms": PRERAMP_MS, "library_build": build_id,
                    "parallelism": ("1 GPU" if world == 1 else

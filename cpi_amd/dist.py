@@ -92,12 +92,18 @@ def gather_to_root(flat, fields, W_local, dst=0, group=None, out=None):
     rank = dist.get_rank(group)
     lay, total = pack_layout(fields, W_local)
     assert flat.numel() == total and flat.is_contiguous()
+    # gloo (the CPU test backend; also bench.py's single-device rehearsal) moves host memory: device slabs are staged
+    staged = flat.is_cuda and dist.get_backend(group) == "gloo"
+    src = flat.cpu() if staged else flat
     if rank == dst:
         full = out if out is not None else torch.empty((world, total), dtype=flat.dtype, device=flat.device)
         assert full.shape == (world, total) and full.is_contiguous()
-        dist.gather(flat, [full[r] for r in range(world)], dst=dst, group=group)
+        recv = torch.empty((world, total), dtype=flat.dtype) if staged else full
+        dist.gather(src, [recv[r] for r in range(world)], dst=dst, group=group)
+        if staged:
+            full.copy_(recv)
         return {name: full[:, off:off + n * W_local].view(world, W_local, n) for name, (off, n) in lay.items()}
-    dist.gather(flat, None, dst=dst, group=group)
+    dist.gather(src, None, dst=dst, group=group)
     return None
 
 

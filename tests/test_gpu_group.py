@@ -141,3 +141,28 @@ def test_cpp_host_sharding_a_batch_over_the_device_set(golden_dir):
         ref = {k[len(key):]: v for k, v in d.items() if k.startswith(key)}
         check_pre(got, ref, what=("mean", "cov"), regression=True)
         assert "gathered on rank 0" in p.stderr
+
+
+def test_bench_gpus_2_end_to_end_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: re-executes under torch.distributed.run with two ranks, shards, runs
+    the kernels, gathers the last step's slabs to rank 0, reduces the timing over the ranks and prints ONE line with
+    n_gpus = 2.  On this 1-GPU box both ranks compute on cuda:0 and the exchange goes through gloo
+    (CPI_BENCH_SINGLE_DEVICE=1: RCCL refuses two ranks on one device) -- a rehearsal of the control flow, not a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["CPI_BENCH_SINGLE_DEVICE"] = "1"
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    for extra in ([], ["--workload", "v2_full", "--windows", "20000", "--scaling", "strong"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extra",
+                            "--no-cpu"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 5
+        assert "value_without_gather" in d["config"] and d["config"]["value_without_gather"] >= d["value"] * 0.5
+        assert d["scaling"] == ("strong" if extra else "weak")
+        assert "REHEARSAL" in d["data"]
