@@ -1579,6 +1579,10 @@ struct cpi_ctx {
     int device;
     hipStream_t stream;
     std::string err;
+    // side stream + fork / join events (created at the first use): the two INDEPENDENT kernels of a "model 1, everything"
+    // request (covariance kernel; analytic-Jacobian kernel) run concurrently -- see cpi_preintegrate_batch
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 static thread_local std::string g_create_err;
 
@@ -1631,7 +1635,19 @@ extern "C" int cpi_ctx_create(int device, void *stream, cpi_ctx **out) {
     *out = c;
     return CPI_OK;
 }
-extern "C" void cpi_ctx_destroy(cpi_ctx *ctx) { delete ctx; }
+extern "C" void cpi_ctx_destroy(cpi_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->side) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamDestroy(ctx->side);
+        (void)hipEventDestroy(ctx->ev_fork);
+        (void)hipEventDestroy(ctx->ev_join);
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    delete ctx;
+}
 extern "C" int cpi_ctx_set_stream(cpi_ctx *ctx, void *stream) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     ctx->stream = (hipStream_t)stream;
@@ -1835,6 +1851,24 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     const bool run_cov = want_cov || (stj && want_jac);
     const bool mean_jac = want_jac && !stj;
     const bool run_mean = mean_jac || (want_mean && !run_cov);
+    // Model 1 with Jacobians AND covariance is two independent kernels over the same knots (disjoint outputs).  The
+    // covariance kernel waits on the LDS pipe about as much as it issues VALU work and uses no more than two wavefronts per
+    // SIMD; the Jacobian kernel is pure FP64 VALU with no LDS: issued on a side stream (fork / join by events, so everything
+    // later on the context's stream still waits for both, and a stream capture sees an ordinary fork) they share the SIMDs.
+    static const bool overlap_on = [] { const char *e = getenv("CPI_AMD_NO_OVERLAP"); return !(e && atoi(e)); }();
+    hipStream_t mean_stream = ctx->stream;
+    bool forked = false;
+    if (run_cov && run_mean && mean_jac && overlap_on) {
+        if (!ctx->side) {
+            CPI_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            CPI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            CPI_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        CPI_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        CPI_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        mean_stream = ctx->side;
+        forked = true;
+    }
     if (run_cov) {
         PreArgs c = a;
         c.write_means = want_mean ? 1 : 0;
@@ -1849,7 +1883,8 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
         const int LL = pick_lanes(prm, W, N, mean_jac);
         long long done = 0;
         const int bl = mean_blk_forced();
-        if (getenv("CPI_AMD_BLK_MODE")) m.dbg = atoi(getenv("CPI_AMD_BLK_MODE"));
+        static const int dbg_mode = [] { const char *e = getenv("CPI_AMD_BLK_MODE"); return e ? atoi(e) : 0; }();   // development only
+        m.dbg = dbg_mode;
         if (!mean_jac && !first && bl > 0 && (size_t)(64 / bl) * (size_t)(N + 1) * 56 <= 65536 && N >= 1) {
             if (v2 ? launch_mean_blk<2>(bl, avg, m, ctx->stream) : launch_mean_blk<1>(bl, avg, m, ctx->stream)) done = W;
         }
@@ -1858,8 +1893,12 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
             done = v2 ? launch_mean_dma<2>(dc, avg, m, ctx->stream) : launch_mean_dma<1>(dc, avg, m, ctx->stream);
         if (done < W) {
             const PreArgs t = done ? shift_windows(m, done) : m;
-            if (v2) launch_mean<2>(mean_jac, avg, LL, t, ctx->stream); else launch_mean<1>(mean_jac, avg, LL, t, ctx->stream);
+            if (v2) launch_mean<2>(mean_jac, avg, LL, t, mean_stream); else launch_mean<1>(mean_jac, avg, LL, t, mean_stream);
         }
+    }
+    if (forked) {
+        CPI_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+        CPI_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
@@ -2051,6 +2090,7 @@ static double **out_field(cpi_outputs *o, int k) {
 // rccl/rccl.h:236) -- the reference is a single process too; multi-process hosts (one rank per GPU, torch.distributed)
 // use cpi_amd/dist.py, which issues the same send / recv pattern through ProcessGroupNCCL.
 #include <dlfcn.h>
+#include <mutex>
 #include <vector>
 namespace {
 struct Rccl {
@@ -2063,7 +2103,9 @@ struct Rccl {
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string err;
-    bool load() {
+    std::mutex mu;
+    bool load() {   // serialised: two host threads may create their first groups at the same time
+        std::lock_guard<std::mutex> lock(mu);
         if (h) return true;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);

@@ -781,13 +781,21 @@ def test_calls_are_capturable_into_a_hip_graph(eng):
            "H2": torch.empty((W, 225), dtype=torch.float64, device=eng.device)}
     R = torch.empty((W, 225), dtype=torch.float64, device=eng.device)
 
+    prm1 = eng.make_params(1)
+    meas1 = eng.alloc_outputs(W, ("mean", "jac", "cov"), 1)    # model 1, everything: two kernels forked onto a side stream
+    out1 = {"err": torch.empty((W, 15), dtype=torch.float64, device=eng.device)}
+
     def round_():
         eng.preintegrate(kn, lin, q, prm, out=meas)
         eng.lib.cpi_sqrt_information_batch(eng.ctx, W, meas["P"].data_ptr(), R.data_ptr())
         eng.factor_eval(2, meas, lin, q, xi, out=out, sqrt_info=R)
+        eng.preintegrate(kn, lin, q, prm1, out=meas1)
+        eng.factor_eval(1, meas1, lin, None, xi, out=out1, want_H=False)
+        out["err1"] = out1["err"]
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         round_()                                            # warm-up on the side stream, as graph capture requires
+    torch.cuda.synchronize()
     torch.cuda.synchronize()
     eager = {k: v.clone() for k, v in out.items()}
     g = torch.cuda.CUDAGraph()
