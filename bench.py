@@ -268,14 +268,54 @@ def cpu_baseline(wl, min_seconds=8.0):
         el = time.perf_counter() - t0
         if el >= min_seconds:
             break
+    port = None
+    if wl.model in (1, 2):
+        port = sparse_port_rate(wl, kn, lin, q, cores, min(2.0, min_seconds / 3))
     ws = min(Wc, (1500 if wl.model == 1 else 600) * 50 // max(50, wl.N))
     t1 = time.perf_counter(); lib.run(prm, kn[:ws], lin[:ws], q[:ws], nthreads=1); t1 = time.perf_counter() - t1
     what = {1: "CpiV1::feed_IMU", 2: "CpiV2::feed_IMU (state_transition_jacobians = true)", 3: "the Forster comparator restatement"}[wl.model]
     note = "" if "cov" in wl.want else "; the reference has no mean-only mode: this CPU figure includes bias Jacobians and covariance, the GPU row does not"
-    return {"value": done / el, "unit": "windows/s", "cores": cores, "kind": kind, "single_core_value": ws / t1,
-            "sample": "%d passes over %d of the row's %d-sample windows through %s, %d threads (= usable CPUs: affinity mask "
-                      "capped by the cgroup quota; %d logical CPUs visible)%s"
-                      % (done // Wc, Wc, wl.N, what, cores, os.cpu_count() or 1, note)}
+    res = {"value": done / el, "unit": "windows/s", "cores": cores, "kind": kind, "single_core_value": ws / t1,
+           "sample": "%d passes over %d of the row's %d-sample windows through %s, %d threads (= usable CPUs: affinity mask "
+                     "capped by the cgroup quota; %d logical CPUs visible)%s"
+                     % (done // Wc, Wc, wl.N, what, cores, os.cpu_count() or 1, note)}
+    if port:
+        res["sparse_port"] = port
+    return res
+
+
+def sparse_port_rate(wl, kn, lin, q, cores, seconds):
+    """Second CPU figure beside the dense reference (SURVEY.md 8(d) asks for both): the kernels' OWN sparse arithmetic
+    (cpi_amd/csrc/cpi_math.hpp compiled for the host by tests/hostsim -- column-lane covariance recursion, or the mean-only
+    recursion for mean-only rows, which is the LIKE-FOR-LIKE CPU figure the reference cannot give: it has no mean-only
+    mode), on the same windows, all usable cores and one core.  g++ -O2, no hand vectorisation: a port, not a tuned CPU code."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import hostsim_py as hs
+    mean_only = "cov" not in wl.want
+    Wc = kn.shape[0]
+
+    def run(lo, hi):
+        if mean_only:
+            hs.mean(wl.model, 0, 0, 1, kn[lo:hi], lin[lo:hi], q[lo:hi])
+        else:
+            hs.cov(wl.model, 0, kn[lo:hi], lin[lo:hi], q[lo:hi])
+            if wl.model == 1:
+                hs.mean(1, 1, 0, 1, kn[lo:hi], lin[lo:hi], q[lo:hi])      # model 1: the analytic Jacobians are a second pass
+    hs.lib()
+    n1 = min(Wc, 2000 if mean_only else 200)
+    t = time.perf_counter(); run(0, n1); t = time.perf_counter() - t
+    single = n1 / t
+    Wp = int(min(Wc, max(cores * 16, single * cores * seconds)))
+    cuts = [Wp * i // cores for i in range(cores + 1)]
+    with ThreadPoolExecutor(cores) as ex:
+        t = time.perf_counter()
+        list(ex.map(lambda i: run(cuts[i], cuts[i + 1]), range(cores)))
+        t = time.perf_counter() - t
+    return {"value": Wp / t, "unit": "windows/s", "cores": cores, "kind": "port", "single_core_value": single,
+            "what": ("mean-only recursion (like for like with the GPU row)" if mean_only else
+                     "sparse column-lane covariance recursion" + (" + analytic Jacobians" if wl.model == 1 else " with the state-transition Jacobians")),
+            "sample": "%d of the row's windows over %d threads; %d on one thread" % (Wp, cores, n1)}
+
 
 
 # ------------------------------------------------------------------------------------------------ counters
