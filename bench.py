@@ -49,6 +49,9 @@ WORKLOADS = {
     # packed evaluateError (state-dependent blocks only, include/cpi_amd.h): NOT the dense GTSAM-shaped output
     "factor_v1_packed": dict(model=1, factor=True, packed=True, W=1000000, N=50, bytes=776 + 576, kernel="cpi_factor_packed_kernel<1>"),
     "factor_v2_packed": dict(model=2, factor=True, packed=True, W=1000000, N=50, bytes=952 + 576, kernel="cpi_factor_packed_kernel<2>"),
+    # the same mean-only recursion on the TILED input layout (knots of 64 windows interleaved per step; include/cpi_amd.h)
+    "v1_mean_tiled": dict(model=1, want=("mean",), W=1000000, N=50, bytes=2856 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<1,false,false>"),
+    "v2_mean_tiled": dict(model=2, want=("mean",), W=1000000, N=50, bytes=2888 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<2,false,false>"),
     # BASELINE configs[4]: one GPU's share of 8 M windows x 100 samples (EuRoC-rate synthetic IMU), generated on the device
     "cfg5_mean": dict(model=1, want=("mean",), W=1000000, N=100, bytes=2856 + 88, kernel="cpi_mean_kernel<1,false,false,1>"),
     "cfg5_full": dict(model=1, want=("mean", "jac", "cov"), W=1000000, N=100, bytes=2856 + 2320, kernel="cpi_cov_kernel<1,false>"),
@@ -123,14 +126,23 @@ class Workload:
         self.outs = [eng.alloc_outputs(W, self.want, self.model, packed=True)
                      for _ in range(1 if out_bytes > (1 << 30) else min(self.nbatch, 4))]
         self.i = 0
-        # every (batch, output set) pair of the walk pre-bound: a step is one foreign call (Engine.bind_preintegrate)
+        self.tiled = bool(spec.get("tiled"))
         import math
+        if self.tiled:   # the batches converted once, untimed: the timed step reads tiles only
+            self.tiles = [eng.tile_knots(b[0]) for b in self.batches]
+            torch.cuda.synchronize()
+            for bi in range(self.nbatch):
+                self.batches[bi] = (self.batches[bi][0][:64].clone(), self.batches[bi][1], self.batches[bi][2])   # the dense copy is dropped (lin / q stay)
+        # every (batch, output set) pair of the walk pre-bound: a step is one foreign call (Engine.bind_preintegrate)
         period = self.nbatch * len(self.outs) // math.gcd(self.nbatch, len(self.outs))
         self.calls = []
         for i in range(period):
             kn, lin, q = self.batches[i % self.nbatch]
-            call, _ = eng.bind_preintegrate(kn, lin, q if self.model != 3 else None, self.prm, want=self.want,
-                                            out=self.outs[i % len(self.outs)])
+            if self.tiled:
+                call, _ = eng.preintegrate_tiled(self.tiles[i % self.nbatch], W, lin, q, self.prm, out=self.outs[i % len(self.outs)], bind=True)
+            else:
+                call, _ = eng.bind_preintegrate(kn, lin, q if self.model != 3 else None, self.prm, want=self.want,
+                                                out=self.outs[i % len(self.outs)])
             self.calls.append(call)
 
     def step(self):
@@ -499,7 +511,7 @@ def main():
                                 ("v1_full", 100000, 30), ("v2_full", 100000, 30), ("forster_full", 100000, 30),
                                 ("factor_v1", 1000000, 40), ("factor_v2", 1000000, 40),
                                 ("factor_v1_packed", 1000000, 40), ("factor_v2_packed", 1000000, 40),
-                                ("cfg5_mean", 1000000, 10), ("cfg5_full", 1000000, 3)):
+                                ("cfg5_mean", 1000000, 10), ("cfg5_full", 1000000, 3), ("v1_mean_tiled", 1000000, 40)):
             try:
                 Nx = WORKLOADS[name]["N"]
                 w2 = Workload(eng, name, Wx, Nx, seed=4242)
@@ -508,7 +520,7 @@ def main():
                 row = {"workload": name, "units_per_step": Wx, "samples": Nx, "value": Wx * steps / wall2,
                        "unit": ("factors" if w2.is_factor else "windows") + "/s", "launch_ms": ls * 1e3,
                        "roofline": roofline_of(name, Wx, Nx, ls, pmc_rows, pmc_note)}
-                if not a.no_cpu and not name.endswith("_packed") and not (name == "v1_mean" and Wx != 1000000):
+                if not a.no_cpu and not name.endswith("_packed") and not name.endswith("_tiled") and not (name == "v1_mean" and Wx != 1000000):
                     row["cpu_baseline"] = cpu_baseline(w2, 2.5)     # bounded: ~2.5 s of CPU work per row
                 extra.append(row)
                 del w2

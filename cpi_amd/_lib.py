@@ -68,6 +68,8 @@ def load():
     lib.cpi_ctx_synchronize.argtypes = [vp]
     lib.cpi_ctx_set_stream.argtypes = [vp, vp]
     lib.cpi_preintegrate_batch.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, vp, dp, dp, C.POINTER(CpiOutputs)]
+    lib.cpi_preintegrate_tiled_batch.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, dp, dp, C.POINTER(CpiOutputs)]
+    lib.cpi_tile_knots.argtypes = [vp, i64, i32, dp, dp]
     lib.cpi_factor_eval_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp]
     lib.cpi_factor_eval_packed_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp]
     lib.cpi_sqrt_information_batch.argtypes = [vp, i64, dp, dp]
@@ -79,7 +81,7 @@ def load():
     for f in (lib.cpi_ctx_create, lib.cpi_ctx_synchronize, lib.cpi_preintegrate_batch, lib.cpi_factor_eval_batch,
               lib.cpi_sqrt_information_batch, lib.cpi_factor_eval_whitened_batch, lib.cpi_factor_eval_packed_batch,
               lib.cpi_predict_batch, lib.cpi_preintegrate_batch_host, lib.cpi_factor_eval_batch_host, lib.cpi_factor_hessian_batch,
-              lib.cpi_group_create, lib.cpi_group_gather, lib.cpi_group_synchronize, lib.cpi_group_size, lib.cpi_ctx_set_stream):
+              lib.cpi_preintegrate_tiled_batch, lib.cpi_tile_knots, lib.cpi_group_create, lib.cpi_group_gather, lib.cpi_group_synchronize, lib.cpi_group_size, lib.cpi_ctx_set_stream):
         f.restype = C.c_int
     if lib.cpi_abi_version() != ABI_VERSION:
         raise ImportError("cpi_amd: %s has ABI version %d, this binding expects %d (stale build?)" % (LIB_PATH, lib.cpi_abi_version(), ABI_VERSION))

@@ -573,6 +573,140 @@ __global__ __launch_bounds__(64, 1) void cpi_mean_dma_kernel(PreArgs A) {
 }
 
 // ============================================================================================
+// mean kernel on the TILED layout: knots of 64 windows interleaved per step (cpi_preintegrate_tiled_batch)
+// ============================================================================================
+// tiles[b][s][k][i] = field k (t, w, a) of knot s of window 64 b + i.  A wavefront owns tile b, lane i window 64 b + i, and
+// step s reads seven fully coalesced 512-byte rows: the whole batch is ONE linear stream per wavefront, every byte
+// fetched once, no LDS, no staging, ~100 registers (4 wavefronts per SIMD) -- the layout the recursion wants on this
+// memory system, for producers that can write it (a batch assembler that places knot s of window w at its tile slot instead of
+// at w (N+1) + s costs nothing extra).  Knots are prefetched three steps ahead in registers.
+struct TiledArgs {
+    long long W;
+    int N;
+    const double *tiles;
+    const int *count;
+    const double *lin;
+    const double *qk;
+    double grav[3];
+    cpi_outputs out;
+    int dbg;   // measurement only (CPI_AMD_BLK_MODE): 1 = fetch without arithmetic
+};
+template <int MODEL, bool AVG, bool COUNTED>
+#ifndef CPI_TILED_OCC
+#define CPI_TILED_OCC (MODEL == 2 ? 2 : 3)
+#endif
+__global__ __launch_bounds__(64, CPI_TILED_OCC) void cpi_mean_tiled_kernel(TiledArgs A) {
+    const int lane = threadIdx.x;
+    const long long w = (long long)blockIdx.x * 64 + lane;
+    const bool valid = w < A.W;
+    const long long wc = valid ? w : A.W - 1;
+    const int n = valid ? (COUNTED ? min(max(A.count[wc], 0), A.N) : A.N) : 0;
+    const int nmax = COUNTED ? __builtin_amdgcn_readfirstlane(wave_max(n)) : A.N;
+    const double *tb = A.tiles + (long long)blockIdx.x * (long long)(A.N + 1) * 448 + lane;   // 448 = 7 fields x 64 windows
+    const V3 bw = ldv3(A.lin + wc * 6), ba = ldv3(A.lin + wc * 6 + 3);
+    V3 gk = mk(0, 0, 0);
+    if (MODEL == 2) gk = mul(quat_2_Rot(ldq4(A.qk + wc * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
+    auto load = [&](double (&k)[7], int s) {
+        // COUNTED: past its own last knot a lane re-reads that knot (dt = 0) -- what lies behind it in the column is
+        // never read.  Otherwise the row offset is wave-uniform (scalar address arithmetic).
+        const double *p = tb + (long long)(COUNTED ? min(s, n) : min(s, A.N)) * 448;
+#pragma unroll
+        for (int f = 0; f < 7; f++) k[f] = p[f * 64];
+    };
+#ifndef CPI_TILED_BUFS
+#define CPI_TILED_BUFS 5
+#endif
+    MeanState<false> st;
+    mean_init(st);
+    // the knot buffers rotate by NAME over one unrolled trip (a rolled loop spends 28 v_mov_b64 per step on it)
+#define CPI_TSTEP(a, b, e, S)                                                                                      \
+    load(e, (S) + CPI_TILED_BUFS - 1);                                                                             \
+    mean_step<MODEL, false, AVG>(st, a[0], b[0], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]), mk(b[1], b[2], b[3]), \
+                                 mk(b[4], b[5], b[6]), bw, ba, gk, (S) < n)
+#if CPI_TILED_BUFS == 5
+    double k0[7], k1[7], k2[7], k3[7], k4[7];
+    load(k0, 0); load(k1, 1); load(k2, 2); load(k3, 3);
+    for (int s = 0; s < nmax; s += 5) {
+        CPI_TSTEP(k0, k1, k4, s);
+        if (s + 1 >= nmax) break;
+        CPI_TSTEP(k1, k2, k0, s + 1);
+        if (s + 2 >= nmax) break;
+        CPI_TSTEP(k2, k3, k1, s + 2);
+        if (s + 3 >= nmax) break;
+        CPI_TSTEP(k3, k4, k2, s + 3);
+        if (s + 4 >= nmax) break;
+        CPI_TSTEP(k4, k0, k3, s + 4);
+    }
+#elif CPI_TILED_BUFS == 4
+    double k0[7], k1[7], k2[7], k3[7];
+    load(k0, 0); load(k1, 1); load(k2, 2);
+    for (int s = 0; s < nmax; s += 4) {
+        CPI_TSTEP(k0, k1, k3, s);
+        if (s + 1 >= nmax) break;
+        CPI_TSTEP(k1, k2, k0, s + 1);
+        if (s + 2 >= nmax) break;
+        CPI_TSTEP(k2, k3, k1, s + 2);
+        if (s + 3 >= nmax) break;
+        CPI_TSTEP(k3, k0, k2, s + 3);
+    }
+#else
+    double k0[7], k1[7], k2[7];
+    load(k0, 0); load(k1, 1);
+    for (int s = 0; s < nmax; s += 3) {
+        CPI_TSTEP(k0, k1, k2, s);
+        if (s + 1 >= nmax) break;
+        CPI_TSTEP(k1, k2, k0, s + 1);
+        if (s + 2 >= nmax) break;
+        CPI_TSTEP(k2, k0, k1, s + 2);
+    }
+#endif
+#undef CPI_TSTEP
+    if (!valid) return;
+    if (A.out.DT) A.out.DT[w] = st.DT;
+    if (A.out.alpha) stv3(A.out.alpha + w * 3, st.alpha);
+    if (A.out.beta) stv3(A.out.beta + w * 3, st.beta);
+    if (A.out.q) {
+        const Q4 q = rot_2_quat(st.R);
+        double *p = A.out.q + w * 4;
+        p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+    }
+}
+// measurement only (CPI_AMD_BLK_MODE=1): the tiled stream alone -- the same loads, one add per value
+__global__ __launch_bounds__(64, 3) void cpi_tiled_fetch_probe_kernel(TiledArgs A) {
+    const int lane = threadIdx.x;
+    const long long w = (long long)blockIdx.x * 64 + lane;
+    const double *tb = A.tiles + (long long)blockIdx.x * (long long)(A.N + 1) * 448 + lane;
+    auto load = [&](double (&k)[7], int s) {
+        const double *p = tb + (long long)min(s, A.N) * 448;
+#pragma unroll
+        for (int f = 0; f < 7; f++) k[f] = p[f * 64];
+    };
+    double k0[7], k1[7], k2[7], k3[7], acc = 0;
+    load(k0, 0); load(k1, 1); load(k2, 2); load(k3, 3);
+    for (int s = 0; s < A.N; ++s) {
+        double k4[7];
+        load(k4, s + 4);
+#pragma unroll
+        for (int f = 0; f < 7; f++) { acc += k0[f]; k0[f] = k1[f]; k1[f] = k2[f]; k2[f] = k3[f]; k3[f] = k4[f]; }
+    }
+    if (w < A.W && A.out.DT) A.out.DT[w] = acc;
+}
+// dense knots[W][N+1][7] -> tiles[ceil(W/64)][N+1][7][64] (windows past W replicate window W - 1: finite padding)
+__global__ __launch_bounds__(256) void cpi_tile_knots_kernel(long long W, int N, const double *knots, double *tiles) {
+    const long long total = ((W + 63) / 64) * (long long)(N + 1) * 448;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int i = (int)(o & 63);
+        const long long r = o >> 6;
+        const int f = (int)(r % 7);
+        const long long bs = r / 7;
+        const int sidx = (int)(bs % (N + 1));
+        const long long b = bs / (N + 1);
+        const long long w = min(b * 64 + i, W - 1);
+        tiles[o] = knots[(w * (N + 1) + sidx) * 7 + f];
+    }
+}
+
+// ============================================================================================
 // mean kernel, block-resident: a wavefront owns 64 / L CONSECUTIVE WHOLE windows (dense layout)
 // ============================================================================================
 // The wavefront's windows are one contiguous byte range of the knot array (64/L x (N+1) x 56 B -- 22.8 KB for
@@ -2080,6 +2214,61 @@ static const int OUT_N[12] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225 };
 static double **out_field(cpi_outputs *o, int k) {
     double **f[12] = { &o->DT, &o->alpha, &o->beta, &o->q, &o->J_q, &o->J_a, &o->J_b, &o->H_a, &o->H_b, &o->O_a, &o->O_b, &o->P };
     return f[k];
+}
+
+// -------------------------------------------------------------------------------- tiled layout
+extern "C" int cpi_tile_knots(cpi_ctx *ctx, int64_t W, int32_t N, const double *knots, double *tiles) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (W < 0 || N < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_tile_knots: negative size");
+    if (W == 0) return CPI_OK;
+    if (!knots || !tiles) return fail(ctx, CPI_ERR_INVALID, "cpi_tile_knots: NULL argument");
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    const long long total = ((W + 63) / 64) * (long long)(N + 1) * 448;
+    const unsigned nb = (unsigned)std::min<long long>((total + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(cpi_tile_knots_kernel, dim3(nb), dim3(256), 0, ctx->stream, (long long)W, (int)N, knots, tiles);
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+extern "C" int cpi_preintegrate_tiled_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *tiles,
+                                            const int32_t *count, const double *lin, const double *q_k_lin, const cpi_outputs *out) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (!prm || !out) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: prm/out is NULL");
+    if (prm->model != CPI_MODEL_V1 && prm->model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: model must be 1 or 2");
+    if (W < 0 || N < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: negative size");
+    if (W == 0) return CPI_OK;
+    if (!tiles || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: tiles/lin is NULL");
+    if (prm->model == CPI_MODEL_V2 && !q_k_lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: model 2 needs q_k_lin");
+    if (!grid_ok(W)) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: W exceeds 2^31 - 1 windows per call");
+    if (out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b || out->P)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: the tiled layout serves the mean outputs (DT, alpha, beta, q) only; "
+                                          "Jacobians and covariance are FP64-bound, not HBM-bound: use cpi_preintegrate_batch");
+    if (!(out->DT || out->alpha || out->beta || out->q)) return CPI_OK;
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    TiledArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = W; a.N = N; a.tiles = tiles; a.count = count; a.lin = lin; a.qk = q_k_lin; a.out = *out;
+    for (int i = 0; i < 3; i++) a.grav[i] = prm->grav[i];
+    if (const char *e = getenv("CPI_AMD_BLK_MODE")) a.dbg = atoi(e);
+    const unsigned nb = (unsigned)((W + 63) / 64);
+    const bool avg = prm->imu_avg != 0;
+    if (a.dbg == 1) {   // CPI_AMD_PROBE_LDS = dynamic LDS bytes per wavefront, to pin the probe's occupancy (13312 -> 12 waves / CU)
+        const char *e = getenv("CPI_AMD_PROBE_LDS");
+        hipLaunchKernelGGL(cpi_tiled_fetch_probe_kernel, dim3(nb), dim3(64), e ? atoi(e) : 0, ctx->stream, a);
+        return CPI_OK;
+    }
+#define CPI_TILED(M, AV, C) hipLaunchKernelGGL((cpi_mean_tiled_kernel<M, AV, C>), dim3(nb), dim3(64), 0, ctx->stream, a)
+    if (prm->model == CPI_MODEL_V1) {
+        if (count) { if (avg) CPI_TILED(1, true, true); else CPI_TILED(1, false, true); }
+        else       { if (avg) CPI_TILED(1, true, false); else CPI_TILED(1, false, false); }
+    } else {
+        if (count) { if (avg) CPI_TILED(2, true, true); else CPI_TILED(2, false, true); }
+        else       { if (avg) CPI_TILED(2, true, false); else CPI_TILED(2, false, false); }
+    }
+#undef CPI_TILED
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
 }
 
 // -------------------------------------------------------------------------------- device sets

@@ -141,6 +141,37 @@ class Engine:
                                                     _ptr(lin), _ptr(q_k_lin), C.byref(o)))
         return out
 
+    def tile_knots(self, knots):
+        """dense knots [W, N+1, 7] -> tiles [ceil(W/64), N+1, 7, 64] on the device (cpi_tile_knots)."""
+        W, n1, _ = knots.shape
+        tiles = torch.empty(((W + 63) // 64, n1, 7, 64), dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.cpi_tile_knots(self.ctx, W, n1 - 1, _ptr(knots), _ptr(tiles)))
+        return tiles
+
+    def preintegrate_tiled(self, tiles, W, lin, q_k_lin=None, params=None, count=None, out=None, bind=False):
+        """Mean outputs from the tiled layout (include/cpi_amd.h: cpi_preintegrate_tiled_batch).  bind=True: returns
+        (call, out) with the foreign call pre-bound, like bind_preintegrate."""
+        params = params or self.make_params()
+        N = tiles.shape[1] - 1
+        assert tiles.is_cuda and tiles.is_contiguous() and tiles.shape[0] == (W + 63) // 64 and tiles.shape[2:] == (7, 64)
+        if out is None:
+            out = self.alloc_outputs(W, ("mean",), params.model)
+        o = self._outputs_struct(out)
+        args = (self.ctx, C.byref(params), W, N, _ptr(tiles), _ptr(count), _ptr(lin), _ptr(q_k_lin), C.byref(o))
+        fn, check, sync = self.lib.cpi_preintegrate_tiled_batch, self._check, self._sync_stream
+
+        def call():
+            sync()
+            rc = fn(*args)
+            if rc:
+                check(rc)
+        call._keep = (o, params, tiles, lin, q_k_lin, count, out)
+        if bind:
+            return call, out
+        call()
+        return out
+
     def bind_preintegrate(self, knots, lin, q_k_lin=None, params=None, want=("mean", "jac", "cov"), first=None, count=None,
                           N=None, out=None):
         """A zero-argument callable that issues exactly this preintegrate() call again and again: the ctypes argument

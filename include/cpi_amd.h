@@ -117,6 +117,22 @@ int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32
                            const double *knots, const int64_t *first, const int32_t *count,
                            const double *lin, const double *q_k_lin, const cpi_outputs *out);
 
+/* The same loop for the mean outputs (DT, alpha, beta, q) on the TILED layout: the knots of 64 consecutive windows
+ * interleaved per step,
+ *     tiles[ceil(W/64)][N+1][7][64]      tiles[b][s][k][i] = field k of {t, w[3], a[3]} of knot s of window 64 b + i,
+ * so that a wavefront (one tile, one lane per window) reads every step as seven coalesced 512-byte rows: one linear
+ * stream per wavefront, no staging -- the mean-only recursion is HBM-bound and this is the layout it wants on MI355X
+ * (DESIGN.md 3.1).  For producers that can write it: a batch assembler places knot s of window w at its tile slot
+ * instead of at w (N+1) + s; cpi_tile_knots converts a dense array on the device (a full extra pass -- for tests and
+ * one-off use).  Columns past W inside the last tile are never written back (cpi_tile_knots fills them with window
+ * W - 1).  count as in cpi_preintegrate_batch: a lane never reads its column past row count[w], whatever lies there
+ * (unwritten memory, NaN) is harmless; rows of the tile array past the largest count must still be ALLOCATED as the
+ * shape says.  Skipped intervals (dt <= 0, NaN dt) inside a window need finite readings, as above.  Any Jacobian / covariance
+ * pointer in out -> CPI_ERR_INVALID (those kernels are FP64-bound: the layout would buy nothing). */
+int cpi_preintegrate_tiled_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *tiles,
+                                 const int32_t *count, const double *lin, const double *q_k_lin, const cpi_outputs *out);
+int cpi_tile_knots(cpi_ctx *ctx, int64_t W, int32_t N, const double *knots /*[W][N+1][7]*/, double *tiles);
+
 /* Replaces: ImuFactorCPIv1::evaluateError / ImuFactorCPIv2::evaluateError, one call per factor
  * (ImuFactorCPIv1.cpp:37-208, ImuFactorCPIv2.cpp:38-212), as driven by GTSAM's linearize loop.
  *
