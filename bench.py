@@ -511,7 +511,8 @@ def main():
                                 ("v1_full", 100000, 30), ("v2_full", 100000, 30), ("forster_full", 100000, 30),
                                 ("factor_v1", 1000000, 40), ("factor_v2", 1000000, 40),
                                 ("factor_v1_packed", 1000000, 40), ("factor_v2_packed", 1000000, 40),
-                                ("cfg5_mean", 1000000, 10), ("cfg5_full", 1000000, 3), ("v1_mean_tiled", 1000000, 40)):
+                                ("cfg5_mean", 1000000, 10), ("cfg5_full", 1000000, 3), ("v1_mean_tiled", 1000000, 40),
+                                ("v1_mean_tiled", 10000, 1000)):
             try:
                 Nx = WORKLOADS[name]["N"]
                 w2 = Workload(eng, name, Wx, Nx, seed=4242)

@@ -591,21 +591,35 @@ struct TiledArgs {
     cpi_outputs out;
     int dbg;   // measurement only (CPI_AMD_BLK_MODE): 1 = fetch without arithmetic
 };
-template <int MODEL, bool AVG, bool COUNTED>
 #ifndef CPI_TILED_OCC
 #define CPI_TILED_OCC (MODEL == 2 ? 2 : 3)
 #endif
-__global__ __launch_bounds__(64, CPI_TILED_OCC) void cpi_mean_tiled_kernel(TiledArgs A) {
-    const int lane = threadIdx.x;
+#ifndef CPI_TILED_BUFS
+#define CPI_TILED_BUFS 5
+#endif
+// SPLIT (small batches: fewer tiles than the chip has SIMDs): a workgroup of S = blockDim.x / 64 wavefronts owns the
+// tile; wavefront j integrates the steps [j per, (j + 1) per) of all 64 windows from the identity (model 2: from the raw
+// specific force, with the segment's gravity response -- cpi_math.hpp mean_step_v2seg), parks its segment in LDS, and
+// wavefront 0 composes the S segments in order (mean_combine / grav_combine: the composition cpi_mean_kernel uses
+// across the lanes of a window).  Each wavefront still reads one linear stream.
+template <int MODEL, bool AVG, bool COUNTED, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 512 : 64, SPLIT ? 1 : CPI_TILED_OCC) void cpi_mean_tiled_kernel(TiledArgs A) {
+    constexpr bool GSEG = SPLIT && MODEL == 2;
+    constexpr int NF = GSEG ? 34 : 16;            // doubles of a parked segment
+    extern __shared__ double seg[];               // [S - 1][NF][64]
+    const int lane = threadIdx.x & 63;
+    const int j = SPLIT ? (int)(threadIdx.x >> 6) : 0, S = SPLIT ? (int)(blockDim.x >> 6) : 1;
     const long long w = (long long)blockIdx.x * 64 + lane;
     const bool valid = w < A.W;
     const long long wc = valid ? w : A.W - 1;
     const int n = valid ? (COUNTED ? min(max(A.count[wc], 0), A.N) : A.N) : 0;
     const int nmax = COUNTED ? __builtin_amdgcn_readfirstlane(wave_max(n)) : A.N;
+    const int per = SPLIT ? (A.N + S - 1) / S : A.N;
+    const int sb = __builtin_amdgcn_readfirstlane(j * per), se = min(sb + per, nmax);   // this wavefront's steps
     const double *tb = A.tiles + (long long)blockIdx.x * (long long)(A.N + 1) * 448 + lane;   // 448 = 7 fields x 64 windows
     const V3 bw = ldv3(A.lin + wc * 6), ba = ldv3(A.lin + wc * 6 + 3);
     V3 gk = mk(0, 0, 0);
-    if (MODEL == 2) gk = mul(quat_2_Rot(ldq4(A.qk + wc * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
+    if (MODEL == 2 && j == 0) gk = mul(quat_2_Rot(ldq4(A.qk + wc * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
     auto load = [&](double (&k)[7], int s) {
         // COUNTED: past its own last knot a lane re-reads that knot (dt = 0) -- what lies behind it in the column is
         // never read.  Otherwise the row offset is wave-uniform (scalar address arithmetic).
@@ -613,54 +627,97 @@ __global__ __launch_bounds__(64, CPI_TILED_OCC) void cpi_mean_tiled_kernel(Tiled
 #pragma unroll
         for (int f = 0; f < 7; f++) k[f] = p[f * 64];
     };
-#ifndef CPI_TILED_BUFS
-#define CPI_TILED_BUFS 5
-#endif
     MeanState<false> st;
     mean_init(st);
+    GravAcc ga;
+    if (GSEG) grav_init(ga);
     // the knot buffers rotate by NAME over one unrolled trip (a rolled loop spends 28 v_mov_b64 per step on it)
-#define CPI_TSTEP(a, b, e, S)                                                                                      \
-    load(e, (S) + CPI_TILED_BUFS - 1);                                                                             \
-    mean_step<MODEL, false, AVG>(st, a[0], b[0], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]), mk(b[1], b[2], b[3]), \
-                                 mk(b[4], b[5], b[6]), bw, ba, gk, (S) < n)
+#define CPI_TSTEP(a, b, e, S_)                                                                                        \
+    load(e, (S_) + CPI_TILED_BUFS - 1);                                                                               \
+    if constexpr (GSEG)                                                                                               \
+        mean_step_v2seg<AVG>(st, ga, a[0], b[0], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]), mk(b[1], b[2], b[3]),    \
+                             mk(b[4], b[5], b[6]), bw, ba, (S_) < n);                                                 \
+    else                                                                                                              \
+        mean_step<MODEL, false, AVG>(st, a[0], b[0], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]), mk(b[1], b[2], b[3]), \
+                                     mk(b[4], b[5], b[6]), bw, ba, gk, (S_) < n)
 #if CPI_TILED_BUFS == 5
     double k0[7], k1[7], k2[7], k3[7], k4[7];
-    load(k0, 0); load(k1, 1); load(k2, 2); load(k3, 3);
-    for (int s = 0; s < nmax; s += 5) {
+    load(k0, sb); load(k1, sb + 1); load(k2, sb + 2); load(k3, sb + 3);
+    for (int s = sb; s < se; s += 5) {
         CPI_TSTEP(k0, k1, k4, s);
-        if (s + 1 >= nmax) break;
+        if (s + 1 >= se) break;
         CPI_TSTEP(k1, k2, k0, s + 1);
-        if (s + 2 >= nmax) break;
+        if (s + 2 >= se) break;
         CPI_TSTEP(k2, k3, k1, s + 2);
-        if (s + 3 >= nmax) break;
+        if (s + 3 >= se) break;
         CPI_TSTEP(k3, k4, k2, s + 3);
-        if (s + 4 >= nmax) break;
+        if (s + 4 >= se) break;
         CPI_TSTEP(k4, k0, k3, s + 4);
     }
 #elif CPI_TILED_BUFS == 4
     double k0[7], k1[7], k2[7], k3[7];
-    load(k0, 0); load(k1, 1); load(k2, 2);
-    for (int s = 0; s < nmax; s += 4) {
+    load(k0, sb); load(k1, sb + 1); load(k2, sb + 2);
+    for (int s = sb; s < se; s += 4) {
         CPI_TSTEP(k0, k1, k3, s);
-        if (s + 1 >= nmax) break;
+        if (s + 1 >= se) break;
         CPI_TSTEP(k1, k2, k0, s + 1);
-        if (s + 2 >= nmax) break;
+        if (s + 2 >= se) break;
         CPI_TSTEP(k2, k3, k1, s + 2);
-        if (s + 3 >= nmax) break;
+        if (s + 3 >= se) break;
         CPI_TSTEP(k3, k0, k2, s + 3);
     }
 #else
     double k0[7], k1[7], k2[7];
-    load(k0, 0); load(k1, 1);
-    for (int s = 0; s < nmax; s += 3) {
+    load(k0, sb); load(k1, sb + 1);
+    for (int s = sb; s < se; s += 3) {
         CPI_TSTEP(k0, k1, k2, s);
-        if (s + 1 >= nmax) break;
+        if (s + 1 >= se) break;
         CPI_TSTEP(k1, k2, k0, s + 1);
-        if (s + 2 >= nmax) break;
+        if (s + 2 >= se) break;
         CPI_TSTEP(k2, k0, k1, s + 2);
     }
 #endif
 #undef CPI_TSTEP
+    if constexpr (SPLIT) {
+        auto park = [&](int f, double v) { seg[((j - 1) * NF + f) * 64 + lane] = v; };
+        if (j > 0) {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) park(r * 3 + c, st.R.m[r][c]);
+            park(9, st.alpha.x); park(10, st.alpha.y); park(11, st.alpha.z);
+            park(12, st.beta.x); park(13, st.beta.y); park(14, st.beta.z); park(15, st.DT);
+            if constexpr (GSEG) {
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { park(16 + r * 3 + c, ga.Gam.m[r][c]); park(25 + r * 3 + c, ga.Lam.m[r][c]); }
+            }
+        }
+        __syncthreads();
+        if (j > 0) return;
+        for (int jj = 1; jj < S; ++jj) {        // earlier o later, in order
+            const double *sp = seg + (jj - 1) * NF * 64 + lane;
+            MeanState<false> B;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) B.R.m[r][c] = sp[(r * 3 + c) * 64];
+            B.alpha = mk(sp[9 * 64], sp[10 * 64], sp[11 * 64]);
+            B.beta = mk(sp[12 * 64], sp[13 * 64], sp[14 * 64]);
+            B.DT = sp[15 * 64];
+            if constexpr (GSEG) {
+                GravAcc gB;
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { gB.Gam.m[r][c] = sp[(16 + r * 3 + c) * 64]; gB.Lam.m[r][c] = sp[(25 + r * 3 + c) * 64]; }
+                grav_combine(ga, st, gB, B);    // before mean_combine: needs st.R and B.DT as they are
+            }
+            mean_combine(st, B);
+        }
+        if constexpr (GSEG) grav_apply(st, ga, gk);
+    }
     if (!valid) return;
     if (A.out.DT) A.out.DT[w] = st.DT;
     if (A.out.alpha) stv3(A.out.alpha + w * 3, st.alpha);
@@ -1717,6 +1774,7 @@ struct cpi_ctx {
     // request (covariance kernel; analytic-Jacobian kernel) run concurrently -- see cpi_preintegrate_batch
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned big_lds_set = 0;   // bit per kernel instantiation whose dynamic-LDS limit was raised on this device
 };
 static thread_local std::string g_create_err;
 
@@ -2258,15 +2316,34 @@ extern "C" int cpi_preintegrate_tiled_batch(cpi_ctx *ctx, const cpi_params *prm,
         hipLaunchKernelGGL(cpi_tiled_fetch_probe_kernel, dim3(nb), dim3(64), e ? atoi(e) : 0, ctx->stream, a);
         return CPI_OK;
     }
-#define CPI_TILED(M, AV, C) hipLaunchKernelGGL((cpi_mean_tiled_kernel<M, AV, C>), dim3(nb), dim3(64), 0, ctx->stream, a)
+    // wavefronts per tile.  Measured (MI355X, N = 50, us per launch, S = 1 / 2 / 3 / 4 / 8): 5 k windows 24.9 / 15.0 / 11.5 /
+    // 10.3 / -, 10 k 25.2 / 15.4 / 11.9 / 10.8 / 12.4, 20 k 27.0 / 23.6 / 19.6 / 18.7 / 22.8, 30 k 28.6 / 25.1 / 22.2 / 21.3,
+    // 50 k 33.0 / 34.4 / 34.8 / 34.9, 100 k 61.3 / 64.3 / 65.8 / 65.2: four (one per SIMD of the CU that owns the tile) while
+    // the tiles do not fill the chip, one beyond.  CPI_AMD_TILED_SPLIT overrides (measurements, tests).
+    int S = (nb < 640) ? std::max(1, std::min(4, (int)N / 4)) : 1;
+    if (const char *e = getenv("CPI_AMD_TILED_SPLIT")) S = std::max(1, std::min(8, atoi(e)));
+    const size_t lds = (size_t)(S - 1) * (prm->model == CPI_MODEL_V2 ? 34 : 16) * 64 * sizeof(double);
+    // more than 64 KB of dynamic LDS (model 2, S >= 5) needs the kernel's limit raised once per device
+#define CPI_TILED2(M, AV, C)                                                                                      \
+    do {                                                                                                          \
+        if (S > 1) {                                                                                              \
+            const unsigned bit = 1u << ((M - 1) * 4 + (AV ? 2 : 0) + (C ? 1 : 0));                                \
+            if (lds > 65536 && !(ctx->big_lds_set & bit)) {                                                       \
+                CPI_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cpi_mean_tiled_kernel<M, AV, C, true>), \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 34 * 64 * 8));   \
+                ctx->big_lds_set |= bit;                                                                          \
+            }                                                                                                     \
+            hipLaunchKernelGGL((cpi_mean_tiled_kernel<M, AV, C, true>), dim3(nb), dim3(64 * S), lds, ctx->stream, a); \
+        } else hipLaunchKernelGGL((cpi_mean_tiled_kernel<M, AV, C, false>), dim3(nb), dim3(64), 0, ctx->stream, a); \
+    } while (0)
     if (prm->model == CPI_MODEL_V1) {
-        if (count) { if (avg) CPI_TILED(1, true, true); else CPI_TILED(1, false, true); }
-        else       { if (avg) CPI_TILED(1, true, false); else CPI_TILED(1, false, false); }
+        if (count) { if (avg) CPI_TILED2(1, true, true); else CPI_TILED2(1, false, true); }
+        else       { if (avg) CPI_TILED2(1, true, false); else CPI_TILED2(1, false, false); }
     } else {
-        if (count) { if (avg) CPI_TILED(2, true, true); else CPI_TILED(2, false, true); }
-        else       { if (avg) CPI_TILED(2, true, false); else CPI_TILED(2, false, false); }
+        if (count) { if (avg) CPI_TILED2(2, true, true); else CPI_TILED2(2, false, true); }
+        else       { if (avg) CPI_TILED2(2, true, false); else CPI_TILED2(2, false, false); }
     }
-#undef CPI_TILED
+#undef CPI_TILED2
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }

@@ -123,7 +123,8 @@ int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32
  * so that a wavefront (one tile, one lane per window) reads every step as seven coalesced 512-byte rows: one linear
  * stream per wavefront, no staging -- the mean-only recursion is HBM-bound and this is the layout it wants on MI355X
  * (DESIGN.md 3.1).  For producers that can write it: a batch assembler places knot s of window w at its tile slot
- * instead of at w (N+1) + s; cpi_tile_knots converts a dense array on the device (a full extra pass -- for tests and
+ * instead of at w (N+1) + s; small batches (< 640 tiles) split a tile's steps over four wavefronts, same results to
+ * rounding; cpi_tile_knots converts a dense array on the device (a full extra pass -- for tests and
  * one-off use).  Columns past W inside the last tile are never written back (cpi_tile_knots fills them with window
  * W - 1).  count as in cpi_preintegrate_batch: a lane never reads its column past row count[w], whatever lies there
  * (unwritten memory, NaN) is harmless; rows of the tile array past the largest count must still be ALLOCATED as the
