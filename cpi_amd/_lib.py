@@ -77,6 +77,10 @@ def load():
     lib.cpi_factor_hessian_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp]
     lib.cpi_predict_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, i64, vp, dp]
     lib.cpi_preintegrate_batch_host.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, vp, i64, dp, dp, C.POINTER(CpiOutputs)]
+    lib.cpi_host_alloc.argtypes = [C.c_size_t]
+    lib.cpi_host_alloc.restype = C.c_void_p
+    lib.cpi_host_free.argtypes = [vp]
+    lib.cpi_host_free.restype = None
     lib.cpi_factor_eval_batch_host.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp]
     for f in (lib.cpi_ctx_create, lib.cpi_ctx_synchronize, lib.cpi_preintegrate_batch, lib.cpi_factor_eval_batch,
               lib.cpi_sqrt_information_batch, lib.cpi_factor_eval_whitened_batch, lib.cpi_factor_eval_packed_batch,

@@ -226,7 +226,10 @@ public:
             Oa(W * 9), Ob(W * 9), P(W * 225);
         cpi_outputs o{ DT.data(), al.data(), be.data(), q.data(), Jq.data(), Ja.data(), Jb.data(), Ha.data(), Hb.data(),
                        Oa.data(), Ob.data(), P.data() };
-        ctx.check(cpi_preintegrate_batch_host(ctx.get(), &p, W, N, knots.data(), first.data(), count.data(),
+        // windows of equal length lie back to back = the dense layout: that entry pipelines upload / kernels / download
+        bool dense = true;
+        for (int64_t w = 0; w < W && dense; w++) dense = (count[w] == N) && !win_[w]->knots().empty();
+        ctx.check(cpi_preintegrate_batch_host(ctx.get(), &p, W, N, knots.data(), dense ? nullptr : first.data(), dense ? nullptr : count.data(),
                                               (int64_t)(knots.size() / 7), lin.data(), qk.data(), &o));
         for (int64_t w = 0; w < W; w++) {
             CpiResult &r = *win_[w];

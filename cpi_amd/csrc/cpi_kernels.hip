@@ -1766,6 +1766,8 @@ __global__ __launch_bounds__(256) void cpi_predict_kernel(PredictArgs A) {
 // ============================================================================================
 // C-ABI
 // ============================================================================================
+struct HostPipe;
+static void host_pipe_destroy(HostPipe *);
 struct cpi_ctx {
     int device;
     hipStream_t stream;
@@ -1775,6 +1777,7 @@ struct cpi_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned big_lds_set = 0;   // bit per kernel instantiation whose dynamic-LDS limit was raised on this device
+    struct HostPipe *pipe = nullptr;   // staging of the host-pointer entries (created at their first use)
 };
 static thread_local std::string g_create_err;
 
@@ -1829,13 +1832,16 @@ extern "C" int cpi_ctx_create(int device, void *stream, cpi_ctx **out) {
 }
 extern "C" void cpi_ctx_destroy(cpi_ctx *ctx) {
     if (!ctx) return;
-    if (ctx->side) {
+    if (ctx->side || ctx->pipe) {
         int prev = -1;
         (void)hipGetDevice(&prev);
         (void)hipSetDevice(ctx->device);
-        (void)hipStreamDestroy(ctx->side);
-        (void)hipEventDestroy(ctx->ev_fork);
-        (void)hipEventDestroy(ctx->ev_join);
+        if (ctx->side) {
+            (void)hipStreamDestroy(ctx->side);
+            (void)hipEventDestroy(ctx->ev_fork);
+            (void)hipEventDestroy(ctx->ev_join);
+        }
+        if (ctx->pipe) host_pipe_destroy(ctx->pipe);
         if (prev >= 0) (void)hipSetDevice(prev);
     }
     delete ctx;
@@ -2558,6 +2564,116 @@ struct DevBuf {
         }                                                                                 \
     } while (0)
 
+// Dense batches from host memory run as a three-stage pipeline over chunks of <= 65536 windows: upload of chunk i + 1
+// (copy stream), kernels of chunk i (the context's stream), download of chunk i - 1 (second copy stream) -- PCIe is full
+// duplex, so with PINNED host buffers (cpi_host_alloc, hipHostMalloc, torch pin_memory) a call costs about
+// max(upload, download, kernels) instead of their sum; with pageable memory the copies serialise in the runtime's own
+// staging and the pipeline degenerates to the sum, minus the per-call hipMalloc / hipFree of the device staging, which
+// the context now keeps (two slots, grow-only, released by cpi_ctx_destroy).  Measured (MI355X box, 1 M x 50, everything
+// out = "V1 full", 2.9 GB up + 2.3 GB down): pinned 56 ms (92 GB/s both directions summed), pageable 112 ms; mean only
+// 52 / 56 ms.  Page-locked bounce buffers + copy threads for pageable destinations were built and measured: no faster
+// than the runtime's own path (112 ms) -- what costs is FRESH pageable output memory (first-touch page faults: 375-450 ms
+// for the same call), so callers should re-use their output buffers.
+struct HostPipe {
+    hipStream_t up = nullptr, down = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    void *in[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // knots, count, lin, q_k_lin
+    size_t in_cap[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    void *out[2][12] = {};
+    size_t out_cap[2][12] = {};
+};
+static void host_pipe_destroy(HostPipe *hp) {
+    if (!hp) return;
+    for (int s = 0; s < 2; s++) {
+        for (int k = 0; k < 4; k++) if (hp->in[s][k]) (void)hipFree(hp->in[s][k]);
+        for (int k = 0; k < 12; k++) if (hp->out[s][k]) (void)hipFree(hp->out[s][k]);
+        if (hp->ev_in[s]) (void)hipEventDestroy(hp->ev_in[s]);
+        if (hp->ev_done[s]) (void)hipEventDestroy(hp->ev_done[s]);
+        if (hp->ev_out[s]) (void)hipEventDestroy(hp->ev_out[s]);
+    }
+    if (hp->up) (void)hipStreamDestroy(hp->up);
+    if (hp->down) (void)hipStreamDestroy(hp->down);
+    delete hp;
+}
+static int host_pipe_get(cpi_ctx *ctx) {
+    if (ctx->pipe) return CPI_OK;
+    HostPipe *hp = new HostPipe();
+    ctx->pipe = hp;   // owned by the context from here on: a partial set-up is released by cpi_ctx_destroy
+    CPI_HIP(ctx, hipStreamCreateWithFlags(&hp->up, hipStreamNonBlocking));
+    CPI_HIP(ctx, hipStreamCreateWithFlags(&hp->down, hipStreamNonBlocking));
+    for (int s = 0; s < 2; s++) {
+        CPI_HIP(ctx, hipEventCreateWithFlags(&hp->ev_in[s], hipEventDisableTiming));
+        CPI_HIP(ctx, hipEventCreateWithFlags(&hp->ev_done[s], hipEventDisableTiming));
+        CPI_HIP(ctx, hipEventCreateWithFlags(&hp->ev_out[s], hipEventDisableTiming));
+    }
+    return CPI_OK;
+}
+static int host_pipe_reserve(cpi_ctx *ctx, void *&p, size_t &cap, size_t bytes) {
+    if (bytes <= cap) return CPI_OK;
+    if (p) { CPI_HIP(ctx, hipFree(p)); p = nullptr; cap = 0; }
+    CPI_HIP(ctx, hipMalloc(&p, bytes));
+    cap = bytes;
+    return CPI_OK;
+}
+extern "C" void *cpi_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    return (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess) ? p : nullptr;
+}
+extern "C" void cpi_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+static int preintegrate_host_dense(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *knots,
+                                   const int32_t *count, const double *lin, const double *q_k_lin, const cpi_outputs *out) {
+    int rc = host_pipe_get(ctx);
+    if (rc != CPI_OK) return rc;
+    HostPipe *hp = ctx->pipe;
+    const int64_t nch = (W + 65535) / 65536;
+    const int64_t Wc = std::min<int64_t>(W, (((W + nch - 1) / nch) + 63) / 64 * 64);   // balanced chunks, whole wavefronts
+    const int nslots = nch > 1 ? 2 : 1;
+    const size_t knot_bytes = (size_t)(N + 1) * 7 * sizeof(double);
+    cpi_outputs h = *out;
+    for (int s = 0; s < nslots; s++) {
+        const size_t need[4] = { (size_t)Wc * knot_bytes, count ? (size_t)Wc * sizeof(int32_t) : 0, (size_t)Wc * 6 * sizeof(double),
+                                 q_k_lin ? (size_t)Wc * 4 * sizeof(double) : 0 };
+        for (int k = 0; k < 4; k++)
+            if ((rc = host_pipe_reserve(ctx, hp->in[s][k], hp->in_cap[s][k], need[k])) != CPI_OK) return rc;
+        for (int k = 0; k < 12; k++)
+            if (*out_field(&h, k) && (rc = host_pipe_reserve(ctx, hp->out[s][k], hp->out_cap[s][k], (size_t)Wc * OUT_N[k] * sizeof(double))) != CPI_OK) return rc;
+    }
+    // after the first enqueue nothing may return before the three streams are idle: copies into the caller's memory are in flight
+    std::string err;
+    auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && err.empty()) err = std::string(what) + ": " + hipGetErrorString(e); return e == hipSuccess; };
+    for (int64_t i = 0; i < nch && err.empty() && rc == CPI_OK; i++) {
+        const int s = (int)(i & 1);
+        const int64_t w0 = i * Wc, wn = std::min<int64_t>(Wc, W - w0);
+        if (i >= 2 && !hip_ok(hipStreamWaitEvent(hp->up, hp->ev_done[s], 0), "hipStreamWaitEvent")) break;   // slot's inputs consumed
+        if (!hip_ok(hipMemcpyAsync(hp->in[s][0], knots + (size_t)w0 * (N + 1) * 7, (size_t)wn * knot_bytes, hipMemcpyHostToDevice, hp->up), "upload knots")) break;
+        if (count && !hip_ok(hipMemcpyAsync(hp->in[s][1], count + w0, (size_t)wn * sizeof(int32_t), hipMemcpyHostToDevice, hp->up), "upload count")) break;
+        if (!hip_ok(hipMemcpyAsync(hp->in[s][2], lin + (size_t)w0 * 6, (size_t)wn * 6 * sizeof(double), hipMemcpyHostToDevice, hp->up), "upload lin")) break;
+        if (q_k_lin && !hip_ok(hipMemcpyAsync(hp->in[s][3], q_k_lin + (size_t)w0 * 4, (size_t)wn * 4 * sizeof(double), hipMemcpyHostToDevice, hp->up), "upload q_k_lin")) break;
+        if (!hip_ok(hipEventRecord(hp->ev_in[s], hp->up), "hipEventRecord")) break;
+        if (!hip_ok(hipStreamWaitEvent(ctx->stream, hp->ev_in[s], 0), "hipStreamWaitEvent")) break;
+        if (i >= 2 && !hip_ok(hipStreamWaitEvent(ctx->stream, hp->ev_out[s], 0), "hipStreamWaitEvent")) break;   // slot's outputs downloaded
+        cpi_outputs d;
+        memset(&d, 0, sizeof d);
+        for (int k = 0; k < 12; k++) if (*out_field(&h, k)) *out_field(&d, k) = (double *)hp->out[s][k];
+        rc = cpi_preintegrate_batch(ctx, prm, wn, N, (const double *)hp->in[s][0], nullptr, count ? (const int32_t *)hp->in[s][1] : nullptr,
+                                    (const double *)hp->in[s][2], q_k_lin ? (const double *)hp->in[s][3] : nullptr, &d);
+        if (rc != CPI_OK) break;
+        if (!hip_ok(hipEventRecord(hp->ev_done[s], ctx->stream), "hipEventRecord")) break;
+        if (!hip_ok(hipStreamWaitEvent(hp->down, hp->ev_done[s], 0), "hipStreamWaitEvent")) break;
+        for (int k = 0; k < 12; k++)
+            if (*out_field(&h, k) && !hip_ok(hipMemcpyAsync(*out_field(&h, k) + (size_t)w0 * OUT_N[k], hp->out[s][k], (size_t)wn * OUT_N[k] * sizeof(double),
+                                                            hipMemcpyDeviceToHost, hp->down), "download")) break;
+        if (!err.empty()) break;
+        if (!hip_ok(hipEventRecord(hp->ev_out[s], hp->down), "hipEventRecord")) break;
+    }
+    const hipError_t e1 = hipStreamSynchronize(hp->up), e2 = hipStreamSynchronize(ctx->stream), e3 = hipStreamSynchronize(hp->down);
+    if (rc != CPI_OK) return rc;   // message already set by cpi_preintegrate_batch
+    if (!err.empty()) return fail(ctx, CPI_ERR_HIP, "cpi_preintegrate_batch_host: " + err);
+    hip_ok(e1, "hipStreamSynchronize(upload)"); hip_ok(e2, "hipStreamSynchronize"); hip_ok(e3, "hipStreamSynchronize(download)");
+    if (!err.empty()) return fail(ctx, CPI_ERR_HIP, "cpi_preintegrate_batch_host: " + err);
+    return CPI_OK;
+}
 
 extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
                                            const double *knots, const int64_t *first, const int32_t *count,
@@ -2566,9 +2682,11 @@ extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, 
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (!prm || !out || !knots || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch_host: NULL argument");
     if (W <= 0) return W == 0 ? CPI_OK : fail(ctx, CPI_ERR_INVALID, "negative size");
+    if (N < 0) return fail(ctx, CPI_ERR_INVALID, "negative size");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    if (!first) n_knots = W * (int64_t)(N + 1);
+    if (!first) return preintegrate_host_dense(ctx, prm, W, N, knots, count, lin, q_k_lin, out);
+    // ragged windows share one knot stream: staged whole (one-off calls; the stream is usually small)
     DevBuf dk, df, dc, dl, dq, dout[12];
     CPI_UP(dk, knots, (size_t)n_knots * 7 * sizeof(double));
     CPI_UP(df, first, (size_t)W * sizeof(int64_t));
@@ -2583,7 +2701,7 @@ extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, 
         }
     int rc = cpi_preintegrate_batch(ctx, prm, W, N, (const double *)dk.p, (const int64_t *)df.p, (const int32_t *)dc.p,
                                     (const double *)dl.p, (const double *)dq.p, &d);
-    if (rc != CPI_OK) return rc;
+    if (rc != CPI_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     for (int k = 0; k < 12; k++)
         if (*out_field(&h, k))
             CPI_HIP(ctx, hipMemcpyAsync(*out_field(&h, k), dout[k].p, (size_t)W * OUT_N[k] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -141,6 +141,27 @@ class Engine:
                                                     _ptr(lin), _ptr(q_k_lin), C.byref(o)))
         return out
 
+    def preintegrate_host(self, knots, lin, q_k_lin=None, params=None, want=("mean", "jac", "cov"), count=None, pinned=True, out=None):
+        """Dense batch held in HOST memory (CPU float64 tensors; pinned ones overlap upload / kernels / download):
+        cpi_preintegrate_batch_host.  Returns a dict of CPU tensors (page-locked when pinned=True; out= re-uses the
+        dict of an earlier call); synchronous."""
+        params = params or self.make_params()
+        W, n1, _ = knots.shape
+        for t in (knots, lin, q_k_lin, count):
+            assert t is None or (not t.is_cuda and t.is_contiguous()), "inputs must be contiguous CPU tensors"
+        assert knots.dtype == torch.float64 and lin.dtype == torch.float64 and (count is None or count.dtype == torch.int32)
+        if out is None:
+            out = {}
+            for name, n in OUT_FIELDS:
+                grp = "mean" if name in MEAN_FIELDS else ("cov" if name == "P" else "jac")
+                if grp in want and (params.model == 2 or name not in ("O_a", "O_b")):
+                    out[name] = torch.empty((W,) if n == 1 else (W, n), dtype=torch.float64, pin_memory=pinned)
+        o = self._outputs_struct(out)
+        self._sync_stream()
+        self._check(self.lib.cpi_preintegrate_batch_host(self.ctx, C.byref(params), W, n1 - 1, _ptr(knots), None, _ptr(count), 0,
+                                                         _ptr(lin), _ptr(q_k_lin), C.byref(o)))
+        return out
+
     def tile_knots(self, knots):
         """dense knots [W, N+1, 7] -> tiles [ceil(W/64), N+1, 7, 64] on the device (cpi_tile_knots)."""
         W, n1, _ = knots.shape

@@ -25,6 +25,7 @@
 #ifndef CPI_AMD_H
 #define CPI_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -229,13 +230,20 @@ void cpi_shard_bounds(int64_t W, int rank, int n, int64_t *lo, int64_t *hi);
 int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_outputs *local, const cpi_outputs *root_out);
 int cpi_group_synchronize(cpi_group *g);
 
-/* Convenience for single-window / small host-side callers (the CpiV1-shaped C++ facade in
- * cpi_amd/csrc/cpi_host.hpp): same as cpi_preintegrate_batch but every pointer is a HOST pointer;
- * stages through device memory and synchronises.  PCIe-inclusive, not the benchmarked path. */
+/* For host-side callers (the CpiV1-shaped C++ facade in cpi_amd/csrc/cpi_host.hpp): same as cpi_preintegrate_batch
+ * but every pointer is a HOST pointer; stages through device memory owned by the context and returns when the outputs
+ * are in host memory.  Dense batches (first == NULL) run as an upload / kernels / download pipeline over chunks of
+ * <= 65536 windows: with PINNED host buffers (cpi_host_alloc, hipHostMalloc) the three overlap (PCIe is full duplex);
+ * with pageable memory the result is the same, the copies serialise.  Lanes per window are chosen per chunk, so the
+ * rounding of a window may differ from the device-pointer call on the whole batch (set prm->lanes_per_window to pin
+ * it).  PCIe-inclusive, never the benchmarked path. */
 int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
                                 const double *knots, const int64_t *first, const int32_t *count,
                                 int64_t n_knots, const double *lin, const double *q_k_lin,
                                 const cpi_outputs *out);
+/* page-locked host memory for the entries above (hipHostMalloc / hipHostFree); NULL when the allocation fails */
+void *cpi_host_alloc(size_t bytes);
+void cpi_host_free(void *p);
 int cpi_factor_eval_batch_host(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                                const cpi_outputs *meas, const double *lin, const double *q_k_lin,
                                const double *states, int64_t S, const int32_t *idx_i,

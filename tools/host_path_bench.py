@@ -1,30 +1,25 @@
-"""PCIe-inclusive rate of the host-pointer convenience entry point (development tool; never the benchmarked path)."""
-import ctypes as C, os, sys, time
-import numpy as np
+"""PCIe-inclusive rate of the host-pointer entry (development tool; never the benchmarked path): pageable vs pinned host
+memory, mean-only and "V1 full", per call of cpi_preintegrate_batch_host."""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import cpi_amd
 from cpi_amd import synth
-from cpi_amd._lib import CpiOutputs
 
 eng = cpi_amd.Engine(device=0)
-lib = eng.lib
-for W in (10000, 100000):
-    kn, lin, q = synth.make_windows(W, 50, seed=3)
-    kn, lin = np.ascontiguousarray(kn.numpy()), np.ascontiguousarray(lin.numpy())
-    out = {k: np.zeros((W, n)) for k, n in (("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4))}
-    o = CpiOutputs()
-    for k, v in out.items():
-        setattr(o, k, v.ctypes.data)
-    prm = eng.make_params(1)
-    dp = lambda a: a.ctypes.data_as(C.c_void_p)
-    def call():
-        rc = lib.cpi_preintegrate_batch_host(eng.ctx, C.byref(prm), W, 50, dp(kn), None, None, 0, dp(lin), None, C.byref(o))
-        assert rc == 0, lib.cpi_last_error(eng.ctx)
-    call(); call()
-    t0 = time.perf_counter(); reps = 10
-    for _ in range(reps): call()
-    dt = (time.perf_counter() - t0) / reps
-    print("host-pointer path: W=%d  %.3f ms per call  %.1f M windows/s  (%.1f GB/s over PCIe, pageable host memory)" % (
-        W, dt * 1e3, W / dt / 1e6, W * 2944 / dt / 1e9))
+for W in (10000, 100000, 1000000):
+    kn, lin, q = synth.make_windows(W, 50, seed=3, device=eng.device)
+    kn, lin = kn.cpu(), lin.cpu()
+    for pinned in (False, True):
+        k2, l2 = (kn.pin_memory(), lin.pin_memory()) if pinned else (kn, lin)
+        for want, nbytes in ((("mean",), 2944), (("mean", "jac", "cov"), 2856 + 2320)):
+            prm = eng.make_params(1)
+            out = eng.preintegrate_host(k2, l2, None, prm, want=want, pinned=pinned)   # the caller's buffers: allocated (and touched) once
+            reps = 5 if W >= 1000000 else 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.preintegrate_host(k2, l2, None, prm, want=want, pinned=pinned, out=out)
+            dt = (time.perf_counter() - t0) / reps
+            print("host entry  W=%-8d %-8s %-9s %8.3f ms per call  %6.1f M windows/s  %5.1f GB/s over PCIe (both directions summed)" % (
+                W, "pinned" if pinned else "pageable", "full-V1" if len(want) > 1 else "mean", dt * 1e3, W / dt / 1e6, W * nbytes / dt / 1e9), flush=True)
