@@ -24,6 +24,7 @@ for row in $ROWS; do
     v1_full|cfg5_full) K="cpi_cov_kernel<1;cpi_mean_kernel<1, true";;
     v2_full) K="cpi_cov_kernel<2";;
     forster_full) K="cpi_forster_kernel";;
+    factor_v1_packed|factor_v2_packed) K="cpi_factor_packed_kernel";;
     factor_v1) K="cpi_factor_kernel<1";;
     factor_v2) K="cpi_factor_kernel<2";;
     *) K="cpi_";;
