@@ -143,6 +143,30 @@ def test_cpp_host_sharding_a_batch_over_the_device_set(golden_dir):
         assert "gathered on rank 0" in p.stderr
 
 
+def test_cpp_host_threads_one_context_each(golden_dir):
+    """tests/cpp/test_threads.cpp: four host threads, one context each, run the host-pointer preintegration (pipelined
+    staging owned by the context) and the factor sweep concurrently; each must match the single-threaded run bit for bit."""
+    import os
+    import subprocess
+    import tempfile
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from cpi_amd import _lib, synth
+    _lib.load()
+    exe = os.path.join(tempfile.mkdtemp(), "test_threads")
+    libdir = os.path.join(ROOT, "cpi_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "test_threads.cpp"), "-o", exe, "-L" + libdir, "-lcpi_amd",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    W, N = 70001, 10                                         # two pipeline chunks per call
+    kn, lin, q = synth.make_windows(W, N, seed=77)
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        np.array([W, N], dtype=np.float64).tofile(f)
+        kn.numpy().tofile(f); lin.numpy().tofile(f); q.numpy().tofile(f)
+        path = f.name
+    p = subprocess.run([exe, path, "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0 and "threads ok T=4" in p.stdout, (p.returncode, p.stdout, p.stderr)
+
+
 def test_bench_gpus_2_end_to_end_rehearsal_on_one_gpu():
     """`python bench.py --gpus 2` with no launcher: re-executes under torch.distributed.run with two ranks, shards, runs
     the kernels, gathers the last step's slabs to rank 0, reduces the timing over the ranks and prints ONE line with
