@@ -47,8 +47,8 @@ WORKLOADS = {
     "factor_v1": dict(model=1, factor=True, W=1000000, N=50, bytes=776 + 3720, kernel="cpi_factor_kernel<1,false,8>"),
     "factor_v2": dict(model=2, factor=True, W=1000000, N=50, bytes=952 + 3720, kernel="cpi_factor_kernel<2,false,8>"),
     # packed evaluateError (state-dependent blocks only, include/cpi_amd.h): NOT the dense GTSAM-shaped output
-    "factor_v1_packed": dict(model=1, factor=True, packed=True, W=1000000, N=50, bytes=776 + 576, kernel="cpi_factor_packed_kernel<1>"),
-    "factor_v2_packed": dict(model=2, factor=True, packed=True, W=1000000, N=50, bytes=952 + 576, kernel="cpi_factor_packed_kernel<2>"),
+    "factor_v1_packed": dict(model=1, factor=True, packed=True, W=1000000, N=50, bytes=776 + 576, kernel="cpi_factor_packed_kernel<1,L>"),
+    "factor_v2_packed": dict(model=2, factor=True, packed=True, W=1000000, N=50, bytes=952 + 576, kernel="cpi_factor_packed_kernel<2,L>"),
     # the same mean-only recursion on the TILED input layout (knots of 64 windows interleaved per step; include/cpi_amd.h)
     "v1_mean_tiled": dict(model=1, want=("mean",), W=1000000, N=50, bytes=2856 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<1,false,false>"),
     "v2_mean_tiled": dict(model=2, want=("mean",), W=1000000, N=50, bytes=2888 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<2,false,false>"),

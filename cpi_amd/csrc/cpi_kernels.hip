@@ -1513,17 +1513,17 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
 // H1(12,0), H1(0,3), H2(0,0) and R(q_GtoK), which appears five times; the rest is 0, +-I or a copy of a measurement
 // field the caller already holds.  72 doubles per factor (15 residual + 6 blocks + 3 of padding, 576 B = 36 x 16 B)
 // instead of 465: the sweep stops being bound by the write of mostly-constant matrices.
-// 8 lanes per factor: lane q = 0..2 owns column q of H1 (blocks (0,0), (6,0), (12,0)), of H2(0,0) and of R(q_GtoK);
-// lane q = 3..5 owns column q of H1 (block (0,3)); residual rows q and q + 8.
+// LPF lanes per factor: lane q owns the columns q, q + LPF, ... < 6 of H1 (column c < 3: blocks (0,0), (6,0), (12,0), plus
+// column c of H2(0,0) and of R(q_GtoK); 3 <= c < 6: block (0,3)) and the residual rows q, q + LPF, ... < 15.
 constexpr int FACTOR_PACKED_DOUBLES = 72;
-template <int MODEL>
+template <int MODEL, int LPF>
 __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, double *packed) {
-    constexpr int LPF = 8, FPW = 8, PD = FACTOR_PACKED_DOUBLES, IN_D = fin::IN_D;
+    constexpr int FPW = 64 / LPF, PD = FACTOR_PACKED_DOUBLES, IN_D = fin::IN_D;
     __shared__ __attribute__((aligned(16))) double sP[FPW * PD];
     __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];
     __shared__ double sDummy[2];
     const int lane = threadIdx.x;
-    const int q = lane % LPF, fl = lane / LPF;
+    const int q = lane % LPF, fl = min(lane / LPF, FPW - 1);   // 64 mod LPF spare lanes repeat the last factor's lane 0 (same values, same slots)
     const long long f0 = (long long)blockIdx.x * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sIn, sDummy);
@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, dou
         V3 e5[5];
         factor_shared_core<MODEL>(m, S, e5);
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < (15 + LPF - 1) / LPF; k++) {
             const int c = q + LPF * k;
             if (c < 15) {
                 const V3 ec = pick5(e5[0], e5[1], e5[2], e5[3], e5[4], c / 3);
@@ -1545,29 +1545,32 @@ __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, dou
         }
     }
     const Q4 qi = ldq(m.xi);
-    if (q < 6) {
-        double h[15];
-        S.bc = q / 3; S.cc = q - 3 * S.bc;
-        S.u = unit(S.cc);
-        S.rku = qrot(qi, S.u);
-        factor_H1_column<MODEL>(S, m, h);
-        if (q < 3) {
-            double *b = out + 15 + 3 * q;                    // H1(0,0), H1(6,0), H1(12,0): column q of each
-            b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
-            b[9] = h[6]; b[10] = h[7]; b[11] = h[8];
-            b[18] = h[12]; b[19] = h[13]; b[20] = h[14];
-            double h2[15];
-            factor_H2_column(S, h2);
-            double *r = out + 51 + 3 * q;                    // R(q_GtoK) column q, then H2(0,0) column q
-            r[0] = S.rku.x; r[1] = S.rku.y; r[2] = S.rku.z;
-            r[9] = h2[0]; r[10] = h2[1]; r[11] = h2[2];
-        } else {
-            double *b = out + 42 + 3 * (q - 3);              // H1(0,3) column q - 3
-            b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
+#pragma unroll
+    for (int k = 0; k < (6 + LPF - 1) / LPF; k++) {
+        const int c = q + LPF * k;               // column c of H1: 0..2 -> blocks (0,0), (6,0), (12,0) (+ H2(0,0), R(q_GtoK)); 3..5 -> block (0,3)
+        if (c < 6) {
+            double h[15];
+            S.bc = c / 3; S.cc = c - 3 * S.bc;
+            S.u = unit(S.cc);
+            S.rku = qrot(qi, S.u);
+            factor_H1_column<MODEL>(S, m, h);
+            if (c < 3) {
+                double *b = out + 15 + 3 * c;                    // H1(0,0), H1(6,0), H1(12,0): column c of each
+                b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
+                b[9] = h[6]; b[10] = h[7]; b[11] = h[8];
+                b[18] = h[12]; b[19] = h[13]; b[20] = h[14];
+                double h2[15];
+                factor_H2_column(S, h2);
+                double *r = out + 51 + 3 * c;                    // R(q_GtoK) column c, then H2(0,0) column c
+                r[0] = S.rku.x; r[1] = S.rku.y; r[2] = S.rku.z;
+                r[9] = h2[0]; r[10] = h2[1]; r[11] = h2[2];
+            } else {
+                double *b = out + 42 + 3 * (c - 3);              // H1(0,3) column c - 3
+                b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
+            }
         }
-    } else if (q == 6) {
-        out[69] = 0.0; out[70] = 0.0; out[71] = 0.0;
     }
+    if (q == LPF - 1) { out[69] = 0.0; out[70] = 0.0; out[71] = 0.0; }
     wave_lds_fence();
     struct __attribute__((packed, aligned(8))) d2u { double a, b; };
     d2u *dst = reinterpret_cast<d2u *>(packed + f0 * PD);
@@ -2191,9 +2194,16 @@ extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const d
     a.F = F;
     for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
     a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j;
-    const unsigned nb = (unsigned)((F + 7) / 8);
-    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_packed_kernel<1>), dim3(nb), dim3(64), 0, ctx->stream, a, packed);
-    else hipLaunchKernelGGL((cpi_factor_packed_kernel<2>), dim3(nb), dim3(64), 0, ctx->stream, a, packed);
+    // lanes per factor.  Every lane of a factor repeats the shared quaternion algebra, so fewer lanes = less VALU per factor
+    // but more LDS per wavefront (a factor's staged record + packed output = 1.5 KB).  Measured (MI355X, 1 M factors, model 1 /
+    // model 2, us): 8 lanes 383 / 435 (VALU 53 % busy at 2 wavefronts per SIMD), 6: 335 / 389, 4: 290 / 324, 3: 281 / 314,
+    // 2: 328 / 361 (48 KB of LDS: one wavefront per SIMD); 100 k factors: 4 lanes 31.5, 3 lanes 32.5.
+    int lpf = (F >= 300000) ? 3 : 4;
+    if (const char *e = getenv("CPI_AMD_PACKED_LPF")) lpf = atoi(e);   // measurements
+#define CPI_PACKED(M, L) hipLaunchKernelGGL((cpi_factor_packed_kernel<M, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a, packed)
+    if (model == CPI_MODEL_V1) { if (lpf == 2) CPI_PACKED(1, 2); else if (lpf == 3) CPI_PACKED(1, 3); else if (lpf == 4) CPI_PACKED(1, 4); else if (lpf == 6) CPI_PACKED(1, 6); else CPI_PACKED(1, 8); }
+    else                       { if (lpf == 2) CPI_PACKED(2, 2); else if (lpf == 3) CPI_PACKED(2, 3); else if (lpf == 4) CPI_PACKED(2, 4); else if (lpf == 6) CPI_PACKED(2, 6); else CPI_PACKED(2, 8); }
+#undef CPI_PACKED
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
