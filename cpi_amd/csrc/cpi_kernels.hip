@@ -216,6 +216,19 @@ struct PreArgs {
 // ============================================================================================
 // mean (+ analytic Jacobian) kernel
 // ============================================================================================
+// Workgroups are dispatched to the 8 XCDs round-robin (workgroup b -> XCD b mod 8).  HBM WRITES run 25-30 % faster when
+// every XCD writes ONE contiguous eighth of the output instead of every eighth span of it (measured with pure-store kernels,
+// tools/exp/store_bw.hip: wavefronts writing consecutive 14.4-KB spans 5.25-5.3 TB/s, the same spans XCD-contiguous 5.7 TB/s on
+// one box and 7.0 TB/s on another, hipMemset 6.3-6.6; reads do not care: 6.0-6.8 TB/s either way).  The factor sweeps gain
+// 2-3 % (their mixed 1 : 4.8 read : write traffic tops out near 5.1 TB/s in a plain copy kernel of the same shape; the dense
+// sweep moves 5.5).  Kernels whose time is their output are launched with the grid rounded up to a multiple of 8 (grid8) and
+// work on block xcd_block(): -1 = one of the <= 7 padding workgroups.
+__device__ __forceinline__ long long xcd_block(long long nblocks) {
+    const unsigned per = gridDim.x >> 3;
+    const long long b = (long long)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    return b < nblocks ? b : -1;
+}
+static inline unsigned grid8(long long nblocks) { return (unsigned)((nblocks + 7) / 8 * 8); }
 #ifndef CPI_MEAN_WPS
 #define CPI_MEAN_WPS 1
 #endif
@@ -590,6 +603,7 @@ struct TiledArgs {
     double grav[3];
     cpi_outputs out;
     int dbg;   // measurement only (CPI_AMD_BLK_MODE): 1 = fetch without arithmetic
+    long long ts, ss;   // doubles between consecutive tiles / consecutive steps of a tile
 };
 #ifndef CPI_TILED_OCC
 #define CPI_TILED_OCC (MODEL == 2 ? 2 : 3)
@@ -616,14 +630,14 @@ __global__ __launch_bounds__(SPLIT ? 512 : 64, SPLIT ? 1 : CPI_TILED_OCC) void c
     const int nmax = COUNTED ? __builtin_amdgcn_readfirstlane(wave_max(n)) : A.N;
     const int per = SPLIT ? (A.N + S - 1) / S : A.N;
     const int sb = __builtin_amdgcn_readfirstlane(j * per), se = min(sb + per, nmax);   // this wavefront's steps
-    const double *tb = A.tiles + (long long)blockIdx.x * (long long)(A.N + 1) * 448 + lane;   // 448 = 7 fields x 64 windows
+    const double *tb = A.tiles + (long long)blockIdx.x * A.ts + lane;   // a step of a tile: 448 doubles = 7 fields x 64 windows
     const V3 bw = ldv3(A.lin + wc * 6), ba = ldv3(A.lin + wc * 6 + 3);
     V3 gk = mk(0, 0, 0);
     if (MODEL == 2 && j == 0) gk = mul(quat_2_Rot(ldq4(A.qk + wc * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
     auto load = [&](double (&k)[7], int s) {
         // COUNTED: past its own last knot a lane re-reads that knot (dt = 0) -- what lies behind it in the column is
         // never read.  Otherwise the row offset is wave-uniform (scalar address arithmetic).
-        const double *p = tb + (long long)(COUNTED ? min(s, n) : min(s, A.N)) * 448;
+        const double *p = tb + (long long)(COUNTED ? min(s, n) : min(s, A.N)) * A.ss;
 #pragma unroll
         for (int f = 0; f < 7; f++) k[f] = p[f * 64];
     };
@@ -732,9 +746,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 64, SPLIT ? 1 : CPI_TILED_OCC) void c
 __global__ __launch_bounds__(64, 3) void cpi_tiled_fetch_probe_kernel(TiledArgs A) {
     const int lane = threadIdx.x;
     const long long w = (long long)blockIdx.x * 64 + lane;
-    const double *tb = A.tiles + (long long)blockIdx.x * (long long)(A.N + 1) * 448 + lane;
+    const double *tb = A.tiles + (long long)blockIdx.x * A.ts + lane;
     auto load = [&](double (&k)[7], int s) {
-        const double *p = tb + (long long)min(s, A.N) * 448;
+        const double *p = tb + (long long)min(s, A.N) * A.ss;
 #pragma unroll
         for (int f = 0; f < 7; f++) k[f] = p[f * 64];
     };
@@ -749,7 +763,7 @@ __global__ __launch_bounds__(64, 3) void cpi_tiled_fetch_probe_kernel(TiledArgs 
     if (w < A.W && A.out.DT) A.out.DT[w] = acc;
 }
 // dense knots[W][N+1][7] -> tiles[ceil(W/64)][N+1][7][64] (windows past W replicate window W - 1: finite padding)
-__global__ __launch_bounds__(256) void cpi_tile_knots_kernel(long long W, int N, const double *knots, double *tiles) {
+__global__ __launch_bounds__(256) void cpi_tile_knots_kernel(long long W, int N, const double *knots, double *tiles, long long ts, long long ss) {
     const long long total = ((W + 63) / 64) * (long long)(N + 1) * 448;
     for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
         const int i = (int)(o & 63);
@@ -759,7 +773,7 @@ __global__ __launch_bounds__(256) void cpi_tile_knots_kernel(long long W, int N,
         const int sidx = (int)(bs % (N + 1));
         const long long b = bs / (N + 1);
         const long long w = min(b * 64 + i, W - 1);
-        tiles[o] = knots[(w * (N + 1) + sidx) * 7 + f];
+        tiles[b * ts + sidx * ss + f * 64 + i] = knots[(w * (N + 1) + sidx) * 7 + f];
     }
 }
 
@@ -1408,7 +1422,9 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the factors' R
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = lane / LPF;
-    const long long f0 = (long long)blockIdx.x * FPW;
+    const long long blk = xcd_block((A.F + FPW - 1) / FPW);
+    if (blk < 0) return;
+    const long long f0 = blk * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     constexpr bool whiten = WHITEN;
 
@@ -1524,7 +1540,9 @@ __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, dou
     __shared__ double sDummy[2];
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = min(lane / LPF, FPW - 1);   // 64 mod LPF spare lanes repeat the last factor's lane 0 (same values, same slots)
-    const long long f0 = (long long)blockIdx.x * FPW;
+    const long long blk = xcd_block((A.F + FPW - 1) / FPW);
+    if (blk < 0) return;
+    const long long f0 = blk * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sIn, sDummy);
     __syncthreads();
@@ -1621,7 +1639,9 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
     constexpr int FPW = 4;
     __shared__ __attribute__((aligned(16))) double sA[FPW * 225];
     const int lane = threadIdx.x, j = lane & 15, fl = lane >> 4;
-    const long long f0 = (long long)blockIdx.x * FPW;
+    const long long blk = xcd_block((F + FPW - 1) / FPW);
+    if (blk < 0) return;
+    const long long f0 = blk * FPW;
     const int nf = (int)min((long long)FPW, F - f0);
     struct __attribute__((packed, aligned(8))) d2u { double a, b; };
     {
@@ -1670,7 +1690,9 @@ __global__ __launch_bounds__(64, 1) void cpi_factor_hessian_kernel(FactorArgs A,
     __shared__ __attribute__((aligned(16))) double sP[FPW * HESS_PACKED];   // packed output stage (consecutive 16-byte stores)
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = lane / LPF;
-    const long long f0 = (long long)blockIdx.x * FPW;
+    const long long blk = xcd_block((A.F + FPW - 1) / FPW);
+    if (blk < 0) return;
+    const long long f0 = blk * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     factor_fetch_inputs<MODEL, FPW, true>(A, f0, nf, lane, sIn, sR);
     __syncthreads();
@@ -2157,7 +2179,7 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
     // lanes per factor: 16 gives the most wavefronts (small sweeps), fewer lanes do less redundant arithmetic
     const int lpf = factor_lanes(F, sqrt_info != nullptr);
 #define CPI_LAUNCH_FACTOR(M, WH, L) \
-    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a)
+    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3(grid8((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a)
 #define CPI_LAUNCH_FACTOR_L(M, WH) \
     do { if (lpf == 16) CPI_LAUNCH_FACTOR(M, WH, 16); else if (lpf == 8) CPI_LAUNCH_FACTOR(M, WH, 8); else CPI_LAUNCH_FACTOR(M, WH, 4); } while (0)
     if (sqrt_info) {
@@ -2200,7 +2222,7 @@ extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const d
     // 2: 328 / 361 (48 KB of LDS: one wavefront per SIMD); 100 k factors: 4 lanes 31.5, 3 lanes 32.5.
     int lpf = (F >= 300000) ? 3 : 4;
     if (const char *e = getenv("CPI_AMD_PACKED_LPF")) lpf = atoi(e);   // measurements
-#define CPI_PACKED(M, L) hipLaunchKernelGGL((cpi_factor_packed_kernel<M, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a, packed)
+#define CPI_PACKED(M, L) hipLaunchKernelGGL((cpi_factor_packed_kernel<M, L>), dim3(grid8((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a, packed)
     if (model == CPI_MODEL_V1) { if (lpf == 2) CPI_PACKED(1, 2); else if (lpf == 3) CPI_PACKED(1, 3); else if (lpf == 4) CPI_PACKED(1, 4); else if (lpf == 6) CPI_PACKED(1, 6); else CPI_PACKED(1, 8); }
     else                       { if (lpf == 2) CPI_PACKED(2, 2); else if (lpf == 3) CPI_PACKED(2, 3); else if (lpf == 4) CPI_PACKED(2, 4); else if (lpf == 6) CPI_PACKED(2, 6); else CPI_PACKED(2, 8); }
 #undef CPI_PACKED
@@ -2216,7 +2238,7 @@ extern "C" int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double 
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
     const long long nb = (F + 3) / 4;
-    hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, (long long)F, P, sqrt_info);
+    hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3(grid8(nb)), dim3(64), 0, ctx->stream, (long long)F, P, sqrt_info);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
@@ -2252,7 +2274,7 @@ extern "C" int cpi_factor_hessian_batch(cpi_ctx *ctx, int32_t model, const doubl
     a.F = F;
     for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
     a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j; a.sqrt_info = sqrt_info;
-    const unsigned nb = (unsigned)((F + 3) / 4);
+    const unsigned nb = grid8((F + 3) / 4);
     if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_hessian_kernel<1>), dim3(nb), dim3(64), 0, ctx->stream, a, hess);
     else hipLaunchKernelGGL((cpi_factor_hessian_kernel<2>), dim3(nb), dim3(64), 0, ctx->stream, a, hess);
     CPI_HIP(ctx, hipGetLastError());
@@ -2300,7 +2322,10 @@ extern "C" int cpi_tile_knots(cpi_ctx *ctx, int64_t W, int32_t N, const double *
     CPI_HIP(ctx, guard_.enter(ctx->device));
     const long long total = ((W + 63) / 64) * (long long)(N + 1) * 448;
     const unsigned nb = (unsigned)std::min<long long>((total + 255) / 256, 256 * 64);
-    hipLaunchKernelGGL(cpi_tile_knots_kernel, dim3(nb), dim3(256), 0, ctx->stream, (long long)W, (int)N, knots, tiles);
+    // tile-major.  (Step-major -- tiles[N+1][ceil(W/64)][7][64], all resident wavefronts reading one moving window -- was
+    // measured: 557 vs 571 us per 1 M x 50, 58.2 vs 61.1 us per 100 k, stream alone 472 vs 481 us: not worth a second contract.)
+    const long long ts = (long long)(N + 1) * 448, ss = 448;
+    hipLaunchKernelGGL(cpi_tile_knots_kernel, dim3(nb), dim3(256), 0, ctx->stream, (long long)W, (int)N, knots, tiles, ts, ss);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
@@ -2325,6 +2350,7 @@ extern "C" int cpi_preintegrate_tiled_batch(cpi_ctx *ctx, const cpi_params *prm,
     a.W = W; a.N = N; a.tiles = tiles; a.count = count; a.lin = lin; a.qk = q_k_lin; a.out = *out;
     for (int i = 0; i < 3; i++) a.grav[i] = prm->grav[i];
     if (const char *e = getenv("CPI_AMD_BLK_MODE")) a.dbg = atoi(e);
+    a.ts = (long long)(N + 1) * 448; a.ss = 448;
     const unsigned nb = (unsigned)((W + 63) / 64);
     const bool avg = prm->imu_avg != 0;
     if (a.dbg == 1) {   // CPI_AMD_PROBE_LDS = dynamic LDS bytes per wavefront, to pin the probe's occupancy (13312 -> 12 waves / CU)
