@@ -50,6 +50,22 @@ def main():
                 kn, lin, q = kn.numpy(), lin.numpy(), q.numpy()
                 ref = op.oracle().run(oprm, kn, lin, q, nthreads=8)
                 out = host(eng.preintegrate(dev(kn, eng), dev(lin, eng), dev(q, eng), prm, want=want))
+                # the same batch through the host-pointer entry (one pipeline chunk here: same kernels, same bits) ...
+                hout = eng.preintegrate_host(torch.from_numpy(kn), torch.from_numpy(lin), torch.from_numpy(q), prm, want=want,
+                                             pinned=bool(rng.integers(0, 2)))
+                for k in out:
+                    assert np.array_equal(hout[k].numpy(), out[k]), "host entry differs in " + k
+                # ... and, for models 1 / 2, the mean outputs through the tiled layout with a random split over wavefronts
+                if model < 3:
+                    split = int(rng.choice([0, 1, 2, 3, 4, 5, 8]))
+                    if split:
+                        os.environ["CPI_AMD_TILED_SPLIT"] = str(split)
+                    else:
+                        os.environ.pop("CPI_AMD_TILED_SPLIT", None)
+                    tiles = eng.tile_knots(dev(kn, eng))
+                    tout = host(eng.preintegrate_tiled(tiles, W, dev(lin, eng), dev(q, eng), prm))
+                    os.environ.pop("CPI_AMD_TILED_SPLIT", None)
+                    check_pre(tout, ref, what=("mean",), v2=(model == 2), label=label + " tiled split %d" % split)
             else:
                 lens = rng.integers(0, N + 1, W).astype(np.int32)
                 lens[rng.integers(0, W)] = N
