@@ -216,19 +216,6 @@ struct PreArgs {
 // ============================================================================================
 // mean (+ analytic Jacobian) kernel
 // ============================================================================================
-// Workgroups are dispatched to the 8 XCDs round-robin (workgroup b -> XCD b mod 8).  HBM WRITES run 25-30 % faster when
-// every XCD writes ONE contiguous eighth of the output instead of every eighth span of it (measured with pure-store kernels,
-// tools/exp/store_bw.hip: wavefronts writing consecutive 14.4-KB spans 5.25-5.3 TB/s, the same spans XCD-contiguous 5.7 TB/s on
-// one box and 7.0 TB/s on another, hipMemset 6.3-6.6; reads do not care: 6.0-6.8 TB/s either way).  The factor sweeps gain
-// 2-3 % (their mixed 1 : 4.8 read : write traffic tops out near 5.1 TB/s in a plain copy kernel of the same shape; the dense
-// sweep moves 5.5).  Kernels whose time is their output are launched with the grid rounded up to a multiple of 8 (grid8) and
-// work on block xcd_block(): -1 = one of the <= 7 padding workgroups.
-__device__ __forceinline__ long long xcd_block(long long nblocks) {
-    const unsigned per = gridDim.x >> 3;
-    const long long b = (long long)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    return b < nblocks ? b : -1;
-}
-static inline unsigned grid8(long long nblocks) { return (unsigned)((nblocks + 7) / 8 * 8); }
 #ifndef CPI_MEAN_WPS
 #define CPI_MEAN_WPS 1
 #endif
@@ -1422,9 +1409,7 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the factors' R
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = lane / LPF;
-    const long long blk = xcd_block((A.F + FPW - 1) / FPW);
-    if (blk < 0) return;
-    const long long f0 = blk * FPW;
+    const long long f0 = (long long)blockIdx.x * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     constexpr bool whiten = WHITEN;
 
@@ -1540,9 +1525,7 @@ __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, dou
     __shared__ double sDummy[2];
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = min(lane / LPF, FPW - 1);   // 64 mod LPF spare lanes repeat the last factor's lane 0 (same values, same slots)
-    const long long blk = xcd_block((A.F + FPW - 1) / FPW);
-    if (blk < 0) return;
-    const long long f0 = blk * FPW;
+    const long long f0 = (long long)blockIdx.x * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sIn, sDummy);
     __syncthreads();
@@ -1639,9 +1622,7 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
     constexpr int FPW = 4;
     __shared__ __attribute__((aligned(16))) double sA[FPW * 225];
     const int lane = threadIdx.x, j = lane & 15, fl = lane >> 4;
-    const long long blk = xcd_block((F + FPW - 1) / FPW);
-    if (blk < 0) return;
-    const long long f0 = blk * FPW;
+    const long long f0 = (long long)blockIdx.x * FPW;
     const int nf = (int)min((long long)FPW, F - f0);
     struct __attribute__((packed, aligned(8))) d2u { double a, b; };
     {
@@ -1690,9 +1671,7 @@ __global__ __launch_bounds__(64, 1) void cpi_factor_hessian_kernel(FactorArgs A,
     __shared__ __attribute__((aligned(16))) double sP[FPW * HESS_PACKED];   // packed output stage (consecutive 16-byte stores)
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = lane / LPF;
-    const long long blk = xcd_block((A.F + FPW - 1) / FPW);
-    if (blk < 0) return;
-    const long long f0 = blk * FPW;
+    const long long f0 = (long long)blockIdx.x * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     factor_fetch_inputs<MODEL, FPW, true>(A, f0, nf, lane, sIn, sR);
     __syncthreads();
@@ -2179,7 +2158,7 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
     // lanes per factor: 16 gives the most wavefronts (small sweeps), fewer lanes do less redundant arithmetic
     const int lpf = factor_lanes(F, sqrt_info != nullptr);
 #define CPI_LAUNCH_FACTOR(M, WH, L) \
-    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3(grid8((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a)
+    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a)
 #define CPI_LAUNCH_FACTOR_L(M, WH) \
     do { if (lpf == 16) CPI_LAUNCH_FACTOR(M, WH, 16); else if (lpf == 8) CPI_LAUNCH_FACTOR(M, WH, 8); else CPI_LAUNCH_FACTOR(M, WH, 4); } while (0)
     if (sqrt_info) {
@@ -2222,7 +2201,7 @@ extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const d
     // 2: 328 / 361 (48 KB of LDS: one wavefront per SIMD); 100 k factors: 4 lanes 31.5, 3 lanes 32.5.
     int lpf = (F >= 300000) ? 3 : 4;
     if (const char *e = getenv("CPI_AMD_PACKED_LPF")) lpf = atoi(e);   // measurements
-#define CPI_PACKED(M, L) hipLaunchKernelGGL((cpi_factor_packed_kernel<M, L>), dim3(grid8((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a, packed)
+#define CPI_PACKED(M, L) hipLaunchKernelGGL((cpi_factor_packed_kernel<M, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a, packed)
     if (model == CPI_MODEL_V1) { if (lpf == 2) CPI_PACKED(1, 2); else if (lpf == 3) CPI_PACKED(1, 3); else if (lpf == 4) CPI_PACKED(1, 4); else if (lpf == 6) CPI_PACKED(1, 6); else CPI_PACKED(1, 8); }
     else                       { if (lpf == 2) CPI_PACKED(2, 2); else if (lpf == 3) CPI_PACKED(2, 3); else if (lpf == 4) CPI_PACKED(2, 4); else if (lpf == 6) CPI_PACKED(2, 6); else CPI_PACKED(2, 8); }
 #undef CPI_PACKED
@@ -2238,7 +2217,7 @@ extern "C" int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double 
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
     const long long nb = (F + 3) / 4;
-    hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3(grid8(nb)), dim3(64), 0, ctx->stream, (long long)F, P, sqrt_info);
+    hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, (long long)F, P, sqrt_info);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
@@ -2274,7 +2253,7 @@ extern "C" int cpi_factor_hessian_batch(cpi_ctx *ctx, int32_t model, const doubl
     a.F = F;
     for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
     a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j; a.sqrt_info = sqrt_info;
-    const unsigned nb = grid8((F + 3) / 4);
+    const unsigned nb = (unsigned)((F + 3) / 4);
     if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_hessian_kernel<1>), dim3(nb), dim3(64), 0, ctx->stream, a, hess);
     else hipLaunchKernelGGL((cpi_factor_hessian_kernel<2>), dim3(nb), dim3(64), 0, ctx->stream, a, hess);
     CPI_HIP(ctx, hipGetLastError());
