@@ -49,3 +49,37 @@ def test_configs4_full_size_block_periodicity():
     assert torch.isfinite(P[::9973]).all() and (P[::9973].diagonal(dim1=1, dim2=2) > 0).all()
     del full, big, P
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_configs3_full_size_sweep_block_periodicity(model):
+    """configs[3] at its full size: 1 M factors (3.7 GB of err / H1 / H2) = 125 k factors repeated 8 times through the index
+    arrays; dense, packed and whitened sweeps must be block-periodic bit for bit, and the first block equal to the
+    125 k-factor call."""
+    import cpi_amd
+    eng = cpi_amd.Engine()
+    F1, R = 125000, 8
+    kn, lin1, q1 = synth.make_windows(F1, 20, seed=606 + model, device=eng.device)
+    meas1 = eng.preintegrate(kn, lin1, q1, eng.make_params(model))
+    xi, xj = synth.make_states(meas1["alpha"], meas1["beta"], meas1["q"], meas1["DT"], lin1, model, device=eng.device)
+    states = torch.cat([xi, xj], 0).contiguous()
+    ii1 = torch.arange(F1, dtype=torch.int32, device=eng.device)
+    qq1 = q1 if model == 2 else None
+    ref = eng.factor_eval(model, meas1, lin1, qq1, states, ii1, ii1 + F1)
+    meas = {k: (v.repeat(R, 1) if v.dim() == 2 else v.repeat(R)) for k, v in meas1.items() if not k.startswith("_")}
+    lin, qq = lin1.repeat(R, 1), (q1.repeat(R, 1) if model == 2 else None)
+    ii = ii1.repeat(R)
+    F = F1 * R
+    sq = eng.sqrt_information(meas["P"])
+    for name, out in (("dense", eng.factor_eval(model, meas, lin, qq, states, ii, ii + F1)),
+                      ("packed", {"packed": eng.factor_eval_packed(model, meas, lin, qq, states, ii, ii + F1)}),
+                      ("whitened", eng.factor_eval(model, meas, lin, qq, states, ii, ii + F1, sqrt_info=sq))):
+        torch.cuda.synchronize()
+        for k, v in out.items():
+            b = v.reshape(R, F1, -1)
+            for r in range(1, R):
+                assert torch.equal(b[r], b[0]), (name, k, r)
+            if name == "dense":
+                assert torch.equal(b[0], ref[k].reshape(F1, -1)), k
+        del out
+    torch.cuda.empty_cache()
