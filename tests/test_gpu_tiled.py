@@ -107,3 +107,21 @@ def test_tiled_layout_seeded_counts_and_refusals(eng):
     full = eng.alloc_outputs(W, ("mean", "jac", "cov"), 1)
     with pytest.raises(cpi_amd.CpiError):
         eng.preintegrate_tiled(tiles, W, lin, q, eng.make_params(1), out=full)
+
+
+def test_tiled_edge_shapes(eng):
+    """W = 1, W = 0, windows without intervals (N = 0), N smaller than the number of wavefronts per tile."""
+    from oracle import oracle_py as op
+    lib = op.reference() or op.oracle()
+    for W, N in ((1, 50), (65, 1), (3, 0), (130, 3)):
+        kn, lin, q = synth.make_windows(W, max(N, 1), seed=900 + W + N, device=eng.device)
+        kn = kn[:, :N + 1].contiguous()
+        tiles = eng.tile_knots(kn)
+        assert tiles.shape == ((W + 63) // 64, N + 1, 7, 64)
+        for model in (1, 2):
+            out = _host(eng.preintegrate_tiled(tiles, W, lin, q, eng.make_params(model)))
+            ref = lib.run(op.make_params(model, 0, 1), kn.cpu().numpy(), lin.cpu().numpy(), q.cpu().numpy())
+            check_pre(out, ref, what=("mean",))
+    empty = torch.empty((0, 51, 7, 64), dtype=torch.float64, device=eng.device)
+    out = eng.preintegrate_tiled(empty, 0, torch.empty((0, 6), dtype=torch.float64, device=eng.device), None, eng.make_params(1))
+    assert out["DT"].numel() == 0
