@@ -441,6 +441,9 @@ def main():
     rehearsal = bool(os.environ.get("CPI_BENCH_SINGLE_DEVICE"))
     if rehearsal:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d needs device %d but this node shows %d GPU(s) -- one rank per GPU (--gpus N <= devices); "
+                 "CPI_BENCH_SINGLE_DEVICE=1 rehearses the N-rank flow on one device" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if dist_on:
         import torch.distributed as dist
