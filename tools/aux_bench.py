@@ -54,12 +54,15 @@ def main():
         t_pr = timeit(lambda: eng.predict(model, meas, states))
         pk = torch.empty((F, 72), dtype=torch.float64, device=dev)
         t_pk = timeit(lambda: eng.factor_eval_packed(model, meas, lin, qq, states, out=pk))
+        hs = torch.empty((F, 496), dtype=torch.float64, device=dev)
+        t_hs = timeit(lambda: eng.factor_hessian(model, meas, lin, qq, states, R, out=hs))
+        del hs
         gb = lambda b, ms: b * F / (ms * 1e-3) / 1e9
         in_b = 776 if model == 1 else 952
         print("model %d F=%d  sqrt_info %.3f ms (%.0f GB/s)  factor %.3f ms (%.0f GB/s)  whitened %.3f ms (%.0f GB/s)  "
-              "predict %.3f ms (%.0f GB/s)  packed factor %.3f ms (%.0f GB/s)" % (
+              "predict %.3f ms (%.0f GB/s)  packed factor %.3f ms (%.0f GB/s)  hessian blocks %.3f ms (%.0f GB/s)" % (
                   model, F, t_sq, gb(3600, t_sq), t_pl, gb(in_b + 3720, t_pl), t_wh, gb(in_b + 3720 + 1800, t_wh),
-                  t_pr, gb(88 + 128 + 128, t_pr), t_pk, gb(in_b + 576, t_pk)), flush=True)
+                  t_pr, gb(88 + 128 + 128, t_pr), t_pk, gb(in_b + 576, t_pk), t_hs, gb(in_b + 1800 + 3968, t_hs)), flush=True)
         del P, R, out, meas, states
         torch.cuda.empty_cache()
 
