@@ -1665,10 +1665,12 @@ constexpr int HESS_PACKED = 496;
 template <int MODEL>
 __global__ __launch_bounds__(64, 1) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
     constexpr int LPF = 16, FPW = 4, IN_D = fin::IN_D, CP = 16;   // CP: LDS pitch of a whitened column (15 used, 16-B aligned)
-    __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];
-    __shared__ __attribute__((aligned(16))) double sR[FPW * 225];
+    // the packed output stage re-uses the input records and the R matrices: both are dead once the whitened columns sit
+    // in sA (one wavefront per workgroup: program order + the LDS fence below order the re-use) -- 32 KB instead of 43
+    constexpr int IO_D = (FPW * IN_D + FPW * 225 > FPW * HESS_PACKED) ? FPW * IN_D + FPW * 225 : FPW * HESS_PACKED;
+    __shared__ __attribute__((aligned(16))) double sIO[IO_D];
     __shared__ __attribute__((aligned(16))) double sA[FPW * 31 * CP];   // [factor][column][row]
-    __shared__ __attribute__((aligned(16))) double sP[FPW * HESS_PACKED];   // packed output stage (consecutive 16-byte stores)
+    double *sIn = sIO, *sR = sIO + FPW * IN_D, *sP = sIO;
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = lane / LPF;
     const long long f0 = (long long)blockIdx.x * FPW;
@@ -1730,7 +1732,7 @@ __global__ __launch_bounds__(64, 1) void cpi_factor_hessian_kernel(FactorArgs A,
 #pragma unroll
         for (int i = 0; i < 15; i++) {
             const double x = Af[c * CP + i];   // same address for the 16 lanes of a factor: LDS broadcast
-            a1 = fma(x, c1[i], a1);
+            if (c <= 15) a1 = fma(x, c1[i], a1);   // column d1 <= 15 ends at its diagonal: rows 16..30 belong to other lanes
             a2 = fma(x, c2[i], a2);
         }
         // results go to the packed output stage at once (62 accumulators would not fit the register file)
