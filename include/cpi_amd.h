@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define CPI_ABI_VERSION 2   /* 2: state count S in the factor / predict entries; device-set entries (cpi_group_*) */
+#define CPI_ABI_VERSION 2   /* 2: state count S in the factor / predict entries; device-set entries (cpi_group_*);
+                               additions within 2 (new symbols only): tiled layout entries, cpi_host_alloc / _free */
 
 enum { CPI_OK = 0, CPI_ERR_INVALID = 1, CPI_ERR_HIP = 2, CPI_ERR_NO_DEVICE = 3, CPI_ERR_RCCL = 4 };
 enum {
