@@ -12,7 +12,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "cpi_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "cpi_math.hpp"), os.path.join(os.path.dirname(HERE), "include", "cpi_amd.h")]
+KERNEL_PARTS = ["cpi_device_util.hpp", "cpi_mean_kernels.hpp", "cpi_mean_experimental.hpp", "cpi_cov_kernels.hpp", "cpi_factor_kernels.hpp"]
+DEPS = ([SRC, os.path.join(HERE, "csrc", "cpi_math.hpp")] + [os.path.join(HERE, "csrc", f) for f in KERNEL_PARTS] +
+        [os.path.join(os.path.dirname(HERE), "include", "cpi_amd.h")])
 LIB = os.path.join(HERE, "libcpi_amd.so")
 REPORT = os.path.join(HERE, "csrc", "resource_usage.txt")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

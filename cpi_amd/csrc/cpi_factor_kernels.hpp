@@ -1,0 +1,508 @@
+// cpi_factor_kernels.hpp -- evaluateError sweeps (dense, packed, whitened, Hessian blocks), square-root information, state prediction.
+// Part of the single translation unit cpi_kernels.hip (included there, in this order; not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ============================================================================================
+// factor kernels
+// ============================================================================================
+struct FactorArgs {
+    long long F;
+    double grav[3];
+    cpi_outputs meas;
+    const double *lin;
+    const double *qk;
+    const double *states;
+    long long S;               // number of states: indices are clamped into [0, S) (no out-of-bounds read whatever idx holds)
+    const int *idx_i;
+    const int *idx_j;
+    double *err;
+    double *H1;
+    double *H2;
+    const double *sqrt_info;   // optional [F][225] upper-triangular R: outputs are whitened (R err, R H1, R H2)
+};
+
+__device__ __forceinline__ NavState ld_state(const double *p) {
+    NavState s;
+    s.q = ldq4(p); s.bg = ldv3(p + 4); s.v = ldv3(p + 7); s.ba = ldv3(p + 10); s.p = ldv3(p + 13);
+    return s;
+}
+
+// One SoA input field (K doubles per factor) of the FPW consecutive factors of a wavefront: FPW*K contiguous
+// doubles, lane i takes doubles i, i + 64, ...  load() is unconditional (index clamped to the last valid double),
+// store() writes record-major into the LDS staging area.
+template <int FPW, int K>
+struct FieldFetch {
+    static constexpr int R = (FPW * K + 63) / 64;
+    double v[R];
+    __device__ __forceinline__ void load(const double *src, long long f0, int nf, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = src[f0 * K + min(lane + 64 * r, nf * K - 1)];
+    }
+    __device__ __forceinline__ void store(double *sIn, int pitch, int off, int lane) const {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = lane + 64 * r, g = i / K;
+            if (i < FPW * K) sIn[g * pitch + off + (i - g * K)] = v[r];
+        }
+    }
+};
+
+// Record layout of one factor in the LDS staging area (doubles)
+namespace fin {
+constexpr int O_ALPHA = 0, O_BETA = 3, O_Q = 6, O_LIN = 10, O_JQ = 16, O_JB = 25, O_JA = 34, O_HB = 43, O_HA = 52,
+              O_DT = 61, O_QK = 62, O_OB = 66, O_OA = 75, O_XI = 84, O_XJ = 100, IN_D = 116;
+}
+template <int MODEL, int FPW, bool WHITEN>
+__device__ __forceinline__ void factor_fetch_inputs(const FactorArgs &A, long long f0, int nf, int lane, double *sIn,
+                                                    double *sR) {
+    using namespace fin;
+    constexpr bool whiten = WHITEN;
+    constexpr int HB = FPW * 225;
+    // ---- cooperative, de-duplicated input fetch: every double of the FPW factors' records is loaded from HBM
+    // exactly once per wavefront (consecutive lanes = consecutive doubles of one SoA field) into LDS, from
+    // where the lanes of a factor read it as broadcasts.  All loads are issued unconditionally (clamped
+    // addresses) before the first LDS write, so the wavefront pays ONE memory latency (two for the states
+    // when they are gathered through idx_i / idx_j), not one per field.
+    {
+        constexpr int SR = (FPW * 16 + 63) / 64;
+        long long si[SR], sj[SR];
+#pragma unroll
+        for (int r = 0; r < SR; r++) {
+            const int i = min(lane + 64 * r, FPW * 16 - 1), g = i >> 4;
+            const long long ff = min(f0 + g, A.F - 1);
+            // branch-free NULL handling (a valid dummy address is read and discarded) keeps all loads in one block
+            const int vi = (A.idx_i ? A.idx_i : reinterpret_cast<const int *>(A.states))[ff];
+            const int vj = (A.idx_j ? A.idx_j : reinterpret_cast<const int *>(A.states))[ff];
+            si[r] = min(max(A.idx_i ? (long long)vi : ff, 0ll), A.S - 1);
+            sj[r] = min(max(A.idx_j ? (long long)vj : ff + 1, 0ll), A.S - 1);
+        }
+        FieldFetch<FPW, 3> f_alpha, f_beta; FieldFetch<FPW, 4> f_q, f_qk; FieldFetch<FPW, 6> f_lin;
+        FieldFetch<FPW, 9> f_jq, f_jb, f_ja, f_hb, f_ha, f_ob, f_oa; FieldFetch<FPW, 1> f_dt;
+        f_alpha.load(A.meas.alpha, f0, nf, lane); f_beta.load(A.meas.beta, f0, nf, lane); f_q.load(A.meas.q, f0, nf, lane);
+        f_lin.load(A.lin, f0, nf, lane); f_jq.load(A.meas.J_q, f0, nf, lane); f_jb.load(A.meas.J_b, f0, nf, lane);
+        f_ja.load(A.meas.J_a, f0, nf, lane); f_hb.load(A.meas.H_b, f0, nf, lane); f_ha.load(A.meas.H_a, f0, nf, lane);
+        f_dt.load(A.meas.DT, f0, nf, lane);
+        if (MODEL == 2) { f_qk.load(A.qk, f0, nf, lane); f_ob.load(A.meas.O_b, f0, nf, lane); f_oa.load(A.meas.O_a, f0, nf, lane); }
+        double xi[SR], xj[SR];
+#pragma unroll
+        for (int r = 0; r < SR; r++) {
+            const int e = lane & 15;
+            xi[r] = A.states[si[r] * 16 + e];
+            xj[r] = A.states[sj[r] * 16 + e];
+        }
+        double R_[WHITEN ? (HB + 63) / 64 : 1];
+        if (whiten) {
+#pragma unroll
+            for (int r = 0; r < (HB + 63) / 64; r++) R_[r] = A.sqrt_info[f0 * 225 + min(lane + 64 * r, nf * 225 - 1)];
+        }
+        f_alpha.store(sIn, IN_D, O_ALPHA, lane); f_beta.store(sIn, IN_D, O_BETA, lane); f_q.store(sIn, IN_D, O_Q, lane);
+        f_lin.store(sIn, IN_D, O_LIN, lane); f_jq.store(sIn, IN_D, O_JQ, lane); f_jb.store(sIn, IN_D, O_JB, lane);
+        f_ja.store(sIn, IN_D, O_JA, lane); f_hb.store(sIn, IN_D, O_HB, lane); f_ha.store(sIn, IN_D, O_HA, lane);
+        f_dt.store(sIn, IN_D, O_DT, lane);
+        if (MODEL == 2) { f_qk.store(sIn, IN_D, O_QK, lane); f_ob.store(sIn, IN_D, O_OB, lane); f_oa.store(sIn, IN_D, O_OA, lane); }
+#pragma unroll
+        for (int r = 0; r < SR; r++) {
+            const int i = lane + 64 * r, g = i >> 4, e = i & 15;
+            if (i < FPW * 16) { sIn[g * IN_D + O_XI + e] = xi[r]; sIn[g * IN_D + O_XJ + e] = xj[r]; }
+        }
+        if (whiten) {
+#pragma unroll
+            for (int r = 0; r < (HB + 63) / 64; r++)
+                if (lane + 64 * r < HB) sR[lane + 64 * r] = R_[r];
+        }
+    }
+}
+// All fields of a staged record, by reference (read where they are used).
+__device__ __forceinline__ FactorMeas factor_meas_of(const double *in, const double grav[3]) {
+    using namespace fin;
+    FactorMeas m;
+    m.alpha = in + O_ALPHA; m.beta = in + O_BETA; m.q_KtoK1 = in + O_Q; m.lin = in + O_LIN; m.J_q = in + O_JQ;
+    m.J_beta = in + O_JB; m.J_alpha = in + O_JA; m.H_beta = in + O_HB; m.H_alpha = in + O_HA; m.dt = in + O_DT;
+    m.q_K_lin = in + O_QK; m.O_beta = in + O_OB; m.O_alpha = in + O_OA; m.xi = in + O_XI; m.xj = in + O_XJ;
+    m.grav = mk(grav[0], grav[1], grav[2]);
+    return m;
+}
+
+// LPF lanes per factor (16, 8 or 4), FPW = 64 / LPF factors per wavefront.  Every lane evaluates the shared
+// quaternion algebra of its factor (so it is done LPF times per factor); lane q of a factor then owns columns
+// q, q + LPF, ... of H1 / H2.  The sweep is HBM-WRITE bound (3 720 of 4 496 B per factor are the dense 15x15
+// pair), so the columns are transposed through LDS and leave the wavefront as full, consecutive 16-byte stores:
+// the FPW factors' H1 blocks are one contiguous FPW x 1 800-byte span of the output (measured on MI355X: that
+// pattern stores at 4.8 TB/s, per-column 120/240-byte pieces at 2.5 TB/s -- which rules out one lane per factor).
+// LPF = 16 has the most wavefronts (small sweeps fill the chip); LPF = 8 / 4 do 2x / 4x less redundant arithmetic.
+#ifndef CPI_FACTOR_WPS
+#define CPI_FACTOR_WPS 1
+#endif
+template <int MODEL, bool WHITEN, int LPF>
+__global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
+    constexpr int FPW = 64 / LPF;                // factors per wavefront
+    constexpr int CPL = (15 + LPF - 1) / LPF;    // columns per lane
+    constexpr int HB = FPW * 225;                // doubles of H1 (or H2) per wavefront
+    constexpr int IN_D = fin::IN_D;
+    __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
+    __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];         // the factors' input records
+    __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the factors' R
+    const int lane = threadIdx.x;
+    const int q = lane % LPF, fl = lane / LPF;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const int nf = (int)min((long long)FPW, A.F - f0);
+    constexpr bool whiten = WHITEN;
+
+    factor_fetch_inputs<MODEL, FPW, WHITEN>(A, f0, nf, lane, sIn, sR);
+    __syncthreads();
+    const double *in = sIn + fl * IN_D;
+    const FactorMeas m = factor_meas_of(in, A.grav);   // every field is read from LDS where it is used
+    double *s1 = sH, *se = sH + HB;
+    const double *Rf = sR + fl * 225;
+    const int nd = nf * 225, ne = nf * 15;
+
+    // ---- shared algebra; the residual goes to the staging area at once.  Lane q of a factor publishes rows
+    // q, q + LPF, ... of the 15-vector.
+    FactorShared S;
+    {
+        V3 e5[5];
+        factor_shared_core<MODEL>(m, S, e5);
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int c = q + LPF * k;
+            if (c < 15) {
+                const V3 ec = pick5(e5[0], e5[1], e5[2], e5[3], e5[4], c / 3);
+                se[fl * 15 + c] = sel3(ec.x, ec.y, ec.z, c % 3);
+            }
+        }
+    }
+    // ---- optional whitening (GTSAM Gaussian::WhitenSystem): y = R x with R upper triangular, column-major
+    auto whiten_col = [&](double *h) {   // in place: out[i] = sum_{k >= i} R[i][k] h[k]
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = i; k < 15; k++) acc = fma(Rf[k * 15 + i], h[k], acc);
+            h[i] = acc;                   // rows are finished top-down, so h[k], k > i, is still unwhitened
+        }
+    };
+    if (whiten) {   // R err needs the whole residual
+        wave_lds_fence();
+        double acc[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int cr = min(q + LPF * k, 14);
+            acc[k] = 0.0;
+            for (int j = 0; j < 15; j++) acc[k] = fma((j >= cr) ? Rf[j * 15 + cr] : 0.0, se[fl * 15 + j], acc[k]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int c = q + LPF * k;
+            if (c < 15) se[fl * 15 + c] = acc[k];
+        }
+    }
+
+    // ---- this lane's columns -> LDS (layout identical to the global layout of this wavefront's span) -> HBM,
+    // consecutive lanes = consecutive 16-byte pieces (gfx950 global memory takes dwordx4 at 8-byte alignment).
+    // H1 and H2 take turns in the same staging area to keep LDS per wavefront small.
+    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
+    auto flush = [&](double *dst, const double *src, int n) {
+        const int n2 = n >> 1;
+        for (int i = lane; i < n2; i += 64) { d2u v; v.a = src[2 * i]; v.b = src[2 * i + 1]; ((d2u *)dst)[i] = v; }
+        if ((n & 1) && lane == 0) dst[n - 1] = src[n - 1];
+    };
+    const Q4 qi = ldq(m.xi);
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        double *H = pass == 0 ? A.H1 : A.H2;
+        if (H) {
+            if (pass == 1 && A.H1) wave_lds_fence();   // in-order DS: the H1 flush reads complete before these writes land
+#pragma unroll
+            for (int k = 0; k < CPL; k++) {
+                // (Measured: giving lane q the ADJACENT columns CPL*q + k instead removes the 2-way LDS bank conflict of
+                // these column writes -- a 16-lane ds_write_b64 group holds two factors one 8-byte slot apart --
+                // SQ_LDS_BANK_CONFLICT -83 %, but the sweep is HBM-write bound and gets no faster: A/B on one box
+                // 0.88 / 0.89-0.92 ms vs 0.85-0.89 / 0.90-0.91 ms per 1 M factors (model 1 / 2).  Kept interleaved.)
+                const int c = q + LPF * k;
+                if (c < 15) {
+                    double h[15];
+                    S.bc = c / 3; S.cc = c - 3 * S.bc;
+                    S.u = unit(S.cc);
+                    S.rku = qrot(qi, S.u);      // column cc of quat_2_Rot(q_GtoK)
+                    if (pass == 0) factor_H1_column<MODEL>(S, m, h);
+                    else factor_H2_column(S, h);
+                    if (whiten) whiten_col(h);
+#pragma unroll
+                    for (int i = 0; i < 15; i++) s1[fl * 225 + c * 15 + i] = h[i];
+                }
+            }
+        }
+        if (pass == 0) {
+            wave_lds_fence();
+            flush(A.err + f0 * 15, se, ne);
+            if (A.H1) flush(A.H1 + f0 * 225, s1, nd);
+        } else if (H) {
+            wave_lds_fence();
+            flush(A.H2 + f0 * 225, s1, nd);
+        }
+    }
+}
+
+// Packed evaluateError: only what depends on the current states (cpi_factor_eval_packed_batch, include/cpi_amd.h).
+// Of the 450 doubles of the dense H1 / H2 pair, 54 depend on the states -- the 3x3 blocks H1(0,0), H1(6,0),
+// H1(12,0), H1(0,3), H2(0,0) and R(q_GtoK), which appears five times; the rest is 0, +-I or a copy of a measurement
+// field the caller already holds.  72 doubles per factor (15 residual + 6 blocks + 3 of padding, 576 B = 36 x 16 B)
+// instead of 465: the sweep stops being bound by the write of mostly-constant matrices.
+// LPF lanes per factor: lane q owns the columns q, q + LPF, ... < 6 of H1 (column c < 3: blocks (0,0), (6,0), (12,0), plus
+// column c of H2(0,0) and of R(q_GtoK); 3 <= c < 6: block (0,3)) and the residual rows q, q + LPF, ... < 15.
+constexpr int FACTOR_PACKED_DOUBLES = 72;
+template <int MODEL, int LPF>
+__global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, double *packed) {
+    constexpr int FPW = 64 / LPF, PD = FACTOR_PACKED_DOUBLES, IN_D = fin::IN_D;
+    __shared__ __attribute__((aligned(16))) double sP[FPW * PD];
+    __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];
+    __shared__ double sDummy[2];
+    const int lane = threadIdx.x;
+    const int q = lane % LPF, fl = min(lane / LPF, FPW - 1);   // 64 mod LPF spare lanes repeat the last factor's lane 0 (same values, same slots)
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const int nf = (int)min((long long)FPW, A.F - f0);
+    factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sIn, sDummy);
+    __syncthreads();
+    const double *in = sIn + fl * IN_D;
+    const FactorMeas m = factor_meas_of(in, A.grav);
+    double *out = sP + fl * PD;
+    FactorShared S;
+    {
+        V3 e5[5];
+        factor_shared_core<MODEL>(m, S, e5);
+#pragma unroll
+        for (int k = 0; k < (15 + LPF - 1) / LPF; k++) {
+            const int c = q + LPF * k;
+            if (c < 15) {
+                const V3 ec = pick5(e5[0], e5[1], e5[2], e5[3], e5[4], c / 3);
+                out[c] = sel3(ec.x, ec.y, ec.z, c % 3);
+            }
+        }
+    }
+    const Q4 qi = ldq(m.xi);
+#pragma unroll
+    for (int k = 0; k < (6 + LPF - 1) / LPF; k++) {
+        const int c = q + LPF * k;               // column c of H1: 0..2 -> blocks (0,0), (6,0), (12,0) (+ H2(0,0), R(q_GtoK)); 3..5 -> block (0,3)
+        if (c < 6) {
+            double h[15];
+            S.bc = c / 3; S.cc = c - 3 * S.bc;
+            S.u = unit(S.cc);
+            S.rku = qrot(qi, S.u);
+            factor_H1_column<MODEL>(S, m, h);
+            if (c < 3) {
+                double *b = out + 15 + 3 * c;                    // H1(0,0), H1(6,0), H1(12,0): column c of each
+                b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
+                b[9] = h[6]; b[10] = h[7]; b[11] = h[8];
+                b[18] = h[12]; b[19] = h[13]; b[20] = h[14];
+                double h2[15];
+                factor_H2_column(S, h2);
+                double *r = out + 51 + 3 * c;                    // R(q_GtoK) column c, then H2(0,0) column c
+                r[0] = S.rku.x; r[1] = S.rku.y; r[2] = S.rku.z;
+                r[9] = h2[0]; r[10] = h2[1]; r[11] = h2[2];
+            } else {
+                double *b = out + 42 + 3 * (c - 3);              // H1(0,3) column c - 3
+                b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
+            }
+        }
+    }
+    if (q == LPF - 1) { out[69] = 0.0; out[70] = 0.0; out[71] = 0.0; }
+    wave_lds_fence();
+    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
+    d2u *dst = reinterpret_cast<d2u *>(packed + f0 * PD);
+    for (int i = lane; i < nf * (PD / 2); i += 64) { d2u v; v.a = sP[2 * i]; v.b = sP[2 * i + 1]; dst[i] = v; }
+}
+
+// R = chol_upper(P^-1) = B^-1 with P = B B^T, B upper triangular ("reverse" Cholesky, from the last pivot up).
+// 16 lanes (one DPP row) per factor, 4 factors per wavefront; lane j keeps the FULL symmetric column j of the
+// working matrix in registers, so its own B[j][k] is a static register (a[k]) and the only cross-lane traffic is
+// "every lane reads column k of lane k": DPP row_share broadcasts, no LDS in the factorisation.  The inverse of
+// the triangular factor is fused into the same sweep: back substitution for column j of U = B^-1,
+//   U[j][j] = 1/B[j][j],   U[k][j] = -(sum_{m=k+1..j} B[k][m] U[m][j]) / B[k][k]   (k < j),   0 below the diagonal,
+// consumes the columns of B in the order the factorisation produces them (k = 14 .. 0), so every lane folds the
+// broadcast column k into its running sums acc[i] = sum_m B[i][m] U[m][j] right away and B is never stored.
+// Input and output pass through LDS so that HBM sees full consecutive 16-byte pieces (see cpi_factor_kernel).
+template <int K>
+__device__ __forceinline__ double row_share(double v) {   // all 16 lanes of a DPP row read lane K of that row
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int nlo = __builtin_amdgcn_mov_dpp(lo, 0x150 + K, 0xf, 0xf, false);
+    const int nhi = __builtin_amdgcn_mov_dpp(hi, 0x150 + K, 0xf, 0xf, false);
+    return __hiloint2double(nhi, nlo);
+}
+template <int K>
+__device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], double (&acc)[15], int j) {
+    if constexpr (K >= 0) {
+        // pivot: b_kk = sqrt(A[k][k]); a non-positive (or NaN) pivot poisons the factor with NaNs
+        const double akk = row_share<K>(a[K]);
+        double bkk, inv;
+        mag_and_inverse(akk, bkk, inv);
+        if (!(akk > 0.0)) inv = __builtin_nan("");
+        // row k of column j of U
+        u[K] = (K == j) ? inv : ((K < j) ? -acc[K] * inv : 0.0);
+        // lanes j < k: trailing update of column j (all rows < k) with B[j][k] = A[k][j] / b_kk (symmetry: a
+        // static register of lane j); finished lanes multiply by zero
+        const double bjk = (j < K) ? a[K] * inv : 0.0;
+        const double uk = u[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const double c = row_share<K>(a[i]) * inv;     // B[i][k], i < k
+            a[i] = fma(-c, bjk, a[i]);
+            acc[i] = fma(c, uk, acc[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the steps in order: hoisted broadcasts would cost ~200 registers
+        chol_inv_step<K - 1>(a, u, acc, j);
+    }
+}
+__global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const double *P, double *Rout) {
+    constexpr int FPW = 4;
+    __shared__ __attribute__((aligned(16))) double sA[FPW * 225];
+    const int lane = threadIdx.x, j = lane & 15, fl = lane >> 4;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const int nf = (int)min((long long)FPW, F - f0);
+    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
+    {
+        const int n2 = (nf * 225) >> 1;
+        const d2u *src = reinterpret_cast<const d2u *>(P + f0 * 225);
+        for (int i = lane; i < n2; i += 64) { const d2u v = src[i]; sA[2 * i] = v.a; sA[2 * i + 1] = v.b; }
+        if (((nf * 225) & 1) && lane == 0) sA[nf * 225 - 1] = P[f0 * 225 + nf * 225 - 1];
+    }
+    wave_lds_fence();
+    const int fc = min(fl, nf - 1), jc = min(j, 14);   // idle lanes (j == 15, missing factors) redo a valid column
+    double a[15], u[15], acc[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) { a[i] = sA[fc * 225 + jc * 15 + i]; acc[i] = 0.0; }
+    chol_inv_step<14>(a, u, acc, j);
+    wave_lds_fence();   // the column reads above are complete (in-order DS) before the staging area is reused
+    if (j < 15 && fl < nf) {
+#pragma unroll
+        for (int i = 0; i < 15; i++) sA[fl * 225 + j * 15 + i] = u[i];
+    }
+    wave_lds_fence();
+    {
+        const int n2 = (nf * 225) >> 1;
+        d2u *dst = reinterpret_cast<d2u *>(Rout + f0 * 225);
+        for (int i = lane; i < n2; i += 64) { d2u v; v.a = sA[2 * i]; v.b = sA[2 * i + 1]; dst[i] = v; }
+        if (((nf * 225) & 1) && lane == 0) Rout[f0 * 225 + nf * 225 - 1] = sA[nf * 225 - 1];
+    }
+}
+
+// Hessian contribution of a factor: what GTSAM's linear solver consumes after
+// NoiseModelFactor::linearize (ImuFactorCPIv1.h:82 -> Gaussian::WhitenSystem -> JacobianFactor [A1 A2 | b] with
+// A1 = R H1, A2 = R H2, b = -R e) when it builds a HessianFactor: the augmented information matrix
+//     [A1 A2 b]^T [A1 A2 b]  =  [ G  g ]      G = A^T A (30x30),  g = A^T b,  f = b^T b
+//                               [ g^T f ]
+// 31x31 symmetric, written as its packed upper triangle (column-major packed, LAPACK 'U': entry (i, d), i <= d, at
+// i + d (d + 1) / 2), 496 doubles per factor.  Fused into the whitened sweep: the 31 whitened columns never leave the
+// chip.  16 lanes per factor: lane q < 15 produces columns q of A1 and of A2 (as cpi_factor_kernel), lane 15 the b column;
+// lane q then owns columns q and 30 - q of the result (lane 15: column 15): every lane forms 32 dot products' worth of
+// useful output from two columns held in registers against the 31 columns broadcast from LDS.
+constexpr int HESS_PACKED = 496;
+template <int MODEL>
+__global__ __launch_bounds__(64, 1) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
+    constexpr int LPF = 16, FPW = 4, IN_D = fin::IN_D, CP = 16;   // CP: LDS pitch of a whitened column (15 used, 16-B aligned)
+    // the packed output stage re-uses the input records and the R matrices: both are dead once the whitened columns sit
+    // in sA (one wavefront per workgroup: program order + the LDS fence below order the re-use) -- 32 KB instead of 43
+    constexpr int IO_D = (FPW * IN_D + FPW * 225 > FPW * HESS_PACKED) ? FPW * IN_D + FPW * 225 : FPW * HESS_PACKED;
+    __shared__ __attribute__((aligned(16))) double sIO[IO_D];
+    __shared__ __attribute__((aligned(16))) double sA[FPW * 31 * CP];   // [factor][column][row]
+    double *sIn = sIO, *sR = sIO + FPW * IN_D, *sP = sIO;
+    const int lane = threadIdx.x;
+    const int q = lane % LPF, fl = lane / LPF;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const int nf = (int)min((long long)FPW, A.F - f0);
+    factor_fetch_inputs<MODEL, FPW, true>(A, f0, nf, lane, sIn, sR);
+    __syncthreads();
+    const double *in = sIn + fl * IN_D;
+    const FactorMeas m = factor_meas_of(in, A.grav);
+    const double *Rf = sR + fl * 225;
+    double *Af = sA + fl * 31 * CP;
+    auto whiten_col = [&](double *h) {   // in place: out[i] = sum_{k >= i} R[i][k] h[k]  (R upper triangular, column-major)
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = i; k < 15; k++) acc = fma(Rf[k * 15 + i], h[k], acc);
+            h[i] = acc;
+        }
+    };
+    FactorShared S;
+    {
+        V3 e5[5];
+        factor_shared_core<MODEL>(m, S, e5);
+        if (q == 15) {   // b = -R e
+            double h[15];
+#pragma unroll
+            for (int b = 0; b < 5; b++) { h[3 * b] = -e5[b].x; h[3 * b + 1] = -e5[b].y; h[3 * b + 2] = -e5[b].z; }
+            whiten_col(h);
+#pragma unroll
+            for (int i = 0; i < 15; i++) Af[30 * CP + i] = h[i];
+        }
+    }
+    if (q < 15) {
+        const Q4 qi = ldq(m.xi);
+        double h[15];
+        S.bc = q / 3; S.cc = q - 3 * S.bc;
+        S.u = unit(S.cc);
+        S.rku = qrot(qi, S.u);
+        factor_H1_column<MODEL>(S, m, h);
+        whiten_col(h);
+#pragma unroll
+        for (int i = 0; i < 15; i++) Af[q * CP + i] = h[i];
+        factor_H2_column(S, h);
+        whiten_col(h);
+#pragma unroll
+        for (int i = 0; i < 15; i++) Af[(15 + q) * CP + i] = h[i];
+    }
+    wave_lds_fence();
+    // ---- lane q: columns d1 = q and d2 = 30 - q (lane 15: d1 = d2 = 15) against every column c, broadcast from LDS
+    const int d1 = q, d2 = 30 - q;
+    double c1[15], c2[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) { c1[i] = Af[d1 * CP + i]; c2[i] = Af[d2 * CP + i]; }
+    double *Pf = sP + fl * HESS_PACKED;
+    const int o1 = d1 * (d1 + 1) / 2, o2 = d2 * (d2 + 1) / 2;
+#pragma unroll
+    for (int c = 0; c < 31; c++) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 15; i++) {
+            const double x = Af[c * CP + i];   // same address for the 16 lanes of a factor: LDS broadcast
+            if (c <= 15) a1 = fma(x, c1[i], a1);   // column d1 <= 15 ends at its diagonal: rows 16..30 belong to other lanes
+            a2 = fma(x, c2[i], a2);
+        }
+        // results go to the packed output stage at once (62 accumulators would not fit the register file)
+        if (c <= d1) Pf[o1 + c] = a1;
+        if (c <= d2 && q != 15) Pf[o2 + c] = a2;
+    }
+    wave_lds_fence();
+    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
+    d2u *dst = reinterpret_cast<d2u *>(hess + f0 * HESS_PACKED);
+    for (int i = lane; i < nf * (HESS_PACKED / 2); i += 64) { d2u v; v.a = sP[2 * i]; v.b = sP[2 * i + 1]; dst[i] = v; }
+}
+
+struct PredictArgs {
+    long long F;
+    double grav[3];
+    cpi_outputs meas;
+    const double *states_i;
+    long long S;
+    const int *idx_i;
+    double *states_j;
+};
+template <int MODEL>
+__global__ __launch_bounds__(256) void cpi_predict_kernel(PredictArgs A) {
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= A.F) return;
+    const long long ii = min(max(A.idx_i ? (long long)A.idx_i[f] : f, 0ll), A.S - 1);
+    const NavState xi = ld_state(A.states_i + ii * 16);
+    const NavState o = predict_state<MODEL>(xi, ldv3(A.meas.alpha + f * 3), ldv3(A.meas.beta + f * 3),
+                                            ldq4(A.meas.q + f * 4), A.meas.DT[f], mk(A.grav[0], A.grav[1], A.grav[2]));
+    double *d = A.states_j + f * 16;
+    d[0] = o.q.x; d[1] = o.q.y; d[2] = o.q.z; d[3] = o.q.w;
+    stv3(d + 4, o.bg); stv3(d + 7, o.v); stv3(d + 10, o.ba); stv3(d + 13, o.p);
+}
+
+
+}  // namespace

@@ -1,0 +1,418 @@
+// cpi_mean_kernels.hpp -- the mean (+ analytic Jacobian) recursion: cpi_mean_kernel (dense / ragged layouts) and cpi_mean_tiled_kernel (tiled layout).
+// Part of the single translation unit cpi_kernels.hip (included there, in this order; not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ============================================================================================
+// mean (+ analytic Jacobian) kernel
+// ============================================================================================
+#ifndef CPI_MEAN_WPS
+#define CPI_MEAN_WPS 1
+#endif
+template <int MODEL, bool JAC, bool AVG, int L>
+__global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) && L == 1 ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
+    constexpr int WPB = 64 / L;       // windows per wavefront
+    // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has several intervals (L <= 8; 20 k x 50 with
+    // L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us, 15 k with L = 4: 16.0 -> 15.3 us, 10 k with L = 6:
+    // 12.5 -> 11.8 us once the padded second step of an odd last chunk is skipped), 1 when a wave is latency-bound
+    // with few intervals per lane (L >= 12: 5 k windows 9.55 vs 9.65 us, 2.5 k 7.7 vs 8.0 us); 3 / 4 knots per chunk cost the second
+    // wavefront per SIMD
+    constexpr int C = (L <= 8 && !JAC) ? 2 : 1;
+    constexpr int SEGD = 7 * C;       // doubles per lane per chunk
+    constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
+    __shared__ double tile[64 * PITCH];
+    __shared__ unsigned long long segdesc[64];  // per lane-segment: (first double of the segment << 16) | intervals
+
+    const int lane = threadIdx.x;
+    const int grp = lane / L, l = lane - grp * L;
+    long long w = (long long)blockIdx.x * WPB + grp;
+    const bool valid = (w < A.W) && (grp < WPB);   // L not a power of two leaves 64 - WPB*L idle lanes
+    if (grp >= WPB) w = (long long)blockIdx.x * WPB;   // idle lanes shadow the block's first window (stays near the block)
+    if (w >= A.W) w = A.W - 1;
+    const int n = A.count ? min(max(A.count[w], 0), A.N) : A.N;   // a count outside [0, N] must not corrupt the packed descriptors
+    const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
+    const int per = (n + L - 1) / L;
+    const int s0 = min(n, l * per), s1 = min(n, s0 + per);
+    const int len = s1 - s0;
+    const int maxlen = __builtin_amdgcn_readfirstlane(wave_max(len));   // wave-uniform: loop control stays scalar
+
+    // (Deriving the descriptors of a dense layout arithmetically instead of through LDS was measured: +0.35 us per
+    // 13 us launch -- the 64-bit integer arithmetic costs more than the shuffle reduction and the LDS round trip.)
+    segdesc[lane] = ((unsigned long long)((k0 + s0) * 7) << 16) | (unsigned long long)(unsigned)len;
+
+    const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
+    V3 gk = mk(0, 0, 0);
+    if (MODEL == 2) gk = mul(quat_2_Rot(ldq4(A.qk + w * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
+
+    double pk[7];
+    {
+        const double *kb = A.knots + (k0 + s0) * 7;
+#pragma unroll
+        for (int i = 0; i < 7; i++) pk[i] = kb[i];  // knot s0 always exists (a window owns count+1 knots)
+    }
+    MeanState<JAC> st;
+    mean_init(st);
+    // model 2, mean-only, several lanes per window: a lane integrates its segment from the raw specific force and
+    // accumulates the segment's gravity response (cpi_math.hpp: mean_step_v2seg); gravity is applied after the tree
+    constexpr bool GSEG = (MODEL == 2) && !JAC && (L > 1);
+    GravAcc ga;
+    if (GSEG) grav_init(ga);
+    __syncthreads();
+
+    // Analytic-Jacobian variant of model 1, one lane per window (large batches): the recursion is bound by registers
+    // (61 doubles of state + the per-interval 3x3 temporaries), not by HBM, so it streams its knots straight into
+    // registers, one interval ahead, instead of through the coalescing LDS stage -- that frees the stage's address /
+    // staging registers and lets two wavefronts share a SIMD (256 registers + 36 B of scratch each).  Measured inside
+    // "V1 full" (covariance kernel + this one): 1.405 -> 1.376 ms per 100 k windows, 13.25 -> 13.10 ms per 1 M.  With
+    // several lanes per window (small, latency-bound batches) it loses (10 k windows: 192 -> 205 us), so those keep the stage.
+    constexpr bool DIRECT = JAC && (MODEL == 1) && (L == 1);
+    if constexpr (DIRECT) {
+        const double *kp = A.knots + (k0 + s0) * 7;
+        double nx[7];
+        {
+            const double *kb = kp + 7 * min(1, len);
+#pragma unroll
+            for (int i = 0; i < 7; i++) nx[i] = kb[i];
+        }
+        for (int sidx = 0; sidx < maxlen; ++sidx) {
+            double q[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) q[i] = nx[i];
+            {
+                const double *kb = kp + 7 * min(sidx + 2, len);   // knot s0 + len is the window segment's last: always valid
+#pragma unroll
+                for (int i = 0; i < 7; i++) nx[i] = kb[i];
+            }
+            mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                       mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, sidx < len);
+#pragma unroll
+            for (int i = 0; i < 7; i++) pk[i] = q[i];
+        }
+    } else {
+    // Tile element idx = e*64 + lane belongs to segment idx / SEGD at offset idx % SEGD, so consecutive
+    // lanes read consecutive doubles of (mostly) one segment: coalesced.  Everything that does not depend
+    // on the chunk index is hoisted: per staged element a lane keeps one pointer and the last chunk for
+    // which its knot exists (later chunks re-read that knot; the value is never consumed), so the hot loop
+    // spends ~3 VALU per element on addressing and no load is ever out of bounds.
+    double stage[SEGD];
+    const double *sptr[SEGD];
+    unsigned voff[SEGD];   // byte offset of the element from the block's first knot (dense layouts)
+    int smax[SEGD];
+    int tofs[SEGD];
+    const double *blk0 = A.knots + (long long)blockIdx.x * WPB * (long long)(A.N + 1) * 7;   // wave-uniform
+    {
+        // (Issuing all SEGD descriptor reads before using the first -- one LDS round trip instead of SEGD dependent ones,
+        // which hipcc keeps in program order with an s_waitcnt after each -- was measured: 12.55 vs 12.33 us per launch
+        // at 10 k windows, i.e. slower; the wavefronts wait for the first HBM burst either way and start less staggered.)
+        int seg = lane / SEGD, off = lane - seg * SEGD;
+#pragma unroll
+        for (int e = 0; e < SEGD; ++e) {
+            const unsigned long long d = segdesc[seg];
+            const long long base = (long long)(d >> 16);
+            const int slen = (int)(d & 0xffffULL);
+            const int kn = off / 7;                       // knot (1 + kn) of chunk 0
+            const bool ok = slen >= 1 + kn;
+            sptr[e] = A.knots + base + (ok ? 7 + off : off - 7 * kn);
+            voff[e] = (unsigned)((sptr[e] - blk0) * 8);   // only used when safe_overread (then 0 <= offset < 2^32)
+            smax[e] = ok ? (slen - 1 - kn) / C : 0;       // never-valid elements keep re-reading knot 0
+            tofs[e] = seg * PITCH + off;
+            off += 64 % SEGD; seg += 64 / SEGD;   // idx advances by 64 per staged element
+            if (off >= SEGD) { off -= SEGD; seg += 1; }
+        }
+    }
+    // Dense layout, not one of the last waves: reading a few knots past a short segment's end stays inside
+    // the knot array, so every chunk is "block base + chunk stride (scalar) + constant lane offset".
+    // (Not with per-window counts: the knots behind a short window's last interval belong to the caller's dense array and
+    // may never have been written -- a NaN there would reach the state through 0 * NaN on the inactive steps.  The
+    // per-element path below stops at the segment's end and re-reads its last, valid knot instead.)
+    const bool safe_overread = (A.first == nullptr) && (A.count == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W);
+    auto issue = [&](int it) {
+        if (safe_overread) {
+            // scalar base (advanced by SALU) + constant 32-bit lane offsets: no vector arithmetic per element
+            const char *cb = reinterpret_cast<const char *>(blk0) + (long long)it * (SEGD * 8);
+#pragma unroll
+            for (int e = 0; e < SEGD; ++e) {
+                asm volatile("" : "+v"(voff[e]));   // keeps the zero-extension next to the load: `global_load v, v_off32, s[base]`
+                stage[e] = *reinterpret_cast<const double *>(cb + voff[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += (it < smax[e]) ? SEGD : 0; }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int e = 0; e < SEGD; ++e) tile[tofs[e]] = stage[e];
+    };
+
+    // One chunk ahead: the HBM round trip of chunk it+1 overlaps the FP64 work of chunk it.  Measured alternatives:
+    // a TRUE two-chunk pipeline (two register stages, every path issuing the same loads so that hipcc emits the partial
+    // wait s_waitcnt vmcnt(14) -- one conditional issue in the loop and it drains the queue with vmcnt(0)) is 8 % slower
+    // at 10 k windows x 50 (13.5 vs 12.5 us: the first chunk's data queues behind the second's) and 5 % slower at 1 M;
+    // a double-buffered LDS tile with the next chunk read back into registers during the integration: +2 %.
+    // Per-wavefront time stamps explain why: with 1000 wavefronts in flight a chunk is 3.6 MB and takes 0.89 us
+    // (0.74 us with 625 wavefronts, 1.2 us with 2000) -- the loop streams at ~4 TB/s and is paced by the memory
+    // system, not by the latency of one wavefront's accesses.
+    const int nchunks = (maxlen + C - 1) / C;
+    if (nchunks > 0) issue(0);
+    for (int it = 0; it < nchunks; ++it) {
+        commit();
+        __syncthreads();
+        if (it + 1 < nchunks) issue(it + 1);
+#pragma unroll   // C <= 2: the two steps of a chunk share one basic block (no knot copy between them)
+        for (int c = 0; c < C; ++c) {
+            const int s = it * C + c;
+            if (C > 1 && s >= maxlen) break;   // wave-uniform: no lane has this interval (odd longest segment)
+            const double *nk = &tile[lane * PITCH + c * 7];
+            double q[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) q[i] = nk[i];
+            if constexpr (GSEG)
+                mean_step_v2seg<AVG>(st, ga, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                     mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, s < len);
+            else
+                mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                           mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, s < len);
+#pragma unroll
+            for (int i = 0; i < 7; i++) pk[i] = q[i];
+        }
+        __syncthreads();
+    }
+
+    }   // !DIRECT
+
+    // order-preserving composition tree over the L lanes of a window (earlier = lower lane)
+#pragma unroll
+    for (int stp = 1; stp < L; stp <<= 1) {
+        MeanState<JAC> B = shfl_down(st, stp);
+        GravAcc gB;
+        if constexpr (GSEG) gB = shfl_down(ga, stp);
+        if ((L & (L - 1)) != 0) {
+            // L not a power of two: lane l + stp may belong to the next window -- compose with the identity instead
+            if (l + stp >= L) { mean_init(B); if (GSEG) grav_init(gB); }
+        }
+        if constexpr (GSEG) grav_combine(ga, st, gB, B);   // needs st.R / B.DT before they are composed
+        mean_combine(st, B);
+    }
+    if constexpr (GSEG) grav_apply(st, ga, gk);
+
+    if (valid && l == 0) {
+        if (A.write_means) {
+            if (A.out.DT) A.out.DT[w] = st.DT;
+            if (A.out.alpha) stv3(A.out.alpha + w * 3, st.alpha);
+            if (A.out.beta) stv3(A.out.beta + w * 3, st.beta);
+            if (A.out.q) {
+                const Q4 q = rot_2_quat(st.R);
+                double *p = A.out.q + w * 4;
+                p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+            }
+        }
+        if (JAC && A.write_jac) {
+            if (A.out.J_q) stm3_cm(A.out.J_q + w * 9, st.Jq);
+            if (A.out.J_a) stm3_cm(A.out.J_a + w * 9, st.Ja);
+            if (A.out.J_b) stm3_cm(A.out.J_b + w * 9, st.Jb);
+            if (A.out.H_a) stm3_cm(A.out.H_a + w * 9, st.Ha);
+            if (A.out.H_b) stm3_cm(A.out.H_b + w * 9, st.Hb);
+            if (MODEL == 2) {
+                if (A.out.O_a) stm3_cm(A.out.O_a + w * 9, st.Oa);
+                if (A.out.O_b) stm3_cm(A.out.O_b + w * 9, st.Ob);
+            }
+        }
+    }
+}
+
+// ============================================================================================
+// mean kernel on the TILED layout: knots of 64 windows interleaved per step (cpi_preintegrate_tiled_batch)
+// ============================================================================================
+// tiles[b][s][k][i] = field k (t, w, a) of knot s of window 64 b + i.  A wavefront owns tile b, lane i window 64 b + i, and
+// step s reads seven fully coalesced 512-byte rows: the whole batch is ONE linear stream per wavefront, every byte
+// fetched once, no LDS, no staging, ~100 registers (4 wavefronts per SIMD) -- the layout the recursion wants on this
+// memory system, for producers that can write it (a batch assembler that places knot s of window w at its tile slot instead of
+// at w (N+1) + s costs nothing extra).  Knots are prefetched three steps ahead in registers.
+struct TiledArgs {
+    long long W;
+    int N;
+    const double *tiles;
+    const int *count;
+    const double *lin;
+    const double *qk;
+    double grav[3];
+    cpi_outputs out;
+    int dbg;   // measurement only (CPI_AMD_BLK_MODE): 1 = fetch without arithmetic
+    long long ts, ss;   // doubles between consecutive tiles / consecutive steps of a tile
+};
+#ifndef CPI_TILED_OCC
+#define CPI_TILED_OCC (MODEL == 2 ? 2 : 3)
+#endif
+#ifndef CPI_TILED_BUFS
+#define CPI_TILED_BUFS 5
+#endif
+// SPLIT (small batches: fewer tiles than the chip has SIMDs): a workgroup of S = blockDim.x / 64 wavefronts owns the
+// tile; wavefront j integrates the steps [j per, (j + 1) per) of all 64 windows from the identity (model 2: from the raw
+// specific force, with the segment's gravity response -- cpi_math.hpp mean_step_v2seg), parks its segment in LDS, and
+// wavefront 0 composes the S segments in order (mean_combine / grav_combine: the composition cpi_mean_kernel uses
+// across the lanes of a window).  Each wavefront still reads one linear stream.
+template <int MODEL, bool AVG, bool COUNTED, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 512 : 64, SPLIT ? 1 : CPI_TILED_OCC) void cpi_mean_tiled_kernel(TiledArgs A) {
+    constexpr bool GSEG = SPLIT && MODEL == 2;
+    constexpr int NF = GSEG ? 34 : 16;            // doubles of a parked segment
+    extern __shared__ double seg[];               // [S - 1][NF][64]
+    const int lane = threadIdx.x & 63;
+    const int j = SPLIT ? (int)(threadIdx.x >> 6) : 0, S = SPLIT ? (int)(blockDim.x >> 6) : 1;
+    const long long w = (long long)blockIdx.x * 64 + lane;
+    const bool valid = w < A.W;
+    const long long wc = valid ? w : A.W - 1;
+    const int n = valid ? (COUNTED ? min(max(A.count[wc], 0), A.N) : A.N) : 0;
+    const int nmax = COUNTED ? __builtin_amdgcn_readfirstlane(wave_max(n)) : A.N;
+    const int per = SPLIT ? (A.N + S - 1) / S : A.N;
+    const int sb = __builtin_amdgcn_readfirstlane(j * per), se = min(sb + per, nmax);   // this wavefront's steps
+    const double *tb = A.tiles + (long long)blockIdx.x * A.ts + lane;   // a step of a tile: 448 doubles = 7 fields x 64 windows
+    const V3 bw = ldv3(A.lin + wc * 6), ba = ldv3(A.lin + wc * 6 + 3);
+    V3 gk = mk(0, 0, 0);
+    if (MODEL == 2 && j == 0) gk = mul(quat_2_Rot(ldq4(A.qk + wc * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
+    auto load = [&](double (&k)[7], int s) {
+        // COUNTED: past its own last knot a lane re-reads that knot (dt = 0) -- what lies behind it in the column is
+        // never read.  Otherwise the row offset is wave-uniform (scalar address arithmetic).
+        const double *p = tb + (long long)(COUNTED ? min(s, n) : min(s, A.N)) * A.ss;
+#pragma unroll
+        for (int f = 0; f < 7; f++) k[f] = p[f * 64];
+    };
+    MeanState<false> st;
+    mean_init(st);
+    GravAcc ga;
+    if (GSEG) grav_init(ga);
+    // the knot buffers rotate by NAME over one unrolled trip (a rolled loop spends 28 v_mov_b64 per step on it)
+#define CPI_TSTEP(a, b, e, S_)                                                                                        \
+    load(e, (S_) + CPI_TILED_BUFS - 1);                                                                               \
+    if constexpr (GSEG)                                                                                               \
+        mean_step_v2seg<AVG>(st, ga, a[0], b[0], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]), mk(b[1], b[2], b[3]),    \
+                             mk(b[4], b[5], b[6]), bw, ba, (S_) < n);                                                 \
+    else                                                                                                              \
+        mean_step<MODEL, false, AVG>(st, a[0], b[0], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]), mk(b[1], b[2], b[3]), \
+                                     mk(b[4], b[5], b[6]), bw, ba, gk, (S_) < n)
+#if CPI_TILED_BUFS == 5
+    double k0[7], k1[7], k2[7], k3[7], k4[7];
+    load(k0, sb); load(k1, sb + 1); load(k2, sb + 2); load(k3, sb + 3);
+    for (int s = sb; s < se; s += 5) {
+        CPI_TSTEP(k0, k1, k4, s);
+        if (s + 1 >= se) break;
+        CPI_TSTEP(k1, k2, k0, s + 1);
+        if (s + 2 >= se) break;
+        CPI_TSTEP(k2, k3, k1, s + 2);
+        if (s + 3 >= se) break;
+        CPI_TSTEP(k3, k4, k2, s + 3);
+        if (s + 4 >= se) break;
+        CPI_TSTEP(k4, k0, k3, s + 4);
+    }
+#elif CPI_TILED_BUFS == 4
+    double k0[7], k1[7], k2[7], k3[7];
+    load(k0, sb); load(k1, sb + 1); load(k2, sb + 2);
+    for (int s = sb; s < se; s += 4) {
+        CPI_TSTEP(k0, k1, k3, s);
+        if (s + 1 >= se) break;
+        CPI_TSTEP(k1, k2, k0, s + 1);
+        if (s + 2 >= se) break;
+        CPI_TSTEP(k2, k3, k1, s + 2);
+        if (s + 3 >= se) break;
+        CPI_TSTEP(k3, k0, k2, s + 3);
+    }
+#else
+    double k0[7], k1[7], k2[7];
+    load(k0, sb); load(k1, sb + 1);
+    for (int s = sb; s < se; s += 3) {
+        CPI_TSTEP(k0, k1, k2, s);
+        if (s + 1 >= se) break;
+        CPI_TSTEP(k1, k2, k0, s + 1);
+        if (s + 2 >= se) break;
+        CPI_TSTEP(k2, k0, k1, s + 2);
+    }
+#endif
+#undef CPI_TSTEP
+    if constexpr (SPLIT) {
+        auto park = [&](int f, double v) { seg[((j - 1) * NF + f) * 64 + lane] = v; };
+        if (j > 0) {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) park(r * 3 + c, st.R.m[r][c]);
+            park(9, st.alpha.x); park(10, st.alpha.y); park(11, st.alpha.z);
+            park(12, st.beta.x); park(13, st.beta.y); park(14, st.beta.z); park(15, st.DT);
+            if constexpr (GSEG) {
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { park(16 + r * 3 + c, ga.Gam.m[r][c]); park(25 + r * 3 + c, ga.Lam.m[r][c]); }
+            }
+        }
+        __syncthreads();
+        if (j > 0) return;
+        for (int jj = 1; jj < S; ++jj) {        // earlier o later, in order
+            const double *sp = seg + (jj - 1) * NF * 64 + lane;
+            MeanState<false> B;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) B.R.m[r][c] = sp[(r * 3 + c) * 64];
+            B.alpha = mk(sp[9 * 64], sp[10 * 64], sp[11 * 64]);
+            B.beta = mk(sp[12 * 64], sp[13 * 64], sp[14 * 64]);
+            B.DT = sp[15 * 64];
+            if constexpr (GSEG) {
+                GravAcc gB;
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { gB.Gam.m[r][c] = sp[(16 + r * 3 + c) * 64]; gB.Lam.m[r][c] = sp[(25 + r * 3 + c) * 64]; }
+                grav_combine(ga, st, gB, B);    // before mean_combine: needs st.R and B.DT as they are
+            }
+            mean_combine(st, B);
+        }
+        if constexpr (GSEG) grav_apply(st, ga, gk);
+    }
+    if (!valid) return;
+    if (A.out.DT) A.out.DT[w] = st.DT;
+    if (A.out.alpha) stv3(A.out.alpha + w * 3, st.alpha);
+    if (A.out.beta) stv3(A.out.beta + w * 3, st.beta);
+    if (A.out.q) {
+        const Q4 q = rot_2_quat(st.R);
+        double *p = A.out.q + w * 4;
+        p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+    }
+}
+// measurement only (CPI_AMD_BLK_MODE=1): the tiled stream alone -- the same loads, one add per value
+__global__ __launch_bounds__(64, 3) void cpi_tiled_fetch_probe_kernel(TiledArgs A) {
+    const int lane = threadIdx.x;
+    const long long w = (long long)blockIdx.x * 64 + lane;
+    const double *tb = A.tiles + (long long)blockIdx.x * A.ts + lane;
+    auto load = [&](double (&k)[7], int s) {
+        const double *p = tb + (long long)min(s, A.N) * A.ss;
+#pragma unroll
+        for (int f = 0; f < 7; f++) k[f] = p[f * 64];
+    };
+    double k0[7], k1[7], k2[7], k3[7], acc = 0;
+    load(k0, 0); load(k1, 1); load(k2, 2); load(k3, 3);
+    for (int s = 0; s < A.N; ++s) {
+        double k4[7];
+        load(k4, s + 4);
+#pragma unroll
+        for (int f = 0; f < 7; f++) { acc += k0[f]; k0[f] = k1[f]; k1[f] = k2[f]; k2[f] = k3[f]; k3[f] = k4[f]; }
+    }
+    if (w < A.W && A.out.DT) A.out.DT[w] = acc;
+}
+// dense knots[W][N+1][7] -> tiles[ceil(W/64)][N+1][7][64] (windows past W replicate window W - 1: finite padding)
+__global__ __launch_bounds__(256) void cpi_tile_knots_kernel(long long W, int N, const double *knots, double *tiles, long long ts, long long ss) {
+    const long long total = ((W + 63) / 64) * (long long)(N + 1) * 448;
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
+        const int i = (int)(o & 63);
+        const long long r = o >> 6;
+        const int f = (int)(r % 7);
+        const long long bs = r / 7;
+        const int sidx = (int)(bs % (N + 1));
+        const long long b = bs / (N + 1);
+        const long long w = min(b * 64 + i, W - 1);
+        tiles[b * ts + sidx * ss + f * 64 + i] = knots[(w * (N + 1) + sidx) * 7 + f];
+    }
+}
+
+
+}  // namespace
