@@ -60,3 +60,24 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".sh", ".hip", ".hpp", ".h", ".cpp")):
                     txt = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "oracle_py" not in txt and "liboracle" not in txt and "cpi_oracle" not in txt, f
+
+
+def test_build_id_covers_every_source_of_the_translation_unit():
+    """cpi_build_id() ties measurement records to the library: every file the translation unit includes from the repository
+    must be in the hash (cpi_amd/build.py DEPS + the test header), or an edit could leave stale counters looking valid."""
+    import os
+    import re
+    from cpi_amd import build
+    root = os.path.dirname(build.SRC)
+    hashed = {os.path.realpath(p) for p in build.DEPS} | {os.path.realpath(os.path.join(os.path.dirname(build.HERE), "include", "cpi_amd_test.h"))}
+    seen, todo = set(), [build.SRC]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(f).read(), flags=re.M):
+            path = os.path.realpath(os.path.join(os.path.dirname(f), inc))
+            assert os.path.exists(path), (f, inc)
+            todo.append(path)
+    assert {os.path.realpath(p) for p in seen} <= hashed, sorted({os.path.realpath(p) for p in seen} - hashed)
