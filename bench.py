@@ -50,8 +50,8 @@ WORKLOADS = {
     "factor_v1_packed": dict(model=1, factor=True, packed=True, W=1000000, N=50, bytes=776 + 576, kernel="cpi_factor_packed_kernel<1,L>"),
     "factor_v2_packed": dict(model=2, factor=True, packed=True, W=1000000, N=50, bytes=952 + 576, kernel="cpi_factor_packed_kernel<2,L>"),
     # the same mean-only recursion on the TILED input layout (knots of 64 windows interleaved per step; include/cpi_amd.h)
-    "v1_mean_tiled": dict(model=1, want=("mean",), W=1000000, N=50, bytes=2856 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<1,false,false>"),
-    "v2_mean_tiled": dict(model=2, want=("mean",), W=1000000, N=50, bytes=2888 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<2,false,false>"),
+    "v1_mean_tiled": dict(model=1, want=("mean",), W=1000000, N=50, bytes=2856 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<1,false,false,SPLIT>"),
+    "v2_mean_tiled": dict(model=2, want=("mean",), W=1000000, N=50, bytes=2888 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<2,false,false,SPLIT>"),
     # BASELINE configs[4]: one GPU's share of 8 M windows x 100 samples (EuRoC-rate synthetic IMU), generated on the device
     "cfg5_mean": dict(model=1, want=("mean",), W=1000000, N=100, bytes=2856 + 88, kernel="cpi_mean_kernel<1,false,false,1>"),
     "cfg5_full": dict(model=1, want=("mean", "jac", "cov"), W=1000000, N=100, bytes=2856 + 2320, kernel="cpi_cov_kernel<1,false>"),
