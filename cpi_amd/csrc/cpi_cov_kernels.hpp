@@ -157,6 +157,12 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                 if (stg == 0) { if (sl == 0) Rs = rec_mat(gs, GS_R0); }
                 else if (stg != 2) Rs = cov_stage_rotation<MODEL>(ir, stg);
                 cov_stage_M(Ln, stg, Rs, M);
+                // From here to the end of the stage the wavefront sits on the latency chain "exchange write -> transposed
+                // read -> accumulate": it issues ahead of its SIMD neighbour, which is in the F x phase of another stage
+                // and has independent arithmetic to fill the gaps with.  Measured (same box, alternating runs, 100 k x 50):
+                // V1 full 1.357 -> 1.321 ms (-2.7 %), V2 full 2.719 -> 2.701 ms (-0.7 %); the opposite assignment (priority
+                // during F x) loses 1.5 / 3 %, a constant priority changes nothing.
+                __builtin_amdgcn_s_setprio(3);
                 if (jj < D::NPCOL) {
 #pragma unroll
                     for (int rr = 0; rr < CovExchRows<MODEL>::V; rr++) ex_g[rr * EP + exch_pos<MODEL>(jj)] = M[rr];
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                 } else {
                     cov_stage_finish(Ln, stg, M, ex_row);
                 }
+                __builtin_amdgcn_s_setprio(0);
             }
             cov_end(Ln);
             if (MODEL == 2) {  // column clone: columns 15:18 := columns 0:3 (CpiV2.h:436-441)
