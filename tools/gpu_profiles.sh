@@ -10,3 +10,4 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/r02_bench_default.json 2> gpu
 bash tools/prof_run.sh gpurun_out/r02_kernel_stats.md --steps 20 --warmup 5 > /dev/null 2>&1; head -12 gpurun_out/r02_kernel_stats.md | cut -c1-160
 CPI_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 20 --warmup 5 --workload v2_full --scaling strong --no-extra --no-cpu > gpurun_out/r02_bench_v2full_strong_dist1.json 2> gpurun_out/r02_bench_v2full_strong_dist1.err; tail -c 700 gpurun_out/r02_bench_v2full_strong_dist1.json
 CPI_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --steps 20 --warmup 5 --gather all --no-extra --no-cpu > gpurun_out/r02_bench_dist1_allgather.json 2> gpurun_out/r02_bench_dist1_allgather.err; tail -c 400 gpurun_out/r02_bench_dist1_allgather.json
+python tools/profile_digest.py gpurun_out/r02_bench_default.json gpurun_out/r02_pmc.json > gpurun_out/r02_digest.md 2>/dev/null || true
