@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPI_AMD_LIB") or os.path.join(_HERE, "libcpi_amd.so")  # env override: kernel-variant A/B runs
 
-CPI_OK, CPI_ERR_INVALID, CPI_ERR_HIP, CPI_ERR_NO_DEVICE = 0, 1, 2, 3
+CPI_OK, CPI_ERR_INVALID, CPI_ERR_HIP, CPI_ERR_NO_DEVICE, CPI_ERR_RCCL = 0, 1, 2, 3, 4
 ABI_VERSION = 2   # include/cpi_amd.h CPI_ABI_VERSION
 OUT_FIELDS = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9),
               ("H_a", 9), ("H_b", 9), ("O_a", 9), ("O_b", 9), ("P", 225)]
@@ -39,14 +39,21 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build as _build  # hipcc cross-compiles without a GPU; raises if hipcc fails
-        _build.build()
+    from . import build as _build
+    if LIB_PATH == _build.LIB and _build.stale():
+        _build.build()   # missing, or built from other sources than the tree holds (content hash); hipcc cross-compiles without a GPU
     if not os.path.exists(LIB_PATH):
         raise ImportError("cpi_amd: %s is missing and could not be built (no CPU fallback exists)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+    # the ABI guard comes FIRST: a stale library must fail with this message, not with an AttributeError on a new symbol
     lib.cpi_abi_version.restype = C.c_int
+    if lib.cpi_abi_version() != ABI_VERSION:
+        raise ImportError("cpi_amd: %s has ABI version %d, this binding expects %d (stale build?)" % (LIB_PATH, lib.cpi_abi_version(), ABI_VERSION))
+    missing = [n for n in ("cpi_assemble_tiles", "cpi_tile_windows", "cpi_outputs_bind_slab", "cpi_preintegrate_tiled_batch_host")
+               if not hasattr(lib, n)]
+    if missing:
+        raise ImportError("cpi_amd: %s lacks %s (a build from before round 3: run python -m cpi_amd.build --force)" % (LIB_PATH, ", ".join(missing)))
     lib.cpi_build_id.restype = C.c_char_p
     lib.cpi_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     lib.cpi_group_destroy.argtypes = [vp]
@@ -70,6 +77,14 @@ def load():
     lib.cpi_preintegrate_batch.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, vp, dp, dp, C.POINTER(CpiOutputs)]
     lib.cpi_preintegrate_tiled_batch.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, dp, dp, C.POINTER(CpiOutputs)]
     lib.cpi_tile_knots.argtypes = [vp, i64, i32, dp, dp]
+    lib.cpi_tile_windows.argtypes = [vp, i64, i32, dp, vp, vp, dp]
+    lib.cpi_assemble_tiles.argtypes = [vp, i64, dp, i64, dp, i32, dp, vp]
+    lib.cpi_preintegrate_tiled_batch_host.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, dp, dp, C.POINTER(CpiOutputs)]
+    lib.cpi_outputs_slab_doubles.argtypes = [C.POINTER(CpiOutputs), i64]
+    lib.cpi_outputs_slab_doubles.restype = C.c_size_t
+    lib.cpi_outputs_bind_slab.argtypes = [C.POINTER(CpiOutputs), i64, dp, C.POINTER(CpiOutputs)]
+    lib.cpi_group_last_gather_messages.argtypes = [vp]
+    lib.cpi_test_group_create_shared.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
     lib.cpi_factor_eval_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp]
     lib.cpi_factor_eval_packed_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp]
     lib.cpi_sqrt_information_batch.argtypes = [vp, i64, dp, dp]
@@ -85,9 +100,9 @@ def load():
     for f in (lib.cpi_ctx_create, lib.cpi_ctx_synchronize, lib.cpi_preintegrate_batch, lib.cpi_factor_eval_batch,
               lib.cpi_sqrt_information_batch, lib.cpi_factor_eval_whitened_batch, lib.cpi_factor_eval_packed_batch,
               lib.cpi_predict_batch, lib.cpi_preintegrate_batch_host, lib.cpi_factor_eval_batch_host, lib.cpi_factor_hessian_batch,
-              lib.cpi_preintegrate_tiled_batch, lib.cpi_tile_knots, lib.cpi_group_create, lib.cpi_group_gather, lib.cpi_group_synchronize, lib.cpi_group_size, lib.cpi_ctx_set_stream):
+              lib.cpi_preintegrate_tiled_batch, lib.cpi_tile_knots, lib.cpi_group_create, lib.cpi_group_gather, lib.cpi_group_synchronize, lib.cpi_group_size, lib.cpi_ctx_set_stream,
+              lib.cpi_tile_windows, lib.cpi_assemble_tiles, lib.cpi_preintegrate_tiled_batch_host, lib.cpi_outputs_bind_slab,
+              lib.cpi_group_last_gather_messages, lib.cpi_test_group_create_shared):
         f.restype = C.c_int
-    if lib.cpi_abi_version() != ABI_VERSION:
-        raise ImportError("cpi_amd: %s has ABI version %d, this binding expects %d (stale build?)" % (LIB_PATH, lib.cpi_abi_version(), ABI_VERSION))
     _lib = lib
     return lib

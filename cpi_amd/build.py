@@ -1,52 +1,102 @@
 """Build libcpi_amd.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
 
-    python -m cpi_amd.build            # build if stale
-    python -m cpi_amd.build --force --report   # rebuild and write the per-kernel resource table
+    python -m cpi_amd.build                      # build what is stale
+    python -m cpi_amd.build --force --report     # rebuild everything and print the per-kernel resource table
+    python -m cpi_amd.build --experiments        # additionally libcpi_amd_exp.so (-DCPI_EXPERIMENTS: the measurement-only
+                                                 # kernels and environment switches of tools/exp/; load it with CPI_AMD_LIB)
 
-hipcc cross-compiles gfx950 without a GPU present; the .so is git-ignored but ships to the GPU box.
+The library is four translation units (cpi_amd/csrc/cpi_args.hpp) compiled IN PARALLEL into cpi_amd/csrc/_obj/*.o and
+linked into one shared object; an object is rebuilt only when the sources it includes (or the flags) change, so touching
+one kernel family costs one TU.  hipcc cross-compiles gfx950 without a GPU present; the .so is git-ignored but ships to
+the GPU box.
 """
+import hashlib
 import os
 import re
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "cpi_kernels.hip")
-KERNEL_PARTS = ["cpi_device_util.hpp", "cpi_mean_kernels.hpp", "cpi_mean_experimental.hpp", "cpi_cov_kernels.hpp", "cpi_factor_kernels.hpp"]
-DEPS = ([SRC, os.path.join(HERE, "csrc", "cpi_math.hpp")] + [os.path.join(HERE, "csrc", f) for f in KERNEL_PARTS] +
-        [os.path.join(os.path.dirname(HERE), "include", "cpi_amd.h")])
+CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(os.path.dirname(HERE), "include")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcpi_amd.so")
-REPORT = os.path.join(HERE, "csrc", "resource_usage.txt")
+LIB_EXP = os.path.join(HERE, "libcpi_amd_exp.so")
+REPORT = os.path.join(CSRC, "resource_usage.txt")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
-         "-Rpass-analysis=kernel-resource-usage"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage"]
+COMMON = ["cpi_args.hpp", "../../include/cpi_amd.h"]
+DEVICE = COMMON + ["cpi_math.hpp", "cpi_device_util.hpp"]
+# translation unit -> the files it includes (what its object depends on)
+UNITS = {
+    "cpi_mean": DEVICE + ["cpi_mean.hip", "cpi_mean_kernels.hpp"],
+    "cpi_cov": DEVICE + ["cpi_cov.hip", "cpi_cov_kernels.hpp"],
+    "cpi_factor": DEVICE + ["cpi_factor.hip", "cpi_factor_kernels.hpp"],
+    "cpi_abi": COMMON + ["cpi_abi.hip", "../../include/cpi_amd_test.h"],
+}
+EXP_EXTRA = {"cpi_mean": ["cpi_mean_experimental.hpp"]}   # additional includes under -DCPI_EXPERIMENTS
+EXP_UNITS = ("cpi_mean", "cpi_abi")                        # the units that differ in an experiments build
 
 
-def source_id():
+def _path(rel):
+    return os.path.normpath(os.path.join(CSRC, rel))
+
+
+def _sources(experiments=False):
+    s = set()
+    for u, deps in UNITS.items():
+        s.update(deps)
+        if experiments:
+            s.update(EXP_EXTRA.get(u, []))
+    return sorted(s)
+
+
+def source_id(experiments=False):
     """sha256[:16] over the sources the library is built from -- compiled into it (cpi_build_id()), so that measurement
     records (profiles/*_pmc.json) can be tied to the exact library that is loaded."""
-    import hashlib
     h = hashlib.sha256()
-    for d in DEPS + [os.path.join(os.path.dirname(HERE), "include", "cpi_amd_test.h")]:
-        with open(d, "rb") as f:
-            h.update(f.read())
+    for d in _sources(experiments):
+        with open(_path(d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    if experiments:
+        h.update(b"CPI_EXPERIMENTS")
     return h.hexdigest()[:16]
 
 
-def stale():
-    return (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+def _unit_key(unit, defines, experiments):
+    h = hashlib.sha256(" ".join(CFLAGS + defines).encode())
+    for d in UNITS[unit] + (EXP_EXTRA.get(unit, []) if experiments else []):
+        with open(_path(d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
-def build(force=False, report=False):
-    if not (force or stale()):
-        return LIB
-    cmd = [HIPCC] + FLAGS + ['-DCPI_BUILD_ID="%s"' % source_id(), "-o", LIB, SRC]
+def _compile(unit, experiments, force):
+    exp = experiments and unit in EXP_UNITS
+    defines = (["-DCPI_EXPERIMENTS"] if exp else [])
+    if unit == "cpi_abi":
+        defines.append('-DCPI_BUILD_ID="%s"' % source_id(experiments))
+    obj = os.path.join(OBJ, unit + ("_exp" if exp else "") + ".o")
+    stamp, log = obj + ".key", obj + ".log"
+    key = _unit_key(unit, defines, exp)
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
+        return obj, (open(log).read() if os.path.exists(log) else "")
+    cmd = [HIPCC] + CFLAGS + defines + ["-c", "-o", obj, os.path.join(CSRC, unit + ".hip")]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if p.returncode != 0:
         sys.stderr.write(p.stdout)
-        raise RuntimeError("hipcc failed")
+        raise RuntimeError("hipcc failed on %s.hip" % unit)
+    with open(log, "w") as f:
+        f.write(p.stdout)
+    with open(stamp, "w") as f:
+        f.write(key)
+    return obj, p.stdout
+
+
+def _resource_rows(text):
     rows, cur = [], {}
-    for line in p.stdout.splitlines():
+    for line in text.splitlines():
         m = re.search(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]):\s*(\S+)", line)
         if not m:
             continue
@@ -56,19 +106,56 @@ def build(force=False, report=False):
             rows.append(cur)
         else:
             cur[k.split(" ")[0]] = v
-    if report or True:
-        with open(REPORT, "w") as f:
-            f.write("%-72s %5s %5s %5s %7s %4s %6s\n" % ("kernel", "SGPR", "VGPR", "AGPR", "scratch", "occ", "LDS"))
-            for r in rows:
-                name = subprocess.run(["c++filt", r["name"]], stdout=subprocess.PIPE, text=True).stdout.strip()
-                name = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-                f.write("%-72s %5s %5s %5s %7s %4s %6s\n" % (name, r.get("TotalSGPRs"), r.get("VGPRs"), r.get("AGPRs"),
-                                                         r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS")))
+    return rows
+
+
+def _link(lib, objs):
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout)
+        raise RuntimeError("link failed: %s" % lib)
+
+
+def stale(lib=LIB, experiments=False):
+    """Content-based (a sidecar file holds the source id the library was built from): file times do not survive a copy of
+    the tree to another machine, and a rebuild there would burn GPU-box minutes for nothing."""
+    try:
+        with open(lib + ".id") as f:
+            return (not os.path.exists(lib)) or f.read().strip() != source_id(experiments)
+    except OSError:
+        return True
+
+
+def build(force=False, report=False, experiments=False):
+    """Returns the path of the library built (the default library; with experiments=True BOTH are built and the default's
+    path is returned)."""
+    os.makedirs(OBJ, exist_ok=True)
+    todo = []
+    if force or stale(LIB, False):
+        todo.append((LIB, False))
+    if experiments and (force or stale(LIB_EXP, True)):
+        todo.append((LIB_EXP, True))
+    for lib, exp in todo:
+        with ThreadPoolExecutor(len(UNITS)) as ex:
+            res = list(ex.map(lambda u: _compile(u, exp, force and (not exp or u in EXP_UNITS)), UNITS))
+        _link(lib, [o for o, _ in res])
+        with open(lib + ".id", "w") as f:
+            f.write(source_id(exp))
+        if not exp:
+            rows = [r for _, text in res for r in _resource_rows(text)]
+            with open(REPORT, "w") as f:
+                f.write("%-72s %5s %5s %5s %7s %4s %6s\n" % ("kernel", "SGPR", "VGPR", "AGPR", "scratch", "occ", "LDS"))
+                names = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), stdout=subprocess.PIPE, text=True).stdout.splitlines()
+                for r, name in zip(rows, names):
+                    name = name.strip().replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+                    f.write("%-72s %5s %5s %5s %7s %4s %6s\n" % (name, r.get("TotalSGPRs"), r.get("VGPRs"), r.get("AGPRs"),
+                                                             r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS")))
     return LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, report="--report" in sys.argv)
+    build(force="--force" in sys.argv, report="--report" in sys.argv, experiments="--experiments" in sys.argv)
     print(LIB)
     if "--report" in sys.argv:
         print(open(REPORT).read())

@@ -1,47 +1,39 @@
-// cpi_kernels.hip -- CDNA4 (gfx950) kernels + C-ABI of the batched continuous-preintegration engine.
+// cpi_abi.hip -- the C-ABI of include/cpi_amd.h: argument checks, launch heuristics, device sets (RCCL over xGMI) and the
+// host-pointer pipelines.  Host code only; the kernels live in cpi_mean.hip / cpi_cov.hip / cpi_factor.hip and are reached
+// through cpi::launch (cpi_args.hpp).
 //
-// Kernels (one 64-lane wavefront per workgroup; all arithmetic f64 VALU, no MFMA -- the
-// contractions are 3x3 / sparse 15x15):
-//   cpi_mean_kernel<MODEL,JAC,AVG,L>   means (+ analytic bias Jacobians).  L lanes per window, each lane
-//        integrates a contiguous run of intervals read through an LDS-staged, coalesced tile of IMU
-//        knots, then an order-preserving shuffle tree composes the L segments.
-//        Replaces CpiV1.h:67-259 / CpiV2.h:88-305.
-//   cpi_cov_kernel<MODEL,AVG>          covariance (model 2: + compounded state transition -> Jacobians)
-//        and means.  A 16- (model 1) or 32-lane (model 2) group owns one window; lane j owns column j
-//        of P (or of Discrete_J_b).  Phase A computes the per-interval closed forms lane-parallel over
-//        samples into LDS; phase C walks the samples sequentially: F x is lane-local, P F^T arrives
-//        through a 9-row LDS transpose exchange; classic RK4.  Replaces CpiV1.h:266-353 / CpiV2.h:314-464.
-//   cpi_factor_kernel<MODEL,WHITEN,LPF> evaluateError residual + dense 15x15 H1/H2; LPF (16/8/4) lanes per
-//        factor, lane q emits columns q, q+LPF, ...  Replaces ImuFactorCPIv1.cpp:37-208 / ImuFactorCPIv2.cpp:38-212.
-//   cpi_sqrt_info_kernel               R = chol_upper(P^-1) per factor (GTSAM noiseModel::Gaussian::Covariance, called
-//        from ImuFactorCPIv1.h:82 / ImuFactorCPIv2.h:86): 16 lanes per factor, columns in registers, DPP row_share
-//        broadcasts, triangular inverse fused into the factorisation.
+// Kernels behind the entries (one 64-lane wavefront per workgroup; all arithmetic f64 VALU, no MFMA -- the contractions
+// are 3x3 / sparse 15x15):
+//   cpi_mean_kernel<MODEL,JAC,AVG,L>   means (+ analytic bias Jacobians), L lanes per window.  CpiV1.h:67-259 / CpiV2.h:88-305.
+//   cpi_mean_tiled_kernel              the same recursion on the tiled input layout (one lane per window, no staging).
+//   cpi_cov_kernel<MODEL,AVG>          covariance (model 2: + compounded state transition -> Jacobians) and means;
+//                                      column-lane RK4 recursion.  CpiV1.h:266-353 / CpiV2.h:314-464.
+//   cpi_forster_kernel                 GTSAM's discrete comparator.  GraphSolver_IMU.cpp:141-232.
+//   cpi_factor_kernel<MODEL,WHITEN,LPF> / cpi_factor_packed_kernel / cpi_factor_hessian_kernel
+//                                      evaluateError residual + Jacobian blocks.  ImuFactorCPIv1.cpp:37-208 / v2.cpp:38-212.
+//   cpi_sqrt_info_kernel               R = chol_upper(P^-1) per factor (ImuFactorCPIv1.h:82).
 //   cpi_predict_kernel<MODEL>          GraphSolver_IMU.cpp:263-307.
+//   cpi_tile_knots_kernel / cpi_assemble_tiles_kernel   producers of the tiled layout (GraphSolver_IMU.cpp:50-69).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // prototypes and enums only: the library is bound lazily with dlopen (never linked)
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
-#include <string>
 #include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "../../include/cpi_amd.h"
 #include "../../include/cpi_amd_test.h"
-#include "cpi_math.hpp"
+#include "cpi_args.hpp"
 
 using namespace cpi;
 
-
-// The kernels live in the files below (one translation unit: everything is compiled here, in this order).
-#include "cpi_device_util.hpp"
-#include "cpi_mean_kernels.hpp"
-#include "cpi_mean_experimental.hpp"
-#include "cpi_cov_kernels.hpp"
-#include "cpi_factor_kernels.hpp"
-
-
 // ============================================================================================
-// C-ABI
+// contexts
 // ============================================================================================
 struct HostPipe;
 static void host_pipe_destroy(HostPipe *);
@@ -139,11 +131,34 @@ extern "C" int cpi_ctx_synchronize(cpi_ctx *ctx) {
 
 // hipLaunchKernelGGL takes 32-bit grid dimensions: a launch is refused rather than silently truncated
 static bool grid_ok(long long nb) { return nb > 0 && nb <= 0x7fffffffLL; }
-static const int kMeanLanes[] = {1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64};
-static bool mean_lanes_supported(int L) {
-    for (int c : kMeanLanes) if (c == L) return true;
-    return false;
+
+#ifdef CPI_EXPERIMENTS
+// Measurement switches of tools/exp/ (A/B runs of kernel variants).  They exist ONLY in a -DCPI_EXPERIMENTS build
+// (python -m cpi_amd.build --experiments -> libcpi_amd_exp.so, loaded through CPI_AMD_LIB); the default library reads no
+// environment variable on any launch path.  Each is read once per process.
+namespace expsw {
+static launch::MeanDmaCfg mean_dma() {   // CPI_AMD_MEAN_DMA = "off" | "KC,S,A" (A = 1: 16-byte aligned pieces)
+    static launch::MeanDmaCfg c = [] {
+        launch::MeanDmaCfg d = {0, 0, 0};
+        const char *e = getenv("CPI_AMD_MEAN_DMA");
+        if (e && strcmp(e, "off") != 0) { int k = 0, s = 0, al = 1; if (sscanf(e, "%d,%d,%d", &k, &s, &al) >= 2) d = {k, s, al}; }
+        return d;
+    }();
+    return c;
 }
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static int mean_blk() { static int v = [] { const char *e = getenv("CPI_AMD_MEAN_BLK"); return e ? (strcmp(e, "off") == 0 ? -1 : atoi(e)) : 0; }(); return v; }
+static int blk_mode() { static int v = env_int("CPI_AMD_BLK_MODE", 0); return v; }
+static int probe_lds() { static int v = env_int("CPI_AMD_PROBE_LDS", 0); return v; }
+static bool no_overlap() { static int v = env_int("CPI_AMD_NO_OVERLAP", 0); return v != 0; }
+static int factor_lanes() { static int v = env_int("CPI_AMD_FACTOR_LANES", 0); return (v == 16 || v == 8 || v == 4) ? v : 0; }
+static int packed_lpf() { static int v = env_int("CPI_AMD_PACKED_LPF", 0); return (v == 2 || v == 3 || v == 4 || v == 6 || v == 8) ? v : 0; }
+}  // namespace expsw
+#endif
+
+// ============================================================================================
+// preintegration
+// ============================================================================================
 static int pick_lanes(const cpi_params *prm, int64_t W, int N, bool jac) {
     // model 2 with analytic Jacobians: sequential per window (the O_a / O_b recursion is not composed); model 2
     // mean-only composes through the gravity response matrices at roughly twice the arithmetic per interval
@@ -158,7 +173,10 @@ static int pick_lanes(const cpi_params *prm, int64_t W, int N, bool jac) {
         // Measured optima: L = 12 at 5 k windows x 50, 6 at 10 k, 4 at 15 k, 3 at 20 k, 2 at 30 k, 1 from ~60 k.
         double best = 1e300;
         L = 1;
-        for (int c : kMeanLanes) {
+        const int *choices = nullptr;
+        const int nc = launch::mean_lane_choices(&choices);
+        for (int i = 0; i < nc; i++) {
+            const int c = choices[i];
             if (c > 1 && 2 * c > N) break;
             const int64_t waves = (W + (64 / c) - 1) / (64 / c);
             if (c > 1 && waves > 1024) break;
@@ -171,65 +189,7 @@ static int pick_lanes(const cpi_params *prm, int64_t W, int N, bool jac) {
     return L;
 }
 
-template <int MODEL, bool JAC, bool AVG>
-static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
-#define CPI_LAUNCH_L(LL)                                                                         \
-    case LL: {                                                                                   \
-        const long long nb = (a.W + (64 / LL) - 1) / (64 / LL);                                  \
-        hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL>), dim3((unsigned)nb), dim3(64), 0, st, a); \
-    } break;
-    if constexpr (MODEL == 2 && JAC) { switch (L) { CPI_LAUNCH_L(1) default: break; } } else
-    switch (L) {
-        CPI_LAUNCH_L(1) CPI_LAUNCH_L(2) CPI_LAUNCH_L(3) CPI_LAUNCH_L(4) CPI_LAUNCH_L(5) CPI_LAUNCH_L(6) CPI_LAUNCH_L(8)
-        CPI_LAUNCH_L(12) CPI_LAUNCH_L(16) CPI_LAUNCH_L(32) CPI_LAUNCH_L(64)
-        default: break;
-    }
-#undef CPI_LAUNCH_L
-}
-template <int MODEL>
-static void launch_mean(bool jac, bool avg, int L, const PreArgs &a, hipStream_t st) {
-    if (jac) { if (avg) launch_mean_L<MODEL, true, true>(L, a, st); else launch_mean_L<MODEL, true, false>(L, a, st); }
-    else     { if (avg) launch_mean_L<MODEL, false, true>(L, a, st); else launch_mean_L<MODEL, false, false>(L, a, st); }
-}
-// ---- LDS-DMA mean kernel (large mean-only batches, dense layout, one lane per window)
-struct MeanDmaCfg { int kc, s, aligned; };
-// CPI_AMD_MEAN_DMA = "off" | "KC,S,A" (A = 1: 16-byte aligned pieces): development override of the default below
-static MeanDmaCfg mean_dma_cfg() {
-    static MeanDmaCfg c = [] {
-        MeanDmaCfg d = {0, 0, 0};   // default: see pick below
-        const char *e = getenv("CPI_AMD_MEAN_DMA");
-        if (e && strcmp(e, "off") != 0) { int k = 0, s = 0, al = 1; if (sscanf(e, "%d,%d,%d", &k, &s, &al) >= 2) d = {k, s, al}; }
-        return d;
-    }();
-    return c;
-}
-template <int KC, bool ALIGNED>
-static long long mean_dma_safe_blocks(long long W, int N) {
-    typedef DmaGeom<KC, ALIGNED> G;
-    const long long wstride = (long long)(N + 1) * 56;
-    const long long nst = (N + KC - 1) / KC;
-    long long nb = W / 64;
-    // furthest byte a block touches: window (b*64 + NI*WPI - 1), knot 1 + nst*KC, plus 16 bytes of alignment slack
-    while (nb > 0 && ((nb - 1) * 64 + (long long)G::NI * G::WPI - 1) * wstride + 56 + nst * KC * 56 + 16 > W * wstride) --nb;
-    return nb;
-}
-template <int MODEL, int KC, int S, bool ALIGNED>
-static long long launch_mean_dma_one(bool avg, const PreArgs &a, hipStream_t st) {
-    const long long nb = mean_dma_safe_blocks<KC, ALIGNED>(a.W, a.N);
-    if (nb <= 0) return 0;
-    if (avg) hipLaunchKernelGGL((cpi_mean_dma_kernel<MODEL, true, KC, S, ALIGNED>), dim3((unsigned)nb), dim3(64), 0, st, a);
-    else     hipLaunchKernelGGL((cpi_mean_dma_kernel<MODEL, false, KC, S, ALIGNED>), dim3((unsigned)nb), dim3(64), 0, st, a);
-    return nb * 64;
-}
-// Returns the number of leading windows handled (a multiple of 64; the caller runs the rest through cpi_mean_kernel).
-template <int MODEL>
-static long long launch_mean_dma(const MeanDmaCfg &c, bool avg, const PreArgs &a, hipStream_t st) {
-#define CPI_DMA_CASE(K, S_, A_) if (c.kc == K && c.s == S_ && c.aligned == A_) return launch_mean_dma_one<MODEL, K, S_, (A_ != 0)>(avg, a, st);
-    CPI_DMA_CASE(4, 2, 1) CPI_DMA_CASE(4, 2, 0) CPI_DMA_CASE(2, 3, 0) CPI_DMA_CASE(8, 1, 1)
-    CPI_DMA_CASE(4, 1, 0) CPI_DMA_CASE(4, 1, 1) CPI_DMA_CASE(6, 1, 0) CPI_DMA_CASE(6, 2, 0)
-#undef CPI_DMA_CASE
-    return 0;
-}
+#ifdef CPI_EXPERIMENTS
 static PreArgs shift_windows(const PreArgs &a, long long w0) {
     PreArgs t = a;
     t.W = a.W - w0;
@@ -237,45 +197,13 @@ static PreArgs shift_windows(const PreArgs &a, long long w0) {
     if (a.count) t.count = a.count + w0;
     t.lin = a.lin + w0 * 6;
     if (a.qk) t.qk = a.qk + w0 * 4;
-    for (int k = 0; k < 12; k++) {
-        static const int n[12] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225 };
-        double **f[12] = { &t.out.DT, &t.out.alpha, &t.out.beta, &t.out.q, &t.out.J_q, &t.out.J_a, &t.out.J_b, &t.out.H_a,
-                           &t.out.H_b, &t.out.O_a, &t.out.O_b, &t.out.P };
-        if (*f[k]) *f[k] += w0 * n[k];
-    }
+    static const int n[12] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225 };
+    double **f[12] = { &t.out.DT, &t.out.alpha, &t.out.beta, &t.out.q, &t.out.J_q, &t.out.J_a, &t.out.J_b, &t.out.H_a,
+                       &t.out.H_b, &t.out.O_a, &t.out.O_b, &t.out.P };
+    for (int k = 0; k < 12; k++) if (*f[k]) *f[k] += w0 * n[k];
     return t;
 }
-
-// ---- block-resident mean kernel: L lanes per window (power of two) so that 64/L whole windows fit the LDS budget
-// CPI_AMD_MEAN_BLK = "off" | L : development override of pick_blk_lanes
-static int mean_blk_forced() {
-    static int v = [] { const char *e = getenv("CPI_AMD_MEAN_BLK"); return e ? (strcmp(e, "off") == 0 ? -1 : atoi(e)) : 0; }();
-    return v;
-}
-template <int MODEL, int L>
-static void launch_mean_blk_L(bool avg, const PreArgs &a, hipStream_t st) {
-    constexpr int WPB = 64 / L;
-    const long long nb = (a.W + WPB - 1) / WPB;
-    const size_t lds = ((size_t)WPB * (size_t)(a.N + 1) * 56 + 15) & ~(size_t)15;
-    if (avg) hipLaunchKernelGGL((cpi_mean_blk_kernel<MODEL, true, L>), dim3((unsigned)nb), dim3(64), lds, st, a);
-    else     hipLaunchKernelGGL((cpi_mean_blk_kernel<MODEL, false, L>), dim3((unsigned)nb), dim3(64), lds, st, a);
-}
-template <int MODEL>
-static bool launch_mean_blk(int L, bool avg, const PreArgs &a, hipStream_t st) {
-    switch (L) {
-        case 8: launch_mean_blk_L<MODEL, 8>(avg, a, st); return true;
-        case 16: launch_mean_blk_L<MODEL, 16>(avg, a, st); return true;
-        default: return false;
-    }
-}
-
-template <int MODEL>
-static void launch_cov(bool avg, const PreArgs &a, hipStream_t st) {
-    constexpr int G = 64 / CovDims<MODEL>::GROUP;
-    const long long nb = (a.W + G - 1) / G;
-    if (avg) hipLaunchKernelGGL((cpi_cov_kernel<MODEL, true>), dim3((unsigned)nb), dim3(64), 0, st, a);
-    else     hipLaunchKernelGGL((cpi_cov_kernel<MODEL, false>), dim3((unsigned)nb), dim3(64), 0, st, a);
-}
+#endif
 
 extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
                                       const double *knots, const int64_t *first, const int32_t *count,
@@ -292,7 +220,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     if (!grid_ok(W)) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: W exceeds 2^31 - 1 windows per call (32-bit grid)");
     if (N > 65535) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: N (intervals per window) must be <= 65535");
     int L = prm->lanes_per_window;
-    if (L != 0 && !mean_lanes_supported(L)) return fail(ctx, CPI_ERR_INVALID, "lanes_per_window must be 0 or one of 1,2,3,4,5,6,8,12,16,32,64");
+    if (L != 0 && !launch::mean_lanes_supported(L)) return fail(ctx, CPI_ERR_INVALID, "lanes_per_window must be 0 or one of 1,2,3,4,5,6,8,12,16,32,64");
 
     const bool want_mean = out->DT || out->alpha || out->beta || out->q;
     const bool want_jac = out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b;
@@ -310,7 +238,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     a.q4[2] = prm->sigma_a * prm->sigma_a; a.q4[3] = prm->sigma_ab * prm->sigma_ab;
     a.out = *out;
     if (prm->model == CPI_MODEL_FORSTER) {   // one kernel owns everything; imu_avg, q_k_lin, grav play no part
-        hipLaunchKernelGGL(cpi_forster_kernel, dim3((unsigned)((W + 3) / 4)), dim3(64), 0, ctx->stream, a);
+        launch::forster(a, ctx->stream);
         CPI_HIP(ctx, hipGetLastError());
         return CPI_OK;
     }
@@ -330,7 +258,10 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     // covariance kernel waits on the LDS pipe about as much as it issues VALU work and uses no more than two wavefronts per
     // SIMD; the Jacobian kernel is pure FP64 VALU with no LDS: issued on a side stream (fork / join by events, so everything
     // later on the context's stream still waits for both, and a stream capture sees an ordinary fork) they share the SIMDs.
-    static const bool overlap_on = [] { const char *e = getenv("CPI_AMD_NO_OVERLAP"); return !(e && atoi(e)); }();
+    bool overlap_on = true;
+#ifdef CPI_EXPERIMENTS
+    overlap_on = !expsw::no_overlap();
+#endif
     hipStream_t mean_stream = ctx->stream;
     bool forked = false;
     if (run_cov && run_mean && mean_jac && overlap_on) {
@@ -349,7 +280,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
         c.write_means = want_mean ? 1 : 0;
         c.write_jac = (stj && want_jac) ? 1 : 0;
         if (!want_cov) c.out.P = nullptr;
-        if (v2) launch_cov<2>(avg, c, ctx->stream); else launch_cov<1>(avg, c, ctx->stream);
+        launch::cov(prm->model, avg, c, ctx->stream);
     }
     if (run_mean) {
         PreArgs m = a;
@@ -357,19 +288,18 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
         m.write_jac = mean_jac ? 1 : 0;
         const int LL = pick_lanes(prm, W, N, mean_jac);
         long long done = 0;
-        const int bl = mean_blk_forced();
-        static const int dbg_mode = [] { const char *e = getenv("CPI_AMD_BLK_MODE"); return e ? atoi(e) : 0; }();   // development only
-        m.dbg = dbg_mode;
+#ifdef CPI_EXPERIMENTS
+        const int bl = expsw::mean_blk();
+        m.dbg = expsw::blk_mode();
         if (!mean_jac && !first && bl > 0 && (size_t)(64 / bl) * (size_t)(N + 1) * 56 <= 65536 && N >= 1) {
-            if (v2 ? launch_mean_blk<2>(bl, avg, m, ctx->stream) : launch_mean_blk<1>(bl, avg, m, ctx->stream)) done = W;
+            if (launch::mean_blk(prm->model, bl, avg, m, ctx->stream)) done = W;
         }
-        const MeanDmaCfg dc = mean_dma_cfg();
+        const launch::MeanDmaCfg dc = expsw::mean_dma();
         if (!done && !mean_jac && LL == 1 && !first && !count && dc.kc > 0 && N >= 2 * dc.kc)
-            done = v2 ? launch_mean_dma<2>(dc, avg, m, ctx->stream) : launch_mean_dma<1>(dc, avg, m, ctx->stream);
-        if (done < W) {
-            const PreArgs t = done ? shift_windows(m, done) : m;
-            if (v2) launch_mean<2>(mean_jac, avg, LL, t, mean_stream); else launch_mean<1>(mean_jac, avg, LL, t, mean_stream);
-        }
+            done = launch::mean_dma(prm->model, dc, avg, m, ctx->stream);
+        if (done && done < W) m = shift_windows(m, done);
+#endif
+        if (done < W) launch::mean(prm->model, mean_jac, avg, LL, m, mean_stream);
     }
     if (forked) {
         CPI_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
@@ -379,120 +309,64 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     return CPI_OK;
 }
 
-// Lanes per factor of the factor kernel.  CPI_AMD_FACTOR_LANES (16 | 8 | 4) overrides the size heuristic
-// (tuning / A-B measurements).
+// ============================================================================================
+// re-linearisation sweeps
+// ============================================================================================
+// Lanes per factor of the dense sweep: 16 gives the most wavefronts (small sweeps), fewer lanes do less redundant
+// arithmetic.  Measured on MI355X, 1 M factors: plain 0.82 ms with 8 lanes vs 1.09 ms with 16; whitened (37 KB vs 19 KB of
+// LDS per wavefront) 1.45 ms with 8 vs 1.37 ms with 16.
 static int factor_lanes(int64_t F, bool whiten) {
-    static int forced = [] {
-        const char *e = getenv("CPI_AMD_FACTOR_LANES");
-        const int v = e ? atoi(e) : 0;
-        return (v == 16 || v == 8 || v == 4) ? v : 0;
-    }();
-    if (forced) return forced;
-    // measured on MI355X, 1 M factors: plain 0.82 ms with 8 lanes vs 1.09 ms with 16; whitened (37 KB vs 19 KB of
-    // LDS per wavefront) 1.45 ms with 8 vs 1.37 ms with 16
+#ifdef CPI_EXPERIMENTS
+    if (expsw::factor_lanes()) return expsw::factor_lanes();
+#endif
     if (whiten) return 16;
     return F >= 32768 ? 8 : 16;
 }
 
-static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F, const cpi_outputs *meas,
-                            const double *lin, const double *q_k_lin, const double *states, int64_t S, const int32_t *idx_i,
-                            const int32_t *idx_j, const double *sqrt_info, double *err, double *H1, double *H2);
-
-extern "C" int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
-                                     const cpi_outputs *meas, const double *lin, const double *q_k_lin,
-                                     const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
-                                     double *err, double *H1, double *H2) {
-    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, nullptr, err, H1, H2);
+// argument checks shared by the four sweeps; fills the kernel argument block
+static int factor_args(cpi_ctx *ctx, const char *who, int32_t model, const double grav[3], int64_t F, const cpi_outputs *meas,
+                       const double *lin, const double *q_k_lin, const double *states, int64_t S, const int32_t *idx_i,
+                       const int32_t *idx_j, FactorArgs &a) {
+    const std::string w(who);
+    if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, w + ": model must be 1 or 2");
+    if (F < 0) return fail(ctx, CPI_ERR_INVALID, w + ": negative size");
+    if (!grav || !meas || !lin || !states) return fail(ctx, CPI_ERR_INVALID, w + ": NULL argument");
+    if (!meas->DT || !meas->alpha || !meas->beta || !meas->q || !meas->J_q || !meas->J_a || !meas->J_b || !meas->H_a || !meas->H_b)
+        return fail(ctx, CPI_ERR_INVALID, w + ": measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
+    if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
+        return fail(ctx, CPI_ERR_INVALID, w + ": model 2 needs q_k_lin, O_a, O_b");
+    if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, w + ": F exceeds 2^31 - 1 factors per call");
+    if (S <= 0 || (!idx_i && S < F) || (!idx_j && S < F + 1))
+        return fail(ctx, CPI_ERR_INVALID, w + ": S (number of states) must be >= 1, and >= F + 1 when idx_i / idx_j are NULL (chained states f, f + 1)");
+    memset(&a, 0, sizeof a);
+    a.F = F;
+    for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
+    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j;
+    return CPI_OK;
 }
 
 static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F, const cpi_outputs *meas,
                             const double *lin, const double *q_k_lin, const double *states, int64_t S, const int32_t *idx_i,
                             const int32_t *idx_j, const double *sqrt_info, double *err, double *H1, double *H2) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
-    if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: model must be 1 or 2");
-    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: negative size");
     if (F == 0) return CPI_OK;
-    if (!grav || !meas || !lin || !states || !err) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: NULL argument");
-    if (!meas->DT || !meas->alpha || !meas->beta || !meas->q || !meas->J_q || !meas->J_a || !meas->J_b || !meas->H_a || !meas->H_b)
-        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
-    if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
-        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: model 2 needs q_k_lin, O_a, O_b");
-    if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: F exceeds 2^31 - 1 factors per call");
-    if (S <= 0 || (!idx_i && S < F) || (!idx_j && S < F + 1))
-        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: S (number of states) must be >= 1, and >= F + 1 when idx_i / idx_j are NULL (chained states f, f + 1)");
+    if (!err) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: NULL argument");
+    FactorArgs a;
+    const int rc = factor_args(ctx, "cpi_factor_eval_batch", model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, a);
+    if (rc != CPI_OK) return rc;
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    FactorArgs a;
-    memset(&a, 0, sizeof a);
-    a.F = F;
-    for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
-    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j;
     a.err = err; a.H1 = H1; a.H2 = H2; a.sqrt_info = sqrt_info;
-    // lanes per factor: 16 gives the most wavefronts (small sweeps), fewer lanes do less redundant arithmetic
-    const int lpf = factor_lanes(F, sqrt_info != nullptr);
-#define CPI_LAUNCH_FACTOR(M, WH, L) \
-    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a)
-#define CPI_LAUNCH_FACTOR_L(M, WH) \
-    do { if (lpf == 16) CPI_LAUNCH_FACTOR(M, WH, 16); else if (lpf == 8) CPI_LAUNCH_FACTOR(M, WH, 8); else CPI_LAUNCH_FACTOR(M, WH, 4); } while (0)
-    if (sqrt_info) {
-        if (model == CPI_MODEL_V1) CPI_LAUNCH_FACTOR_L(1, true); else CPI_LAUNCH_FACTOR_L(2, true);
-    } else {
-        if (model == CPI_MODEL_V1) CPI_LAUNCH_FACTOR_L(1, false); else CPI_LAUNCH_FACTOR_L(2, false);
-    }
-#undef CPI_LAUNCH_FACTOR_L
-#undef CPI_LAUNCH_FACTOR
+    launch::factor(model, sqrt_info != nullptr, factor_lanes(F, sqrt_info != nullptr), a, ctx->stream);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
 
-extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
-                                            const cpi_outputs *meas, const double *lin, const double *q_k_lin,
-                                            const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
-                                            double *packed) {
-    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
-    if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: model must be 1 or 2");
-    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: negative size");
-    if (F == 0) return CPI_OK;
-    if (!grav || !meas || !lin || !states || !packed) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: NULL argument");
-    if (!meas->DT || !meas->alpha || !meas->beta || !meas->q || !meas->J_q || !meas->J_a || !meas->J_b || !meas->H_a || !meas->H_b)
-        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
-    if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
-        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: model 2 needs q_k_lin, O_a, O_b");
-    if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: F exceeds 2^31 - 1 factors per call");
-    if (S <= 0 || (!idx_i && S < F) || (!idx_j && S < F + 1))
-        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: S (number of states) must be >= 1, and >= F + 1 when idx_i / idx_j are NULL");
-    DeviceGuard guard_;
-    CPI_HIP(ctx, guard_.enter(ctx->device));
-    FactorArgs a;
-    memset(&a, 0, sizeof a);
-    a.F = F;
-    for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
-    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j;
-    // lanes per factor.  Every lane of a factor repeats the shared quaternion algebra, so fewer lanes = less VALU per factor
-    // but more LDS per wavefront (a factor's staged record + packed output = 1.5 KB).  Measured (MI355X, 1 M factors, model 1 /
-    // model 2, us): 8 lanes 383 / 435 (VALU 53 % busy at 2 wavefronts per SIMD), 6: 335 / 389, 4: 290 / 324, 3: 281 / 314,
-    // 2: 328 / 361 (48 KB of LDS: one wavefront per SIMD); 100 k factors: 4 lanes 31.5, 3 lanes 32.5.
-    int lpf = (F >= 300000) ? 3 : 4;
-    if (const char *e = getenv("CPI_AMD_PACKED_LPF")) lpf = atoi(e);   // measurements
-#define CPI_PACKED(M, L) hipLaunchKernelGGL((cpi_factor_packed_kernel<M, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, ctx->stream, a, packed)
-    if (model == CPI_MODEL_V1) { if (lpf == 2) CPI_PACKED(1, 2); else if (lpf == 3) CPI_PACKED(1, 3); else if (lpf == 4) CPI_PACKED(1, 4); else if (lpf == 6) CPI_PACKED(1, 6); else CPI_PACKED(1, 8); }
-    else                       { if (lpf == 2) CPI_PACKED(2, 2); else if (lpf == 3) CPI_PACKED(2, 3); else if (lpf == 4) CPI_PACKED(2, 4); else if (lpf == 6) CPI_PACKED(2, 6); else CPI_PACKED(2, 8); }
-#undef CPI_PACKED
-    CPI_HIP(ctx, hipGetLastError());
-    return CPI_OK;
-}
-
-extern "C" int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double *P, double *sqrt_info) {
-    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
-    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: negative size");
-    if (F == 0) return CPI_OK;
-    if (!P || !sqrt_info) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: NULL argument");
-    DeviceGuard guard_;
-    CPI_HIP(ctx, guard_.enter(ctx->device));
-    const long long nb = (F + 3) / 4;
-    hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, (long long)F, P, sqrt_info);
-    CPI_HIP(ctx, hipGetLastError());
-    return CPI_OK;
+extern "C" int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                     const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                     const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                                     double *err, double *H1, double *H2) {
+    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, nullptr, err, H1, H2);
 }
 
 extern "C" int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
@@ -503,32 +377,58 @@ extern "C" int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const
     return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, sqrt_info, err, H1, H2);
 }
 
+extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                            const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                            const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                                            double *packed) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (F == 0) return CPI_OK;
+    if (!packed) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_packed_batch: NULL argument");
+    FactorArgs a;
+    const int rc = factor_args(ctx, "cpi_factor_eval_packed_batch", model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, a);
+    if (rc != CPI_OK) return rc;
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    // lanes per factor.  Every lane of a factor repeats the shared quaternion algebra, so fewer lanes = less VALU per factor
+    // but more LDS per wavefront (a factor's staged record + packed output = 1.5 KB).  Measured (MI355X, 1 M factors, model 1 /
+    // model 2, us): 8 lanes 383 / 435 (VALU 53 % busy at 2 wavefronts per SIMD), 6: 335 / 389, 4: 290 / 324, 3: 281 / 314,
+    // 2: 328 / 361 (48 KB of LDS: one wavefront per SIMD); 100 k factors: 4 lanes 31.5, 3 lanes 32.5.
+    int lpf = (F >= 300000) ? 3 : 4;
+#ifdef CPI_EXPERIMENTS
+    if (expsw::packed_lpf()) lpf = expsw::packed_lpf();
+#endif
+    launch::factor_packed(model, lpf, a, packed, ctx->stream);
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+
+extern "C" int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double *P, double *sqrt_info) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: negative size");
+    if (F == 0) return CPI_OK;
+    if (!P || !sqrt_info) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: NULL argument");
+    if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: F exceeds 2^31 - 1 factors per call");
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    launch::sqrt_info((long long)F, P, sqrt_info, ctx->stream);
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+
 extern "C" int cpi_factor_hessian_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                                         const cpi_outputs *meas, const double *lin, const double *q_k_lin,
                                         const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                         const double *sqrt_info, double *hess) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
-    if (model != CPI_MODEL_V1 && model != CPI_MODEL_V2) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: model must be 1 or 2");
-    if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: negative size");
     if (F == 0) return CPI_OK;
-    if (!grav || !meas || !lin || !states || !sqrt_info || !hess) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: NULL argument");
-    if (!meas->DT || !meas->alpha || !meas->beta || !meas->q || !meas->J_q || !meas->J_a || !meas->J_b || !meas->H_a || !meas->H_b)
-        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: measurement fields DT/alpha/beta/q/J_q/J_a/J_b/H_a/H_b are required");
-    if (model == CPI_MODEL_V2 && (!q_k_lin || !meas->O_a || !meas->O_b))
-        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: model 2 needs q_k_lin, O_a, O_b");
-    if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: F exceeds 2^31 - 1 factors per call");
-    if (S <= 0 || (!idx_i && S < F) || (!idx_j && S < F + 1))
-        return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: S (number of states) must be >= 1, and >= F + 1 when idx_i / idx_j are NULL");
+    if (!sqrt_info || !hess) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: NULL argument");
+    FactorArgs a;
+    const int rc = factor_args(ctx, "cpi_factor_hessian_batch", model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, a);
+    if (rc != CPI_OK) return rc;
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    FactorArgs a;
-    memset(&a, 0, sizeof a);
-    a.F = F;
-    for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
-    a.meas = *meas; a.lin = lin; a.qk = q_k_lin; a.states = states; a.S = S; a.idx_i = idx_i; a.idx_j = idx_j; a.sqrt_info = sqrt_info;
-    const unsigned nb = (unsigned)((F + 3) / 4);
-    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_hessian_kernel<1>), dim3(nb), dim3(64), 0, ctx->stream, a, hess);
-    else hipLaunchKernelGGL((cpi_factor_hessian_kernel<2>), dim3(nb), dim3(64), 0, ctx->stream, a, hess);
+    a.sqrt_info = sqrt_info;
+    launch::factor_hessian(model, a, hess, ctx->stream);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
@@ -551,9 +451,7 @@ extern "C" int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[
     a.F = F;
     for (int i = 0; i < 3; i++) a.grav[i] = grav[i];
     a.meas = *meas; a.states_i = states_i; a.S = S; a.idx_i = idx_i; a.states_j = states_j;
-    const long long nb = (F + 255) / 256;
-    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_predict_kernel<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((cpi_predict_kernel<2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, a);
+    launch::predict(model, a, ctx->stream);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
@@ -563,21 +461,59 @@ static double **out_field(cpi_outputs *o, int k) {
     double **f[12] = { &o->DT, &o->alpha, &o->beta, &o->q, &o->J_q, &o->J_a, &o->J_b, &o->H_a, &o->H_b, &o->O_a, &o->O_b, &o->P };
     return f[k];
 }
+static double *out_field_c(const cpi_outputs *o, int k) { cpi_outputs t = *o; return *out_field(&t, k); }
 
-// -------------------------------------------------------------------------------- tiled layout
-extern "C" int cpi_tile_knots(cpi_ctx *ctx, int64_t W, int32_t N, const double *knots, double *tiles) {
+extern "C" size_t cpi_outputs_slab_doubles(const cpi_outputs *mask, int64_t Wb) {
+    if (!mask || Wb <= 0) return 0;
+    size_t n = 0;
+    for (int k = 0; k < 12; k++) if (out_field_c(mask, k)) n += (size_t)OUT_N[k] * (size_t)Wb;
+    return n;
+}
+extern "C" int cpi_outputs_bind_slab(const cpi_outputs *mask, int64_t Wb, double *slab, cpi_outputs *bound) {
+    if (!mask || !bound || Wb < 0 || (!slab && Wb > 0)) return CPI_ERR_INVALID;
+    cpi_outputs b;
+    memset(&b, 0, sizeof b);
+    size_t off = 0;
+    for (int k = 0; k < 12; k++)
+        if (out_field_c(mask, k)) { *out_field(&b, k) = slab + off; off += (size_t)OUT_N[k] * (size_t)Wb; }
+    *bound = b;
+    return CPI_OK;
+}
+
+// ============================================================================================
+// tiled layout: producers and the mean-only entry
+// ============================================================================================
+extern "C" int cpi_tile_windows(cpi_ctx *ctx, int64_t W, int32_t N, const double *knots, const int64_t *first,
+                                const int32_t *count, double *tiles) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
-    if (W < 0 || N < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_tile_knots: negative size");
+    if (W < 0 || N < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_tile_windows: negative size");
     if (W == 0) return CPI_OK;
-    if (!knots || !tiles) return fail(ctx, CPI_ERR_INVALID, "cpi_tile_knots: NULL argument");
+    if (!knots || !tiles) return fail(ctx, CPI_ERR_INVALID, "cpi_tile_windows: NULL argument");
+    if (!grid_ok(W)) return fail(ctx, CPI_ERR_INVALID, "cpi_tile_windows: W exceeds 2^31 - 1 windows per call");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    const long long total = ((W + 63) / 64) * (long long)(N + 1) * 448;
-    const unsigned nb = (unsigned)std::min<long long>((total + 255) / 256, 256 * 64);
-    // tile-major.  (Step-major -- tiles[N+1][ceil(W/64)][7][64], all resident wavefronts reading one moving window -- was
-    // measured: 557 vs 571 us per 1 M x 50, 58.2 vs 61.1 us per 100 k, stream alone 472 vs 481 us: not worth a second contract.)
-    const long long ts = (long long)(N + 1) * 448, ss = 448;
-    hipLaunchKernelGGL(cpi_tile_knots_kernel, dim3(nb), dim3(256), 0, ctx->stream, (long long)W, (int)N, knots, tiles, ts, ss);
+    launch::tile_knots((long long)W, (int)N, knots, (const long long *)first, count, tiles, ctx->stream);
+    CPI_HIP(ctx, hipGetLastError());
+    return CPI_OK;
+}
+extern "C" int cpi_tile_knots(cpi_ctx *ctx, int64_t W, int32_t N, const double *knots, double *tiles) {
+    return cpi_tile_windows(ctx, W, N, knots, nullptr, nullptr, tiles);
+}
+extern "C" int cpi_assemble_tiles(cpi_ctx *ctx, int64_t K, const double *stream, int64_t U, const double *update_times,
+                                  int32_t N, double *tiles, int32_t *count) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (K < 0 || U < 0 || N < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_assemble_tiles: negative size");
+    if (U == 0) return CPI_OK;
+    if (K == 0) return fail(ctx, CPI_ERR_INVALID, "cpi_assemble_tiles: the stream is empty");
+    if (!stream || !update_times || !tiles || !count) return fail(ctx, CPI_ERR_INVALID, "cpi_assemble_tiles: NULL argument");
+    if (!grid_ok(U)) return fail(ctx, CPI_ERR_INVALID, "cpi_assemble_tiles: U exceeds 2^31 - 1 windows per call");
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    AssembleArgs a;
+    memset(&a, 0, sizeof a);
+    a.K = K; a.stream = stream; a.U = U; a.update = update_times; a.N = N; a.tiles = tiles; a.count = count;
+    a.ts = (long long)(N + 1) * 448; a.ss = 448;
+    launch::assemble_tiles(a, ctx->stream);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
@@ -594,6 +530,8 @@ extern "C" int cpi_preintegrate_tiled_batch(cpi_ctx *ctx, const cpi_params *prm,
     if (out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b || out->P)
         return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: the tiled layout serves the mean outputs (DT, alpha, beta, q) only; "
                                           "Jacobians and covariance are FP64-bound, not HBM-bound: use cpi_preintegrate_batch");
+    if (prm->lanes_per_window < 0 || prm->lanes_per_window > 8)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: lanes_per_window (here: wavefronts per tile) must be 0 (auto) or 1..8");
     if (!(out->DT || out->alpha || out->beta || out->q)) return CPI_OK;
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
@@ -601,78 +539,74 @@ extern "C" int cpi_preintegrate_tiled_batch(cpi_ctx *ctx, const cpi_params *prm,
     memset(&a, 0, sizeof a);
     a.W = W; a.N = N; a.tiles = tiles; a.count = count; a.lin = lin; a.qk = q_k_lin; a.out = *out;
     for (int i = 0; i < 3; i++) a.grav[i] = prm->grav[i];
-    if (const char *e = getenv("CPI_AMD_BLK_MODE")) a.dbg = atoi(e);
     a.ts = (long long)(N + 1) * 448; a.ss = 448;
-    const unsigned nb = (unsigned)((W + 63) / 64);
-    const bool avg = prm->imu_avg != 0;
+    const long long nb = (W + 63) / 64;
+#ifdef CPI_EXPERIMENTS
+    a.dbg = expsw::blk_mode();
     if (a.dbg == 1) {   // CPI_AMD_PROBE_LDS = dynamic LDS bytes per wavefront, to pin the probe's occupancy (13312 -> 12 waves / CU)
-        const char *e = getenv("CPI_AMD_PROBE_LDS");
-        hipLaunchKernelGGL(cpi_tiled_fetch_probe_kernel, dim3(nb), dim3(64), e ? atoi(e) : 0, ctx->stream, a);
+        launch::tiled_fetch_probe(a, (size_t)expsw::probe_lds(), ctx->stream);
+        CPI_HIP(ctx, hipGetLastError());
         return CPI_OK;
     }
+#endif
     // wavefronts per tile.  Measured (MI355X, N = 50, us per launch, S = 1 / 2 / 3 / 4 / 8): 5 k windows 24.9 / 15.0 / 11.5 /
     // 10.3 / -, 10 k 25.2 / 15.4 / 11.9 / 10.8 / 12.4, 20 k 27.0 / 23.6 / 19.6 / 18.7 / 22.8, 30 k 28.6 / 25.1 / 22.2 / 21.3,
     // 50 k 33.0 / 34.4 / 34.8 / 34.9, 100 k 61.3 / 64.3 / 65.8 / 65.2: four (one per SIMD of the CU that owns the tile) while
-    // the tiles do not fill the chip, one beyond.  CPI_AMD_TILED_SPLIT overrides (measurements, tests).
+    // the tiles do not fill the chip, one beyond.  prm->lanes_per_window (1..8) overrides the choice.
     int S = (nb < 640) ? std::max(1, std::min(4, (int)N / 4)) : 1;
-    if (const char *e = getenv("CPI_AMD_TILED_SPLIT")) S = std::max(1, std::min(8, atoi(e)));
-    const size_t lds = (size_t)(S - 1) * (prm->model == CPI_MODEL_V2 ? 34 : 16) * 64 * sizeof(double);
-    // more than 64 KB of dynamic LDS (model 2, S >= 5) needs the kernel's limit raised once per device
-#define CPI_TILED2(M, AV, C)                                                                                      \
-    do {                                                                                                          \
-        if (S > 1) {                                                                                              \
-            const unsigned bit = 1u << ((M - 1) * 4 + (AV ? 2 : 0) + (C ? 1 : 0));                                \
-            if (lds > 65536 && !(ctx->big_lds_set & bit)) {                                                       \
-                CPI_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cpi_mean_tiled_kernel<M, AV, C, true>), \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 7 * 34 * 64 * 8));   \
-                ctx->big_lds_set |= bit;                                                                          \
-            }                                                                                                     \
-            hipLaunchKernelGGL((cpi_mean_tiled_kernel<M, AV, C, true>), dim3(nb), dim3(64 * S), lds, ctx->stream, a); \
-        } else hipLaunchKernelGGL((cpi_mean_tiled_kernel<M, AV, C, false>), dim3(nb), dim3(64), 0, ctx->stream, a); \
-    } while (0)
-    if (prm->model == CPI_MODEL_V1) {
-        if (count) { if (avg) CPI_TILED2(1, true, true); else CPI_TILED2(1, false, true); }
-        else       { if (avg) CPI_TILED2(1, true, false); else CPI_TILED2(1, false, false); }
-    } else {
-        if (count) { if (avg) CPI_TILED2(2, true, true); else CPI_TILED2(2, false, true); }
-        else       { if (avg) CPI_TILED2(2, true, false); else CPI_TILED2(2, false, false); }
-    }
-#undef CPI_TILED2
+    if (prm->lanes_per_window > 0) S = prm->lanes_per_window;
+    CPI_HIP(ctx, launch::mean_tiled(prm->model, prm->imu_avg != 0, count != nullptr, S, a, ctx->stream, &ctx->big_lds_set));
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
 
-// -------------------------------------------------------------------------------- device sets
+// ============================================================================================
+// device sets
+// ============================================================================================
 // Windows shard embarrassingly: rank r of n owns the contiguous block cpi_shard_bounds(W, r, n) and runs the ordinary
 // entries on its own context; the ONE exchange step is the final gather of the output slabs to a root device.  RCCL is
-// bound lazily (dlopen of librccl.so.1 at the first cpi_group_create): single-GPU users never load it, and a process
-// that already carries an RCCL (PyTorch) shares that copy.  One process drives all devices (ncclCommInitAll,
+// bound lazily (dlopen of librccl.so.1 at the first cpi_group_create with n > 1): single-GPU users never load it, and a
+// process that already carries an RCCL (PyTorch) shares that copy.  One process drives all devices (ncclCommInitAll,
 // rccl/rccl.h:236) -- the reference is a single process too; multi-process hosts (one rank per GPU, torch.distributed)
 // use cpi_amd/dist.py, which issues the same send / recv pattern through ProcessGroupNCCL.
-#include <dlfcn.h>
-#include <mutex>
-#include <vector>
+// The function-pointer types are decltype's of the prototypes in <rccl/rccl.h> and the datatype is its ncclFloat64, so a
+// signature or enum drift is a compile error here, not a silent mismatch behind dlsym.
 namespace {
 struct Rccl {
     void *h = nullptr;
-    int (*CommInitAll)(void **, int, const int *) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
     std::mutex mu;
     bool load() {   // serialised: two host threads may create their first groups at the same time
         std::lock_guard<std::mutex> lock(mu);
         if (h) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (h) break;
+        // CPI_AMD_RCCL_LIB: an explicit library path (deployments with several ROCm installs; the test-suite points it at
+        // tests/fake_rccl).  Read here, once, at the first n > 1 group -- never on a launch path.
+        const char *forced = getenv("CPI_AMD_RCCL_LIB");
+        std::string tried;
+        if (forced && *forced) {
+            h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            tried = forced;
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h) break;
+            }
+            tried = "librccl.so.1";
         }
-        if (!h) { err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return false; }
-#define CPI_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(h, name)); if (!field) { err = std::string("dlsym ") + name; h = nullptr; return false; }
+        if (!h) {
+            const char *de = dlerror();   // dlerror() clears its state: call it ONCE
+            err = "dlopen(" + tried + "): " + (de ? de : "not found");
+            return false;
+        }
+#define CPI_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(h, name)); \
+        if (!field) { err = std::string("dlsym(") + name + "): symbol missing in " + tried; dlclose(h); h = nullptr; return false; }
         CPI_SYM(CommInitAll, "ncclCommInitAll") CPI_SYM(CommDestroy, "ncclCommDestroy") CPI_SYM(GroupStart, "ncclGroupStart")
         CPI_SYM(GroupEnd, "ncclGroupEnd") CPI_SYM(Send, "ncclSend") CPI_SYM(Recv, "ncclRecv") CPI_SYM(GetErrorString, "ncclGetErrorString")
 #undef CPI_SYM
@@ -680,15 +614,20 @@ struct Rccl {
     }
 };
 Rccl g_rccl;
-constexpr int kNcclDouble = 8;   // ncclFloat64 (rccl/rccl.h:467)
+constexpr int kMaxGroup = 16;   // ranks of one device set (a node has 8 GPUs)
 }  // namespace
 
 struct cpi_group {
     int n = 0;
     std::vector<cpi_ctx *> ctx;
     std::vector<hipStream_t> streams;   // owned
-    std::vector<void *> comms;          // ncclComm_t, empty when n == 1
+    std::vector<ncclComm_t> comms;      // empty when n == 1
     std::string err;
+    // slab path of cpi_group_gather: the peers' slabs land here on the root's device before the unpack kernel places them
+    double *staging = nullptr;
+    size_t staging_cap = 0;             // doubles
+    int staging_dev = -1;
+    int last_gather_sends = 0;          // messages per peer of the last gather (1 = slab path); cpi_group_last_gather_messages
 };
 static thread_local std::string g_group_err;
 static int gfail(cpi_group *g, int code, const std::string &msg) { if (g) g->err = msg; else g_group_err = msg; return code; }
@@ -702,6 +641,7 @@ extern "C" void cpi_shard_bounds(int64_t W, int rank, int n, int64_t *lo, int64_
 extern "C" const char *cpi_group_last_error(const cpi_group *g) { return g ? g->err.c_str() : g_group_err.c_str(); }
 extern "C" int cpi_group_size(const cpi_group *g) { return g ? g->n : 0; }
 extern "C" cpi_ctx *cpi_group_ctx(cpi_group *g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->ctx[rank] : nullptr; }
+extern "C" int cpi_group_last_gather_messages(const cpi_group *g) { return g ? g->last_gather_sends : 0; }
 extern "C" void cpi_group_destroy(cpi_group *g) {
     if (!g) return;
     int prev = -1;
@@ -714,21 +654,24 @@ extern "C" void cpi_group_destroy(cpi_group *g) {
             cpi_ctx_destroy(g->ctx[r]);
         }
     }
+    if (g->staging) { (void)hipSetDevice(g->staging_dev); (void)hipFree(g->staging); }
     if (prev >= 0) (void)hipSetDevice(prev);
     delete g;
 }
-extern "C" int cpi_group_create(int n, const int *devices, cpi_group **out) {
+static int group_create(int n, const int *devices, bool shared_device_for_tests, cpi_group **out) {
     if (!out) return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: out is NULL");
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return gfail(nullptr, CPI_ERR_NO_DEVICE, "cpi_group_create: no HIP device available (this library has no CPU fallback)");
-    if (n <= 0 || n > ndev) return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: n must be between 1 and the number of devices");
+    if (n <= 0 || n > kMaxGroup || (!shared_device_for_tests && n > ndev))
+        return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: n must be between 1 and the number of devices");
     std::vector<int> devs(n);
     for (int r = 0; r < n; r++) {
         devs[r] = devices ? devices[r] : r;
         if (devs[r] < 0 || devs[r] >= ndev) return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: device index out of range");
-        for (int q = 0; q < r; q++) if (devs[q] == devs[r]) return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: duplicate device");
+        if (!shared_device_for_tests)
+            for (int q = 0; q < r; q++) if (devs[q] == devs[r]) return gfail(nullptr, CPI_ERR_INVALID, "cpi_group_create: duplicate device");
     }
     int prev = -1;
     (void)hipGetDevice(&prev);
@@ -749,11 +692,19 @@ extern "C" int cpi_group_create(int n, const int *devices, cpi_group **out) {
     if (n > 1) {
         if (!g_rccl.load()) { const std::string m = "cpi_group_create: " + g_rccl.err; cpi_group_destroy(g); return gfail(nullptr, CPI_ERR_RCCL, m); }
         g->comms.assign(n, nullptr);
-        const int rc = g_rccl.CommInitAll(g->comms.data(), n, devs.data());
-        if (rc != 0) { const std::string m = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc); cpi_group_destroy(g); return gfail(nullptr, CPI_ERR_RCCL, m); }
+        const ncclResult_t rc = g_rccl.CommInitAll(g->comms.data(), n, devs.data());
+        if (rc != ncclSuccess) { const std::string m = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc); cpi_group_destroy(g); return gfail(nullptr, CPI_ERR_RCCL, m); }
     }
     *out = g;
     return CPI_OK;
+}
+extern "C" int cpi_group_create(int n, const int *devices, cpi_group **out) { return group_create(n, devices, false, out); }
+// include/cpi_amd_test.h: n ranks that all live on ONE device -- the n > 1 code paths of the device set on a 1-GPU box.
+// Real RCCL refuses duplicate devices in ncclCommInitAll; the test-suite binds tests/fake_rccl through CPI_AMD_RCCL_LIB.
+extern "C" int cpi_test_group_create_shared(int n, int device, cpi_group **out) {
+    if (n <= 0 || n > kMaxGroup) return gfail(nullptr, CPI_ERR_INVALID, "cpi_test_group_create_shared: n out of range");
+    std::vector<int> devs(n, device);
+    return group_create(n, devs.data(), true, out);
 }
 extern "C" int cpi_group_synchronize(cpi_group *g) {
     if (!g) return gfail(nullptr, CPI_ERR_INVALID, "group is NULL");
@@ -763,68 +714,128 @@ extern "C" int cpi_group_synchronize(cpi_group *g) {
     }
     return CPI_OK;
 }
+
+// Is rank r's local output set ONE slab -- the wanted fields back to back, field-major over wb >= cnt windows
+// (cpi_outputs_bind_slab)?  Returns its base, wb and the doubles to send (the last field only up to cnt windows).
+static bool slab_of(const cpi_outputs &loc, const cpi_outputs &want, long long cnt, const double *&base, long long &wb, size_t &len) {
+    int ks[12], nk = 0;
+    for (int k = 0; k < 12; k++) if (out_field_c(&want, k)) ks[nk++] = k;
+    if (nk == 0) return false;
+    const double *p0 = out_field_c(&loc, ks[0]);
+    if (!p0) return false;
+    wb = cnt;
+    if (nk > 1) {
+        const double *p1 = out_field_c(&loc, ks[1]);
+        if (!p1 || p1 <= p0) return false;
+        const long long d = (long long)(p1 - p0);
+        if (d % OUT_N[ks[0]] != 0) return false;
+        wb = d / OUT_N[ks[0]];
+        if (wb < cnt) return false;
+    }
+    size_t off = 0;
+    for (int i = 0; i < nk; i++) {
+        if (out_field_c(&loc, ks[i]) != p0 + off) return false;
+        if (i + 1 < nk) off += (size_t)OUT_N[ks[i]] * (size_t)wb;
+    }
+    base = p0;
+    len = off + (size_t)OUT_N[ks[nk - 1]] * (size_t)cnt;
+    return true;
+}
+
 extern "C" int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_outputs *local, const cpi_outputs *root_out) {
     if (!g) return gfail(nullptr, CPI_ERR_INVALID, "group is NULL");
     if (root < 0 || root >= g->n || W < 0 || !local || !root_out) return gfail(g, CPI_ERR_INVALID, "cpi_group_gather: invalid argument");
     int prev = -1;
     (void)hipGetDevice(&prev);
     struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore_{prev};
-    int rc = 0;
-    if (g->n > 1) { rc = g_rccl.GroupStart(); if (rc) return gfail(g, CPI_ERR_RCCL, std::string("ncclGroupStart: ") + g_rccl.GetErrorString(rc)); }
-    for (int k = 0; k < 12 && rc == 0; k++) {
-        cpi_outputs ro = *root_out;
-        double *dst = *out_field(&ro, k);
-        if (!dst) continue;
-        for (int r = 0; r < g->n && rc == 0; r++) {
-            int64_t lo, hi;
-            cpi_shard_bounds(W, r, g->n, &lo, &hi);
-            const size_t cnt = (size_t)(hi - lo) * (size_t)OUT_N[k];
-            if (cnt == 0) continue;
-            cpi_outputs lr = local[r];
-            const double *src = *out_field(&lr, k);
-            if (!src) { rc = -1; break; }
-            if (r == root) {   // the root's own block: device-to-device copy on its stream (unless it was computed in place)
-                if (src != dst + (size_t)lo * OUT_N[k]) {
-                    if (hipSetDevice(g->ctx[root]->device) != hipSuccess ||
-                        hipMemcpyAsync(dst + (size_t)lo * OUT_N[k], src, cnt * sizeof(double), hipMemcpyDeviceToDevice, g->streams[root]) != hipSuccess) rc = -2;
-                }
-            } else {           // every peer sends its slab straight to the root: one xGMI link per peer, no ring
-                rc = g_rccl.Recv(dst + (size_t)lo * OUT_N[k], cnt, kNcclDouble, r, g->comms[root], g->streams[root]);
-                if (rc == 0) rc = g_rccl.Send(src, cnt, kNcclDouble, root, g->comms[r], g->streams[r]);
+    const int n = g->n;
+    long long lo[kMaxGroup], cnt[kMaxGroup], wb[kMaxGroup];
+    const double *base[kMaxGroup];
+    size_t len[kMaxGroup], stride = 0;
+    bool any_field = false;
+    for (int k = 0; k < 12; k++) any_field = any_field || out_field_c(root_out, k);
+    if (!any_field) return CPI_OK;
+    // every wanted field must exist in every non-empty block
+    bool slabs = n > 1;
+    for (int r = 0; r < n; r++) {
+        int64_t a, b;
+        cpi_shard_bounds(W, r, n, &a, &b);
+        lo[r] = a; cnt[r] = b - a; wb[r] = 0; base[r] = nullptr; len[r] = 0;
+        if (cnt[r] == 0) continue;
+        for (int k = 0; k < 12; k++)
+            if (out_field_c(root_out, k) && !out_field_c(&local[r], k))
+                return gfail(g, CPI_ERR_INVALID, "cpi_group_gather: a field wanted at the root is NULL in a rank's local outputs");
+        if (r == root) continue;
+        if (slabs && slab_of(local[r], *root_out, cnt[r], base[r], wb[r], len[r])) stride = std::max(stride, len[r]);
+        else slabs = false;
+    }
+    hipStream_t rs = g->ctx[root]->stream;
+    // the slab path needs staging for n slabs on the root's device (grow-only; a re-allocation waits for the root's stream)
+    if (slabs && stride > 0) {
+        stride = (stride + 1) & ~(size_t)1;   // 16-byte aligned slabs
+        if (g->staging_cap < stride * (size_t)n || g->staging_dev != g->ctx[root]->device) {
+            if (g->staging) {
+                if (hipSetDevice(g->staging_dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipFree(g->staging) != hipSuccess)
+                    return gfail(g, CPI_ERR_HIP, "cpi_group_gather: releasing the staging buffer failed");
+                g->staging = nullptr; g->staging_cap = 0;
+            }
+            if (hipSetDevice(g->ctx[root]->device) != hipSuccess || hipMalloc((void **)&g->staging, stride * (size_t)n * sizeof(double)) != hipSuccess)
+                return gfail(g, CPI_ERR_HIP, "cpi_group_gather: allocating the root's staging buffer failed");
+            g->staging_cap = stride * (size_t)n; g->staging_dev = g->ctx[root]->device;
+        }
+    }
+    ncclResult_t rc = ncclSuccess;
+    int hip_bad = 0, msgs = 0;
+    if (n > 1) { rc = g_rccl.GroupStart(); if (rc != ncclSuccess) return gfail(g, CPI_ERR_RCCL, std::string("ncclGroupStart: ") + g_rccl.GetErrorString(rc)); }
+    // the root's own block: device-to-device copies on its stream (unless it was computed in place)
+    if (cnt[root] > 0) {
+        for (int k = 0; k < 12 && !hip_bad; k++) {
+            double *dst = out_field_c(root_out, k);
+            if (!dst) continue;
+            const double *src = out_field_c(&local[root], k);
+            if (src != dst + (size_t)lo[root] * OUT_N[k]) {
+                if (hipSetDevice(g->ctx[root]->device) != hipSuccess ||
+                    hipMemcpyAsync(dst + (size_t)lo[root] * OUT_N[k], src, (size_t)cnt[root] * OUT_N[k] * sizeof(double), hipMemcpyDeviceToDevice, rs) != hipSuccess) hip_bad = 1;
             }
         }
     }
-    int rce = 0;
-    if (g->n > 1) rce = g_rccl.GroupEnd();
-    if (rc == -1) return gfail(g, CPI_ERR_INVALID, "cpi_group_gather: a field wanted at the root is NULL in a rank's local outputs");
-    if (rc == -2) return gfail(g, CPI_ERR_HIP, "cpi_group_gather: device-to-device copy of the root's own block failed");
-    if (rc) return gfail(g, CPI_ERR_RCCL, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(rc));
-    if (rce) return gfail(g, CPI_ERR_RCCL, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(rce));
+    // every peer sends straight to the root: one xGMI link per peer, no ring
+    for (int r = 0; r < n && rc == ncclSuccess && !hip_bad; r++) {
+        if (r == root || cnt[r] == 0) continue;
+        if (slabs) {   // ONE message per peer: its whole slab into the root's staging area
+            rc = g_rccl.Recv(g->staging + (size_t)r * stride, len[r], ncclFloat64, r, g->comms[root], rs);
+            if (rc == ncclSuccess) rc = g_rccl.Send(base[r], len[r], ncclFloat64, root, g->comms[r], g->ctx[r]->stream);
+            msgs = 1;
+        } else {       // separately allocated fields: one message per (peer, field), received in place
+            int m = 0;
+            for (int k = 0; k < 12 && rc == ncclSuccess; k++) {
+                double *dst = out_field_c(root_out, k);
+                if (!dst) continue;
+                const size_t c = (size_t)cnt[r] * (size_t)OUT_N[k];
+                rc = g_rccl.Recv(dst + (size_t)lo[r] * OUT_N[k], c, ncclFloat64, r, g->comms[root], rs);
+                if (rc == ncclSuccess) rc = g_rccl.Send(out_field_c(&local[r], k), c, ncclFloat64, root, g->comms[r], g->ctx[r]->stream);
+                m++;
+            }
+            msgs = std::max(msgs, m);
+        }
+    }
+    ncclResult_t rce = ncclSuccess;
+    if (n > 1) rce = g_rccl.GroupEnd();
+    if (hip_bad) return gfail(g, CPI_ERR_HIP, "cpi_group_gather: device-to-device copy of the root's own block failed");
+    if (rc != ncclSuccess) return gfail(g, CPI_ERR_RCCL, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(rc));
+    if (rce != ncclSuccess) return gfail(g, CPI_ERR_RCCL, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(rce));
+    if (slabs && msgs) {   // place the staged slabs: one launch on the root's stream, behind the receives
+        long long c2[kMaxGroup];
+        for (int r = 0; r < n; r++) c2[r] = (r == root) ? 0 : cnt[r];
+        if (hipSetDevice(g->ctx[root]->device) != hipSuccess) return gfail(g, CPI_ERR_HIP, "cpi_group_gather: hipSetDevice(root) failed");
+        launch::unpack_slabs(n, lo, c2, wb, g->staging, (long long)stride, *root_out, rs);
+        if (hipGetLastError() != hipSuccess) return gfail(g, CPI_ERR_HIP, "cpi_group_gather: the unpack launch failed");
+    }
+    g->last_gather_sends = msgs;
     return CPI_OK;
 }
 
 // -------------------------------------------------------------------------------- test hook (include/cpi_amd_test.h)
-namespace {
-__global__ __launch_bounds__(64) void cpi_test_quat_ops_kernel(int op, long long n, const double *in, double *out) {
-    const long long k = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (k >= n) return;
-    auto put_rm = [&](double *o, const M3 &A) {
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) o[i * 3 + j] = A.m[i][j];
-    };
-    auto put_q = [&](double *o, Q4 q) { o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; };
-    switch (op) {
-        case 0: put_q(out + 4 * k, rot_2_quat(rec_mat(in + 9 * k, 0))); break;
-        case 1: put_rm(out + 9 * k, skew(ldv3(in + 3 * k))); break;
-        case 2: put_rm(out + 9 * k, quat_2_Rot(ldq4(in + 4 * k))); break;
-        case 3: put_q(out + 4 * k, quat_multiply(ldq4(in + 8 * k), ldq4(in + 8 * k + 4))); break;
-        case 4: put_rm(out + 9 * k, Exp_so3(ldv3(in + 3 * k))); break;
-        default: put_q(out + 4 * k, quat_inv(ldq4(in + 4 * k))); break;
-    }
-}
-}  // namespace
 extern "C" int cpi_test_quat_ops(cpi_ctx *ctx, int32_t op, int64_t n, const double *in, double *out) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (op < 0 || op > 5 || n < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_test_quat_ops: unknown op / negative size");
@@ -832,12 +843,14 @@ extern "C" int cpi_test_quat_ops(cpi_ctx *ctx, int32_t op, int64_t n, const doub
     if (!in || !out) return fail(ctx, CPI_ERR_INVALID, "cpi_test_quat_ops: NULL argument");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    hipLaunchKernelGGL(cpi_test_quat_ops_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (int)op, (long long)n, in, out);
+    launch::test_quat_ops((int)op, (long long)n, in, out, ctx->stream);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
 
-// -------------------------------------------------------------------------------- host-pointer variants
+// ============================================================================================
+// host-pointer variants
+// ============================================================================================
 namespace {
 struct DevBuf {
     void *p = nullptr;
@@ -852,9 +865,9 @@ struct DevBuf {
         }                                                                                 \
     } while (0)
 
-// Dense batches from host memory run as a three-stage pipeline over chunks of <= 65536 windows: upload of chunk i + 1
-// (copy stream), kernels of chunk i (the context's stream), download of chunk i - 1 (second copy stream) -- PCIe is full
-// duplex, so with PINNED host buffers (cpi_host_alloc, hipHostMalloc, torch pin_memory) a call costs about
+// Dense (and tiled) batches from host memory run as a three-stage pipeline over chunks of <= 65536 windows: upload of
+// chunk i + 1 (copy stream), kernels of chunk i (the context's stream), download of chunk i - 1 (second copy stream) -- PCIe
+// is full duplex, so with PINNED host buffers (cpi_host_alloc, hipHostMalloc, torch pin_memory) a call costs about
 // max(upload, download, kernels) instead of their sum; with pageable memory the copies serialise in the runtime's own
 // staging and the pipeline degenerates to the sum, minus the per-call hipMalloc / hipFree of the device staging, which
 // the context now keeps (two slots, grow-only, released by cpi_ctx_destroy).  Measured (MI355X box, 1 M x 50, everything
@@ -909,18 +922,20 @@ extern "C" void *cpi_host_alloc(size_t bytes) {
 }
 extern "C" void cpi_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
-static int preintegrate_host_dense(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *knots,
-                                   const int32_t *count, const double *lin, const double *q_k_lin, const cpi_outputs *out) {
+// tiled == false: knots[W][N+1][7];  tiled == true: tiles[ceil(W/64)][N+1][7][64] (chunks are whole tiles)
+static int preintegrate_host_pipeline(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *knots, bool tiled,
+                                      const int32_t *count, const double *lin, const double *q_k_lin, const cpi_outputs *out) {
     int rc = host_pipe_get(ctx);
     if (rc != CPI_OK) return rc;
     HostPipe *hp = ctx->pipe;
     const int64_t nch = (W + 65535) / 65536;
-    const int64_t Wc = std::min<int64_t>(W, (((W + nch - 1) / nch) + 63) / 64 * 64);   // balanced chunks, whole wavefronts
+    const int64_t Wc = std::min<int64_t>(W, (((W + nch - 1) / nch) + 63) / 64 * 64);   // balanced chunks, whole wavefronts / tiles
     const int nslots = nch > 1 ? 2 : 1;
     const size_t knot_bytes = (size_t)(N + 1) * 7 * sizeof(double);
+    auto in_bytes = [&](int64_t wn) { return tiled ? (size_t)((wn + 63) / 64) * 64 * knot_bytes : (size_t)wn * knot_bytes; };
     cpi_outputs h = *out;
     for (int s = 0; s < nslots; s++) {
-        const size_t need[4] = { (size_t)Wc * knot_bytes, count ? (size_t)Wc * sizeof(int32_t) : 0, (size_t)Wc * 6 * sizeof(double),
+        const size_t need[4] = { in_bytes(Wc), count ? (size_t)Wc * sizeof(int32_t) : 0, (size_t)Wc * 6 * sizeof(double),
                                  q_k_lin ? (size_t)Wc * 4 * sizeof(double) : 0 };
         for (int k = 0; k < 4; k++)
             if ((rc = host_pipe_reserve(ctx, hp->in[s][k], hp->in_cap[s][k], need[k])) != CPI_OK) return rc;
@@ -934,7 +949,7 @@ static int preintegrate_host_dense(cpi_ctx *ctx, const cpi_params *prm, int64_t 
         const int s = (int)(i & 1);
         const int64_t w0 = i * Wc, wn = std::min<int64_t>(Wc, W - w0);
         if (i >= 2 && !hip_ok(hipStreamWaitEvent(hp->up, hp->ev_done[s], 0), "hipStreamWaitEvent")) break;   // slot's inputs consumed
-        if (!hip_ok(hipMemcpyAsync(hp->in[s][0], knots + (size_t)w0 * (N + 1) * 7, (size_t)wn * knot_bytes, hipMemcpyHostToDevice, hp->up), "upload knots")) break;
+        if (!hip_ok(hipMemcpyAsync(hp->in[s][0], knots + (size_t)w0 * (N + 1) * 7, in_bytes(wn), hipMemcpyHostToDevice, hp->up), "upload knots")) break;
         if (count && !hip_ok(hipMemcpyAsync(hp->in[s][1], count + w0, (size_t)wn * sizeof(int32_t), hipMemcpyHostToDevice, hp->up), "upload count")) break;
         if (!hip_ok(hipMemcpyAsync(hp->in[s][2], lin + (size_t)w0 * 6, (size_t)wn * 6 * sizeof(double), hipMemcpyHostToDevice, hp->up), "upload lin")) break;
         if (q_k_lin && !hip_ok(hipMemcpyAsync(hp->in[s][3], q_k_lin + (size_t)w0 * 4, (size_t)wn * 4 * sizeof(double), hipMemcpyHostToDevice, hp->up), "upload q_k_lin")) break;
@@ -944,8 +959,12 @@ static int preintegrate_host_dense(cpi_ctx *ctx, const cpi_params *prm, int64_t 
         cpi_outputs d;
         memset(&d, 0, sizeof d);
         for (int k = 0; k < 12; k++) if (*out_field(&h, k)) *out_field(&d, k) = (double *)hp->out[s][k];
-        rc = cpi_preintegrate_batch(ctx, prm, wn, N, (const double *)hp->in[s][0], nullptr, count ? (const int32_t *)hp->in[s][1] : nullptr,
-                                    (const double *)hp->in[s][2], q_k_lin ? (const double *)hp->in[s][3] : nullptr, &d);
+        if (tiled)
+            rc = cpi_preintegrate_tiled_batch(ctx, prm, wn, N, (const double *)hp->in[s][0], count ? (const int32_t *)hp->in[s][1] : nullptr,
+                                              (const double *)hp->in[s][2], q_k_lin ? (const double *)hp->in[s][3] : nullptr, &d);
+        else
+            rc = cpi_preintegrate_batch(ctx, prm, wn, N, (const double *)hp->in[s][0], nullptr, count ? (const int32_t *)hp->in[s][1] : nullptr,
+                                        (const double *)hp->in[s][2], q_k_lin ? (const double *)hp->in[s][3] : nullptr, &d);
         if (rc != CPI_OK) break;
         if (!hip_ok(hipEventRecord(hp->ev_done[s], ctx->stream), "hipEventRecord")) break;
         if (!hip_ok(hipStreamWaitEvent(hp->down, hp->ev_done[s], 0), "hipStreamWaitEvent")) break;
@@ -956,11 +975,24 @@ static int preintegrate_host_dense(cpi_ctx *ctx, const cpi_params *prm, int64_t 
         if (!hip_ok(hipEventRecord(hp->ev_out[s], hp->down), "hipEventRecord")) break;
     }
     const hipError_t e1 = hipStreamSynchronize(hp->up), e2 = hipStreamSynchronize(ctx->stream), e3 = hipStreamSynchronize(hp->down);
-    if (rc != CPI_OK) return rc;   // message already set by cpi_preintegrate_batch
+    if (rc != CPI_OK) return rc;   // message already set by the device-pointer entry
     if (!err.empty()) return fail(ctx, CPI_ERR_HIP, "cpi_preintegrate_batch_host: " + err);
     hip_ok(e1, "hipStreamSynchronize(upload)"); hip_ok(e2, "hipStreamSynchronize"); hip_ok(e3, "hipStreamSynchronize(download)");
     if (!err.empty()) return fail(ctx, CPI_ERR_HIP, "cpi_preintegrate_batch_host: " + err);
     return CPI_OK;
+}
+
+extern "C" int cpi_preintegrate_tiled_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *tiles,
+                                                 const int32_t *count, const double *lin, const double *q_k_lin, const cpi_outputs *out) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (!prm || !out || !tiles || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch_host: NULL argument");
+    if (W <= 0) return W == 0 ? CPI_OK : fail(ctx, CPI_ERR_INVALID, "negative size");
+    if (N < 0) return fail(ctx, CPI_ERR_INVALID, "negative size");
+    if (out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b || out->P)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch_host: the tiled layout serves the mean outputs (DT, alpha, beta, q) only");
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    return preintegrate_host_pipeline(ctx, prm, W, N, tiles, true, count, lin, q_k_lin, out);
 }
 
 extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
@@ -973,7 +1005,7 @@ extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, 
     if (N < 0) return fail(ctx, CPI_ERR_INVALID, "negative size");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    if (!first) return preintegrate_host_dense(ctx, prm, W, N, knots, count, lin, q_k_lin, out);
+    if (!first) return preintegrate_host_pipeline(ctx, prm, W, N, knots, false, count, lin, q_k_lin, out);
     // ragged windows share one knot stream: staged whole (one-off calls; the stream is usually small)
     DevBuf dk, df, dc, dl, dq, dout[12];
     CPI_UP(dk, knots, (size_t)n_knots * 7 * sizeof(double));

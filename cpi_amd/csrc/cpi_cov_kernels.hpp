@@ -1,5 +1,5 @@
 // cpi_cov_kernels.hpp -- covariance (+ state transition) recursion of CPI models 1 / 2 and the Forster comparator.
-// Part of the single translation unit cpi_kernels.hip (included there, in this order; not a stand-alone header).
+// Part of the translation unit cpi_cov.hip (included there after cpi_math.hpp / cpi_device_util.hpp; not a stand-alone header).
 #pragma once
 
 namespace {
@@ -7,8 +7,6 @@ namespace {
 // ============================================================================================
 // covariance (+ state transition) kernel
 // ============================================================================================
-// Measured on MI355X: forcing two co-resident wavefronts per SIMD (<= 256 registers) costs spills and does not pay;
-// the recursion runs one wavefront per SIMD and hides LDS latency with instruction-level parallelism instead.
 // Two co-resident wavefronts per SIMD hide the LDS exchange latency of the recursion: <= 256 registers and
 // <= 20 KB of LDS per wavefront.  The latter is why a phase-A pass stages GROUP/2 intervals per window
 // (half the lanes take part in it); measured on MI355X against the one-wave-per-SIMD variant:

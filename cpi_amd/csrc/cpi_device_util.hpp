@@ -1,5 +1,5 @@
 // cpi_device_util.hpp -- device helpers shared by all kernels: loads / stores, DPP moves, wave reductions, kernel argument blocks.
-// Part of the single translation unit cpi_kernels.hip (included there, in this order; not a stand-alone header).
+// Included by every kernel translation unit after cpi_args.hpp / cpi_math.hpp (not a stand-alone header).
 #pragma once
 
 namespace {
@@ -168,21 +168,7 @@ __device__ __forceinline__ int wave_max(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-struct PreArgs {
-    long long W;
-    int N;
-    const double *knots;
-    const long long *first;
-    const int *count;
-    const double *lin;
-    const double *qk;
-    double grav[3];
-    double q4[4];      // sigma^2 of the four diagonal blocks of Q_c (CpiBase.h:54-57)
-    int write_means;   // kernel writes DT/alpha/beta/q
-    int write_jac;     // kernel writes the Jacobians it owns
-    int dbg;           // development switches of the experimental kernels (0 in every shipped path)
-    cpi_outputs out;
-};
+// (PreArgs: cpi_args.hpp)
 
 
 }  // namespace

@@ -1,5 +1,5 @@
 // cpi_factor_kernels.hpp -- evaluateError sweeps (dense, packed, whitened, Hessian blocks), square-root information, state prediction.
-// Part of the single translation unit cpi_kernels.hip (included there, in this order; not a stand-alone header).
+// Part of the translation unit cpi_factor.hip (included there after cpi_math.hpp / cpi_device_util.hpp; not a stand-alone header).
 #pragma once
 
 namespace {
@@ -7,21 +7,7 @@ namespace {
 // ============================================================================================
 // factor kernels
 // ============================================================================================
-struct FactorArgs {
-    long long F;
-    double grav[3];
-    cpi_outputs meas;
-    const double *lin;
-    const double *qk;
-    const double *states;
-    long long S;               // number of states: indices are clamped into [0, S) (no out-of-bounds read whatever idx holds)
-    const int *idx_i;
-    const int *idx_j;
-    double *err;
-    double *H1;
-    double *H2;
-    const double *sqrt_info;   // optional [F][225] upper-triangular R: outputs are whitened (R err, R H1, R H2)
-};
+// (FactorArgs, PredictArgs: cpi_args.hpp)
 
 __device__ __forceinline__ NavState ld_state(const double *p) {
     NavState s;
@@ -482,15 +468,6 @@ __global__ __launch_bounds__(64, 1) void cpi_factor_hessian_kernel(FactorArgs A,
     for (int i = lane; i < nf * (HESS_PACKED / 2); i += 64) { d2u v; v.a = sP[2 * i]; v.b = sP[2 * i + 1]; dst[i] = v; }
 }
 
-struct PredictArgs {
-    long long F;
-    double grav[3];
-    cpi_outputs meas;
-    const double *states_i;
-    long long S;
-    const int *idx_i;
-    double *states_j;
-};
 template <int MODEL>
 __global__ __launch_bounds__(256) void cpi_predict_kernel(PredictArgs A) {
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;

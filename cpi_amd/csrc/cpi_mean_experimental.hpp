@@ -1,5 +1,5 @@
 // cpi_mean_experimental.hpp -- measurement-only mean kernels (LDS-DMA ring, block-resident linear fetch): DESIGN.md 3.1, never the default path.
-// Part of the single translation unit cpi_kernels.hip (included there, in this order; not a stand-alone header).
+// Part of the translation unit cpi_mean.hip (CPI_EXPERIMENTS builds only) (included there after cpi_math.hpp / cpi_device_util.hpp; not a stand-alone header).
 #pragma once
 
 namespace {

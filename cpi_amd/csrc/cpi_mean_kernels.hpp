@@ -1,5 +1,5 @@
 // cpi_mean_kernels.hpp -- the mean (+ analytic Jacobian) recursion: cpi_mean_kernel (dense / ragged layouts) and cpi_mean_tiled_kernel (tiled layout).
-// Part of the single translation unit cpi_kernels.hip (included there, in this order; not a stand-alone header).
+// Part of the translation unit cpi_mean.hip (included there after cpi_math.hpp / cpi_device_util.hpp; not a stand-alone header).
 #pragma once
 
 namespace {
@@ -230,18 +230,7 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
 // fetched once, no LDS, no staging, ~100 registers (4 wavefronts per SIMD) -- the layout the recursion wants on this
 // memory system, for producers that can write it (a batch assembler that places knot s of window w at its tile slot instead of
 // at w (N+1) + s costs nothing extra).  Knots are prefetched three steps ahead in registers.
-struct TiledArgs {
-    long long W;
-    int N;
-    const double *tiles;
-    const int *count;
-    const double *lin;
-    const double *qk;
-    double grav[3];
-    cpi_outputs out;
-    int dbg;   // measurement only (CPI_AMD_BLK_MODE): 1 = fetch without arithmetic
-    long long ts, ss;   // doubles between consecutive tiles / consecutive steps of a tile
-};
+// (TiledArgs: cpi_args.hpp)
 #ifndef CPI_TILED_OCC
 #define CPI_TILED_OCC (MODEL == 2 ? 2 : 3)
 #endif
@@ -379,6 +368,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 64, SPLIT ? 1 : CPI_TILED_OCC) void c
         p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
     }
 }
+#ifdef CPI_EXPERIMENTS
 // measurement only (CPI_AMD_BLK_MODE=1): the tiled stream alone -- the same loads, one add per value
 __global__ __launch_bounds__(64, 3) void cpi_tiled_fetch_probe_kernel(TiledArgs A) {
     const int lane = threadIdx.x;
@@ -399,8 +389,12 @@ __global__ __launch_bounds__(64, 3) void cpi_tiled_fetch_probe_kernel(TiledArgs 
     }
     if (w < A.W && A.out.DT) A.out.DT[w] = acc;
 }
-// dense knots[W][N+1][7] -> tiles[ceil(W/64)][N+1][7][64] (windows past W replicate window W - 1: finite padding)
-__global__ __launch_bounds__(256) void cpi_tile_knots_kernel(long long W, int N, const double *knots, double *tiles, long long ts, long long ss) {
+#endif
+// knots[W][N+1][7] (first == NULL) or a shared stream indexed by first[W] / count[W] (the ragged layout of
+// cpi_preintegrate_batch) -> tiles[ceil(W/64)][N+1][7][64].  Rows past a window's last knot repeat that knot and columns
+// past W repeat window W - 1: finite padding the kernels never integrate.
+__global__ __launch_bounds__(256) void cpi_tile_knots_kernel(long long W, int N, const double *knots, const long long *first,
+                                                             const int *count, double *tiles, long long ts, long long ss) {
     const long long total = ((W + 63) / 64) * (long long)(N + 1) * 448;
     for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long long)gridDim.x * 256) {
         const int i = (int)(o & 63);
@@ -410,7 +404,67 @@ __global__ __launch_bounds__(256) void cpi_tile_knots_kernel(long long W, int N,
         const int sidx = (int)(bs % (N + 1));
         const long long b = bs / (N + 1);
         const long long w = min(b * 64 + i, W - 1);
-        tiles[b * ts + sidx * ss + f * 64 + i] = knots[(w * (N + 1) + sidx) * 7 + f];
+        const long long k0 = first ? first[w] : w * (long long)(N + 1);
+        const int n = count ? min(max(count[w], 0), N) : N;
+        tiles[b * ts + sidx * ss + f * 64 + i] = knots[(k0 + min(sidx, n)) * 7 + f];
+    }
+}
+
+// Window assembly on the device, straight into the tiled layout (cpi_assemble_tiles): ONE IMU stream cut at successive
+// update times with the semantics of GraphSolver::createimufactor_cpi_v1/v2 (GraphSolver_IMU.cpp:50-69) -- whole
+// intervals while imu_times[1] <= updatetime, then the partial tail interval with the front reading repeated, after which
+// the front stamp is overwritten by the update time.  The reference walks a deque, i.e. window u starts where window
+// u - 1 stopped; for a stream whose stamps are non-decreasing (and update times likewise) that state is a pure function of
+// the previous update time, so every window is independent here:
+//     front(T)  = max(#{knots with t <= T} - 1, 0)          (the deque's front index after the window ending at T)
+//     stamp(T)  = max(T, t_0)                               (the front stamp after that window)
+// One wavefront per tile, one lane per window; a row of the tile is seven coalesced 512-byte stores.
+__device__ __forceinline__ long long knots_not_after(const double *stream, long long K, double T) {
+    long long lo = 0, hi = K;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (stream[mid * 7] <= T) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) {
+    const int lane = threadIdx.x;
+    const long long u = (long long)blockIdx.x * 64 + lane;
+    const bool valid = u < A.U;
+    const long long uc = valid ? u : A.U - 1;
+    const double t0 = A.stream[0];
+    const double T = A.update[uc];
+    long long fp = 0;
+    double start_t = t0;
+    if (uc > 0) {
+        const double Tp = A.update[uc - 1];
+        fp = max(knots_not_after(A.stream, A.K, Tp) - 1, 0ll);
+        start_t = fmax(Tp, t0);
+    }
+    const long long fu = max(max(knots_not_after(A.stream, A.K, T) - 1, 0ll), fp);
+    const int m = (int)min(fu - fp, (long long)0x3fffffff);          // whole intervals
+    const double front_t = (m > 0) ? A.stream[fu * 7] : start_t;
+    const bool tail = (T - front_t) > 0;
+    const int cnt = m + (tail ? 1 : 0);
+    if (valid) A.count[u] = cnt;                                      // the TRUE count: a caller can check max(count) <= N
+    const int rows = min(cnt, A.N);                                   // rows 0 .. rows exist in the tile
+    const int rmax = __builtin_amdgcn_readfirstlane(wave_max(rows));
+    double *tb = A.tiles + (long long)blockIdx.x * A.ts + lane;
+    for (int r = 0; r <= rmax; ++r) {
+        // row r of this window: r == 0 the front reading under the window's start stamp; 1 .. m stream knots; m + 1 the tail
+        const int rr = min(r, rows);
+        const bool is_tail = tail && rr == m + 1;
+        const long long src = fp + min(rr, m);
+        const double *kp = A.stream + src * 7;
+        double v[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) v[k] = kp[k];
+        if (rr == 0) v[0] = start_t;
+        if (is_tail) v[0] = T;
+        if (r <= rows) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) tb[(long long)r * A.ss + k * 64] = v[k];
+        }
     }
 }
 

@@ -33,7 +33,9 @@ extern "C" {
 #endif
 
 #define CPI_ABI_VERSION 2   /* 2: state count S in the factor / predict entries; device-set entries (cpi_group_*);
-                               additions within 2 (new symbols only): tiled layout entries, cpi_host_alloc / _free */
+                               additions within 2 (new symbols only): tiled layout entries, cpi_host_alloc / _free;
+                               round 3: cpi_tile_windows, cpi_assemble_tiles, cpi_preintegrate_tiled_batch_host,
+                               cpi_outputs_slab_doubles / _bind_slab, cpi_group_last_gather_messages */
 
 enum { CPI_OK = 0, CPI_ERR_INVALID = 1, CPI_ERR_HIP = 2, CPI_ERR_NO_DEVICE = 3, CPI_ERR_RCCL = 4 };
 enum {
@@ -62,7 +64,8 @@ typedef struct {
     int32_t imu_avg;                     /* 0 / 1 */
     int32_t state_transition_jacobians;  /* model 2 only; reference default 1 */
     int32_t lanes_per_window;            /* mean kernel: 0 = auto, else 1,2,3,4,5,6,8,12,16,32,64 (tuning knob;
-                                            ignored by the covariance kernel and by model 2 with analytic Jacobians) */
+                                            ignored by the covariance kernel and by model 2 with analytic Jacobians).
+                                            cpi_preintegrate_tiled_batch reads it as WAVEFRONTS PER TILE: 0 = auto, else 1..8 */
 } cpi_params;
 
 /* Replaces: the public result members of CpiBase / CpiV2 (CpiBase.h:99-124, CpiV2.h:62-63).
@@ -124,16 +127,38 @@ int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32
  *     tiles[ceil(W/64)][N+1][7][64]      tiles[b][s][k][i] = field k of {t, w[3], a[3]} of knot s of window 64 b + i,
  * so that a wavefront (one tile, one lane per window) reads every step as seven coalesced 512-byte rows: one linear
  * stream per wavefront, no staging -- the mean-only recursion is HBM-bound and this is the layout it wants on MI355X
- * (DESIGN.md 3.1).  For producers that can write it: a batch assembler places knot s of window w at its tile slot
- * instead of at w (N+1) + s; small batches (< 640 tiles) split a tile's steps over four wavefronts, same results to
- * rounding; cpi_tile_knots converts a dense array on the device (a full extra pass -- for tests and
- * one-off use).  Columns past W inside the last tile are never written back (cpi_tile_knots fills them with window
- * W - 1).  count as in cpi_preintegrate_batch: a lane never reads its column past row count[w], whatever lies there
- * (unwritten memory, NaN) is harmless; rows of the tile array past the largest count must still be ALLOCATED as the
- * shape says.  Skipped intervals (dt <= 0, NaN dt) inside a window need finite readings, as above.  Any Jacobian / covariance
- * pointer in out -> CPI_ERR_INVALID (those kernels are FP64-bound: the layout would buy nothing). */
+ * (DESIGN.md 3.1a).  Small batches (< 640 tiles) split a tile's steps over four wavefronts, same results to rounding
+ * (prm->lanes_per_window = 1..8 pins the number of wavefronts per tile).
+ * Columns past W inside the last tile are never written back.  count as in cpi_preintegrate_batch: a lane never reads
+ * its column past row count[w], whatever lies there (unwritten memory, NaN) is harmless; rows of the tile array past the
+ * largest count must still be ALLOCATED as the shape says.  Skipped intervals (dt <= 0, NaN dt) inside a window need
+ * finite readings, as above.  Any Jacobian / covariance pointer in out -> CPI_ERR_INVALID (those kernels are FP64-bound:
+ * the layout would buy nothing).
+ *
+ * PRODUCERS of the layout -- a caller never needs a dense copy first:
+ *   cpi_assemble_tiles    cuts ONE IMU stream (device memory) into windows at successive update times and writes them
+ *                         straight into tiles + count: the loop of GraphSolver::createimufactor_cpi_v1/v2
+ *                         (GraphSolver_IMU.cpp:50-69 -- whole intervals while imu_times[1] <= updatetime, then the partial
+ *                         tail interval with the front reading repeated, the front stamp overwritten by the update time)
+ *                         for every window at once.  stream [K][7] knot records with NON-DECREASING stamps, update_times
+ *                         [U] non-decreasing (then the deque state at the start of a window depends on the previous update
+ *                         time alone; a stream with backward stamps needs the host assembler).  count[u] receives the TRUE
+ *                         number of intervals of window u; rows beyond N are not written -- a caller sizes N >= max count
+ *                         (the kernels clamp count to N).
+ *   cpi_tile_windows      re-tiles windows the caller already holds in the layouts of cpi_preintegrate_batch (dense
+ *                         knots[W][N+1][7] with first == NULL, or a shared stream indexed by first[W] / count[W]); rows
+ *                         past a window's last knot repeat that knot.  A full extra pass: for one-off use and tests.
+ *                         cpi_tile_knots is the dense special case (first = count = NULL).
+ *   host side             cpi_amd/csrc/cpi_host.hpp (assemble_windows_tiled, CpiBatch::flush_means) and
+ *                         cpi_amd/stream.py (assemble_windows(..., layout="tiled")) write knot s of window w at
+ *                         (((w / 64) (N+1) + s) 7 + k) 64 + w % 64 while they assemble; cpi_preintegrate_tiled_batch_host
+ *                         takes such tiles from HOST memory through the chunked upload / kernel / download pipeline. */
 int cpi_preintegrate_tiled_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *tiles,
                                  const int32_t *count, const double *lin, const double *q_k_lin, const cpi_outputs *out);
+int cpi_assemble_tiles(cpi_ctx *ctx, int64_t K, const double *stream /*[K][7]*/, int64_t U, const double *update_times /*[U]*/,
+                       int32_t N, double *tiles /*[ceil(U/64)][N+1][7][64]*/, int32_t *count /*[U]*/);
+int cpi_tile_windows(cpi_ctx *ctx, int64_t W, int32_t N, const double *knots, const int64_t *first, const int32_t *count,
+                     double *tiles);
 int cpi_tile_knots(cpi_ctx *ctx, int64_t W, int32_t N, const double *knots /*[W][N+1][7]*/, double *tiles);
 
 /* Replaces: ImuFactorCPIv1::evaluateError / ImuFactorCPIv2::evaluateError, one call per factor
@@ -215,7 +240,8 @@ int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t
  * ncclGroupStart / End, rccl/rccl.h:700-722,923-933 -- each peer has its own xGMI link to the root, so a direct gather
  * is link-parallel where a ring would be per-link bound), the root's own block is a device-to-device copy.
  * cpi_group_create makes one context + one non-blocking HIP stream per device and, for n > 1, one RCCL communicator per
- * device (ncclCommInitAll, rccl.h:236; librccl.so.1 is bound at that moment, never before).  devices NULL = 0 .. n-1.
+ * device (ncclCommInitAll, rccl.h:236; librccl.so.1 -- or the path in the environment variable CPI_AMD_RCCL_LIB, read at
+ * that moment only -- is bound then, never before; failure to bind it is CPI_ERR_RCCL).  devices NULL = 0 .. n-1.
  * All calls are asynchronous on the group's streams; cpi_group_synchronize waits for every device.
  * Multi-process hosts (one rank per GPU) use torch.distributed instead: cpi_amd/dist.py issues the same pattern. */
 typedef struct cpi_group cpi_group;
@@ -227,8 +253,17 @@ const char *cpi_group_last_error(const cpi_group *g);           /* g may be NULL
 void cpi_shard_bounds(int64_t W, int rank, int n, int64_t *lo, int64_t *hi);
 /* local[r] = the outputs of rank r's block (device pointers on device r, hi - lo windows each); root_out = arrays of W
  * windows on the root's device: rank r's block lands at window offset lo.  Every field that is non-NULL in root_out
- * must be non-NULL in every non-empty local[r].  local[root] may already point into root_out (no copy then). */
+ * must be non-NULL in every non-empty local[r].  local[root] may already point into root_out (no copy then).
+ * When every peer's outputs are ONE SLAB (the wanted fields back to back, field-major over Wb >= hi - lo windows: what
+ * cpi_outputs_bind_slab lays out) the exchange is ONE message per peer into a staging area on the root + one unpack
+ * launch there; separately allocated fields cost one message per (peer, field), received in place.
+ * cpi_group_last_gather_messages: messages per peer of the last gather (1 = slab path). */
 int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_outputs *local, const cpi_outputs *root_out);
+int cpi_group_last_gather_messages(const cpi_group *g);
+/* Slab layout of an output set: the fields that are non-NULL in `mask`, back to back in the order of cpi_outputs, each over
+ * Wb windows.  _slab_doubles: size of the slab; _bind_slab: *bound = mask's fields pointing into slab (others NULL). */
+size_t cpi_outputs_slab_doubles(const cpi_outputs *mask, int64_t Wb);
+int cpi_outputs_bind_slab(const cpi_outputs *mask, int64_t Wb, double *slab, cpi_outputs *bound);
 int cpi_group_synchronize(cpi_group *g);
 
 /* For host-side callers (the CpiV1-shaped C++ facade in cpi_amd/csrc/cpi_host.hpp): same as cpi_preintegrate_batch
@@ -242,6 +277,10 @@ int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, 
                                 const double *knots, const int64_t *first, const int32_t *count,
                                 int64_t n_knots, const double *lin, const double *q_k_lin,
                                 const cpi_outputs *out);
+/* The tiled layout from HOST memory (tiles written by a host-side assembler), mean outputs only: same pipeline, chunks of
+ * 1024 tiles. */
+int cpi_preintegrate_tiled_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *tiles,
+                                      const int32_t *count, const double *lin, const double *q_k_lin, const cpi_outputs *out);
 /* page-locked host memory for the entries above (hipHostMalloc / hipHostFree); NULL when the allocation fails */
 void *cpi_host_alloc(size_t bytes);
 void cpi_host_free(void *p);

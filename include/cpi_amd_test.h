@@ -24,6 +24,11 @@ extern "C" {
  * Returns CPI_OK / CPI_ERR_INVALID (unknown op, NULL pointer) / CPI_ERR_HIP. */
 int cpi_test_quat_ops(cpi_ctx *ctx, int32_t op, int64_t n, const double *in, double *out);
 
+/* A device set of n ranks that all live on ONE device: runs the n > 1 code paths of cpi_group_* (ncclCommInitAll, the
+ * grouped send / recv gather, the slab unpack) on a 1-GPU box.  Real RCCL refuses duplicate devices, so the tests bind
+ * tests/fake_rccl (CPI_AMD_RCCL_LIB), whose ncclSend / ncclRecv are stream-ordered device copies.  n <= 16. */
+int cpi_test_group_create_shared(int n, int device, cpi_group **out);
+
 #ifdef __cplusplus
 }
 #endif

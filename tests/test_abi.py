@@ -62,22 +62,36 @@ def test_product_never_imports_oracle():
                     assert "oracle_py" not in txt and "liboracle" not in txt and "cpi_oracle" not in txt, f
 
 
-def test_build_id_covers_every_source_of_the_translation_unit():
-    """cpi_build_id() ties measurement records to the library: every file the translation unit includes from the repository
-    must be in the hash (cpi_amd/build.py DEPS + the test header), or an edit could leave stale counters looking valid."""
-    import os
-    import re
+def test_build_id_covers_every_source_of_every_translation_unit():
+    """cpi_build_id() ties measurement records to the library: every file a translation unit includes from the repository
+    must be in that unit's dependency list (cpi_amd/build.py UNITS -- it keys the object cache AND feeds the hash), or an
+    edit could leave a stale object / stale counters looking valid."""
     from cpi_amd import build
-    root = os.path.dirname(build.SRC)
-    hashed = {os.path.realpath(p) for p in build.DEPS} | {os.path.realpath(os.path.join(os.path.dirname(build.HERE), "include", "cpi_amd_test.h"))}
-    seen, todo = set(), [build.SRC]
-    while todo:
-        f = todo.pop()
-        if f in seen:
-            continue
-        seen.add(f)
-        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(f).read(), flags=re.M):
-            path = os.path.realpath(os.path.join(os.path.dirname(f), inc))
-            assert os.path.exists(path), (f, inc)
-            todo.append(path)
-    assert {os.path.realpath(p) for p in seen} <= hashed, sorted({os.path.realpath(p) for p in seen} - hashed)
+    hashed = {os.path.realpath(build._path(d)) for d in build._sources(experiments=True)}
+    for unit, deps in build.UNITS.items():
+        listed = {os.path.realpath(build._path(d)) for d in deps + build.EXP_EXTRA.get(unit, [])}
+        seen, todo = set(), [os.path.join(build.CSRC, unit + ".hip")]
+        while todo:
+            f = os.path.realpath(todo.pop())
+            if f in seen:
+                continue
+            seen.add(f)
+            for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(f).read(), flags=re.M):
+                path = os.path.realpath(os.path.join(os.path.dirname(f), inc))
+                assert os.path.exists(path), (f, inc)
+                todo.append(path)
+        assert seen <= listed, (unit, sorted(seen - listed))
+        assert seen <= hashed
+
+
+def test_default_library_reads_no_environment_switches():
+    """The measurement switches of tools/exp/ exist only in a -DCPI_EXPERIMENTS build: the default library's launch paths
+    read no environment variable (the one getenv left is CPI_AMD_RCCL_LIB, at the first n > 1 device set)."""
+    from cpi_amd import build
+    src = open(os.path.join(build.CSRC, "cpi_abi.hip")).read()
+    default = re.sub(r"#ifdef CPI_EXPERIMENTS.*?#endif", "", src, flags=re.S)
+    assert re.findall(r'getenv\("([A-Z_]+)"\)', default) == ["CPI_AMD_RCCL_LIB"]
+    for unit in ("cpi_mean", "cpi_cov", "cpi_factor"):
+        assert "getenv" not in open(os.path.join(build.CSRC, unit + ".hip")).read()
+    rows = open(build.REPORT).read()
+    assert "cpi_mean_dma_kernel" not in rows and "cpi_mean_blk_kernel" not in rows and "probe" not in rows

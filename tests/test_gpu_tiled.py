@@ -52,11 +52,10 @@ def test_tiled_layout_vs_reference_golden(eng, golden_dir, mode):
 
 
 @pytest.mark.parametrize("split", [1, 2, 5, 8])
-def test_tiled_split_over_wavefronts(eng, split, monkeypatch):
+def test_tiled_split_over_wavefronts(eng, split):
     """Small batches split a tile's steps over several wavefronts of one workgroup (segments composed in order by the
     first one); the library picks the split itself -- here it is forced, for both models, with counts and imu_avg."""
     from oracle import oracle_py as op
-    monkeypatch.setenv("CPI_AMD_TILED_SPLIT", str(split))
     W, N = 200, 37
     kn, lin, q = synth.make_windows(W, N, seed=99 + split, device=eng.device)
     g = torch.Generator(device="cpu"); g.manual_seed(split)
@@ -68,11 +67,11 @@ def test_tiled_split_over_wavefronts(eng, split, monkeypatch):
     for model in (1, 2):
         for avg in (0, 1):
             ref = lib.run(op.make_params(model, avg, 1), knh, linh, qh, nthreads=8)
-            out = _host(eng.preintegrate_tiled(tiles, W, lin, q, eng.make_params(model, imu_avg=bool(avg))))
+            out = _host(eng.preintegrate_tiled(tiles, W, lin, q, eng.make_params(model, imu_avg=bool(avg), lanes_per_window=split)))
             check_pre(out, ref, what=("mean",), regression=op.reference() is not None)
         rows = [lib.run(op.make_params(model, 0, 1), knh[w:w + 1, :int(cnt[w]) + 1], linh[w:w + 1], qh[w:w + 1]) for w in range(W)]
         ref = {k: np.concatenate([r[k] for r in rows], axis=0) for k in ("DT", "alpha", "beta", "q")}
-        out = _host(eng.preintegrate_tiled(tiles, W, lin, q, eng.make_params(model), count=cnt.to(eng.device)))
+        out = _host(eng.preintegrate_tiled(tiles, W, lin, q, eng.make_params(model, lanes_per_window=split), count=cnt.to(eng.device)))
         check_pre(out, ref, what=("mean",), regression=op.reference() is not None)
 
 

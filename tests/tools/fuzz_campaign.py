@@ -58,13 +58,10 @@ def main():
                 # ... and, for models 1 / 2, the mean outputs through the tiled layout with a random split over wavefronts
                 if model < 3:
                     split = int(rng.choice([0, 1, 2, 3, 4, 5, 8]))
-                    if split:
-                        os.environ["CPI_AMD_TILED_SPLIT"] = str(split)
-                    else:
-                        os.environ.pop("CPI_AMD_TILED_SPLIT", None)
                     tiles = eng.tile_knots(dev(kn, eng))
-                    tout = host(eng.preintegrate_tiled(tiles, W, dev(lin, eng), dev(q, eng), prm))
-                    os.environ.pop("CPI_AMD_TILED_SPLIT", None)
+                    tprm = eng.make_params(model, imu_avg=bool(prm.imu_avg), state_transition_jacobians=bool(prm.state_transition_jacobians),
+                                           lanes_per_window=split)   # tiled entry: wavefronts per tile
+                    tout = host(eng.preintegrate_tiled(tiles, W, dev(lin, eng), dev(q, eng), tprm))
                     check_pre(tout, ref, what=("mean",), v2=(model == 2), label=label + " tiled split %d" % split)
             else:
                 lens = rng.integers(0, N + 1, W).astype(np.int32)

@@ -1,6 +1,8 @@
 #!/bin/bash
 # GPU experiment: block-resident mean kernel (CPI_AMD_MEAN_BLK=L) -- correctness vs the oracle, then launch times.
 cd ${GRAFT_REPO_ROOT:-.}
+# the measurement switches below exist only in the -DCPI_EXPERIMENTS build (python -m cpi_amd.build --experiments)
+export CPI_AMD_LIB=$PWD/cpi_amd/libcpi_amd_exp.so
 mkdir -p gpurun_out
 OUT=gpurun_out/exp_blk.txt
 : > $OUT

@@ -1,5 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
+# the measurement switches below exist only in the -DCPI_EXPERIMENTS build (python -m cpi_amd.build --experiments)
+export CPI_AMD_LIB=$PWD/cpi_amd/libcpi_amd_exp.so
 OUT=gpurun_out/exp_dma3.txt; mkdir -p gpurun_out; : > $OUT
 for rep in 1 2; do
 for cfg in off 4,2,0 4,2,1; do

@@ -1,5 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
+# the measurement switches below exist only in the -DCPI_EXPERIMENTS build (python -m cpi_amd.build --experiments)
+export CPI_AMD_LIB=$PWD/cpi_amd/libcpi_amd_exp.so
 OUT=gpurun_out/exp_dma4.txt; mkdir -p gpurun_out; : > $OUT
 for cfg in off 4,1,0 4,1,1 6,1,0 6,2,0 4,2,0; do
   echo "=== cfg $cfg" >> $OUT

@@ -1,6 +1,8 @@
 #!/bin/bash
 # GPU experiment: LDS-DMA mean kernel variants -- correctness vs the oracle, then launch times (run through gpurun).
 cd ${GRAFT_REPO_ROOT:-.}
+# the measurement switches below exist only in the -DCPI_EXPERIMENTS build (python -m cpi_amd.build --experiments)
+export CPI_AMD_LIB=$PWD/cpi_amd/libcpi_amd_exp.so
 mkdir -p gpurun_out
 OUT=gpurun_out/exp_dma.txt
 : > $OUT

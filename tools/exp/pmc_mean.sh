@@ -1,6 +1,8 @@
 #!/bin/bash
 # HBM traffic of the three mean-kernel designs at 1 M x 50 (calibration: the block-resident kernel reads every byte once, linearly)
 cd ${GRAFT_REPO_ROOT:-.}
+# the measurement switches below exist only in the -DCPI_EXPERIMENTS build (python -m cpi_amd.build --experiments)
+export CPI_AMD_LIB=$PWD/cpi_amd/libcpi_amd_exp.so
 R=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
