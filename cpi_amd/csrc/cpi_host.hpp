@@ -50,15 +50,18 @@ public:
     explicit DeviceGroup(int n, const int *devices = nullptr) {
         if (cpi_group_create(n, devices, &g_) != CPI_OK) throw std::runtime_error(cpi_group_last_error(nullptr));
     }
+    explicit DeviceGroup(cpi_group *adopt) : g_(adopt) { if (!g_) throw std::runtime_error("DeviceGroup: null group"); }   // takes ownership
     ~DeviceGroup() { cpi_group_destroy(g_); }
     DeviceGroup(const DeviceGroup &) = delete;
     DeviceGroup &operator=(const DeviceGroup &) = delete;
+    DeviceGroup(DeviceGroup &&o) noexcept : g_(o.g_) { o.g_ = nullptr; }
     int size() const { return cpi_group_size(g_); }
     cpi_ctx *ctx(int rank) const { return cpi_group_ctx(g_, rank); }
     void bounds(int64_t W, int rank, int64_t &lo, int64_t &hi) const { cpi_shard_bounds(W, rank, size(), &lo, &hi); }
     void check(int rc) const { if (rc != CPI_OK) throw std::runtime_error(cpi_group_last_error(g_)); }
     void gather(int root, int64_t W, const cpi_outputs *local, const cpi_outputs &root_out) { check(cpi_group_gather(g_, root, W, local, &root_out)); }
     void synchronize() { check(cpi_group_synchronize(g_)); }
+    int last_gather_messages() const { return cpi_group_last_gather_messages(g_); }   // per peer; 1 = slab path
 private:
     cpi_group *g_ = nullptr;
 };
@@ -244,6 +247,43 @@ public:
         }
         win_.clear();
     }
+    // Mean outputs only (DT, alpha_tau, beta_tau, q_k2tau): the HBM-bound request.  The recorded windows are written
+    // straight into the TILED layout (include/cpi_amd.h: tiles[ceil(W/64)][N+1][7][64], knot s of window w at
+    // (((w / 64) (N+1) + s) 7 + k) 64 + w % 64 -- no dense copy is ever made) with their own interval counts, and go
+    // through cpi_preintegrate_tiled_batch_host (chunked upload / kernel / download pipeline).  Models 1 and 2.
+    void flush_means(const Context &ctx) {
+        if (win_.empty()) return;
+        const int64_t W = (int64_t)win_.size();
+        std::vector<int32_t> count(W);
+        int32_t N = 0;
+        for (int64_t w = 0; w < W; w++) {
+            const std::vector<double> &k = win_[w]->knots();
+            count[w] = k.empty() ? 0 : (int32_t)(k.size() / 7 - 1);
+            if (count[w] > N) N = count[w];
+        }
+        const int64_t nb = (W + 63) / 64;
+        std::vector<double> tiles((size_t)nb * (N + 1) * 448, 0.0), lin(W * 6), qk(W * 4);
+        for (int64_t w = 0; w < W; w++) {
+            const std::vector<double> &k = win_[w]->knots();
+            double *col = &tiles[(size_t)(w / 64) * (N + 1) * 448 + (size_t)(w % 64)];
+            for (int32_t s = 0; s <= count[w] && !k.empty(); s++)
+                for (int f = 0; f < 7; f++) col[((size_t)s * 7 + f) * 64] = k[(size_t)s * 7 + f];
+            for (int i = 0; i < 3; i++) { lin[w * 6 + i] = win_[w]->b_w_lin[i]; lin[w * 6 + 3 + i] = win_[w]->b_a_lin[i]; }
+            for (int i = 0; i < 4; i++) qk[w * 4 + i] = win_[w]->q_k_lin[i];
+        }
+        cpi_params p = win_[0]->params();
+        std::vector<double> DT(W), al(W * 3), be(W * 3), q(W * 4);
+        cpi_outputs o{};
+        o.DT = DT.data(); o.alpha = al.data(); o.beta = be.data(); o.q = q.data();
+        ctx.check(cpi_preintegrate_tiled_batch_host(ctx.get(), &p, W, N, tiles.data(), count.data(), lin.data(), qk.data(), &o));
+        for (int64_t w = 0; w < W; w++) {
+            CpiResult &r = *win_[w];
+            r.DT = DT[w];
+            for (int i = 0; i < 3; i++) { r.alpha_tau[i] = al[w * 3 + i]; r.beta_tau[i] = be[w * 3 + i]; }
+            for (int i = 0; i < 4; i++) r.q_k2tau[i] = q[w * 4 + i];
+        }
+        win_.clear();
+    }
 private:
     std::vector<CpiBase *> win_;
 };
@@ -310,6 +350,48 @@ inline WindowSet assemble_windows(const std::vector<double> &stream, const std::
         if (n > ws.max_count) ws.max_count = n;
     }
     return ws;
+}
+
+// The same cutting written STRAIGHT into the tiled layout of cpi_preintegrate_tiled_batch (mean-only requests; DESIGN.md
+// 3.1a): pass 1 walks the deque loop and records where each window starts and how long it is, pass 2 places knot s of
+// window w at its tile slot.  No intermediate knots / first / count copy.  N = the largest count (or min_N if larger).
+struct TiledWindowSet {
+    std::vector<double> tiles;     // [ceil(W/64)][N+1][7][64]
+    std::vector<int32_t> count;    // [W]
+    int64_t W = 0;
+    int32_t N = 0;
+};
+inline TiledWindowSet assemble_windows_tiled(const std::vector<double> &stream, const std::vector<double> &update_times, int32_t min_N = 0) {
+    TiledWindowSet ts;
+    const size_t K = stream.size() / 7;
+    if (K == 0) return ts;
+    struct Win { size_t front0; double start_t; int32_t whole; bool tail; double T; };
+    std::vector<Win> win;
+    win.reserve(update_times.size());
+    size_t front = 0;
+    double front_t = stream[0];
+    int32_t N = min_N;
+    for (double T : update_times) {
+        Win w{front, front_t, 0, false, T};
+        while (K - front > 1 && stream[(front + 1) * 7] <= T) { front++; front_t = stream[front * 7]; w.whole++; }
+        if (T - front_t > 0) { w.tail = true; front_t = T; }
+        win.push_back(w);
+        const int32_t n = w.whole + (w.tail ? 1 : 0);
+        ts.count.push_back(n);
+        if (n > N) N = n;
+    }
+    ts.W = (int64_t)win.size();
+    ts.N = N;
+    const size_t nb = (size_t)((ts.W + 63) / 64), tstride = (size_t)(N + 1) * 448;
+    ts.tiles.assign(nb * tstride, 0.0);
+    for (size_t w = 0; w < win.size(); w++) {
+        double *col = &ts.tiles[(w / 64) * tstride + (w % 64)];
+        auto put = [&](int32_t s, double t, const double *r) { col[((size_t)s * 7) * 64] = t; for (int f = 1; f < 7; f++) col[((size_t)s * 7 + f) * 64] = r[f]; };
+        put(0, win[w].start_t, &stream[win[w].front0 * 7]);
+        for (int32_t s = 1; s <= win[w].whole; s++) put(s, stream[(win[w].front0 + s) * 7], &stream[(win[w].front0 + s) * 7]);
+        if (win[w].tail) put(win[w].whole + 1, win[w].T, &stream[(win[w].front0 + win[w].whole) * 7]);
+    }
+    return ts;
 }
 
 // evaluateError-shaped evaluator (ImuFactorCPIv1.h:139 / ImuFactorCPIv2.h:151).  state = 16 doubles

@@ -170,6 +170,66 @@ class Engine:
         self._check(self.lib.cpi_tile_knots(self.ctx, W, n1 - 1, _ptr(knots), _ptr(tiles)))
         return tiles
 
+    def tile_windows(self, knots, first, count, N):
+        """a shared knot stream [K, 7] indexed by first[W] (int64) / count[W] (int32) -> tiles [ceil(W/64), N+1, 7, 64] on the
+        device (cpi_tile_windows).  A full extra pass: one-off use and tests."""
+        W = first.shape[0]
+        tiles = torch.empty(((W + 63) // 64, N + 1, 7, 64), dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.cpi_tile_windows(self.ctx, W, N, _ptr(knots), _ptr(first), _ptr(count), _ptr(tiles)))
+        return tiles
+
+    def assemble_tiles(self, stream, update_times, N, tiles=None, count=None):
+        """Window assembly ON THE DEVICE, straight into the tiled layout (cpi_assemble_tiles; GraphSolver_IMU.cpp:50-69 for
+        every window at once): stream [K, 7] with non-decreasing stamps, update_times [U] non-decreasing, both CUDA float64.
+        Returns (tiles [ceil(U/64), N+1, 7, 64], count [U] int32 = the TRUE interval counts: check count.max() <= N)."""
+        K, U = stream.shape[0], update_times.shape[0]
+        assert stream.is_cuda and stream.is_contiguous() and update_times.is_cuda and update_times.is_contiguous()
+        if tiles is None:
+            tiles = torch.empty(((U + 63) // 64, N + 1, 7, 64), dtype=torch.float64, device=self.device)
+        if count is None:
+            count = torch.empty((U,), dtype=torch.int32, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.cpi_assemble_tiles(self.ctx, K, _ptr(stream), U, _ptr(update_times), N, _ptr(tiles), _ptr(count)))
+        return tiles, count
+
+    def preintegrate_stream(self, stream, update_times, lin, q_k_lin=None, params=None, want=("mean",), N=None):
+        """One IMU stream cut at update times and preintegrated (the caller-side loop of GraphSolver_IMU.cpp:43-75 for all
+        windows at once; stream / update_times CUDA tensors, stamps non-decreasing).  Mean-only requests -- the HBM-bound
+        case -- go through the device assembler and the tiled kernel; requests with Jacobians / covariance (FP64-bound) cut
+        the windows on the host (cpi_amd.stream.assemble_windows) and use the ragged layout of cpi_preintegrate_batch."""
+        params = params or self.make_params()
+        if tuple(want) == ("mean",) and params.model in (1, 2):
+            if N is None:
+                # a safe bound without a pass over the data: no window holds more whole intervals than the stream has knots
+                raise ValueError("preintegrate_stream(mean-only): give N, an upper bound of the intervals per window")
+            tiles, count = self.assemble_tiles(stream, update_times, N)
+            if int(count.max().item()) > N:
+                raise ValueError("preintegrate_stream: a window has %d intervals, more than N = %d" % (int(count.max().item()), N))
+            return self.preintegrate_tiled(tiles, update_times.shape[0], lin, q_k_lin, params, count=count)
+        from .stream import assemble_windows
+        kn, first, count = assemble_windows(stream.cpu().numpy(), update_times.cpu().numpy())
+        dev = self.device
+        return self.preintegrate(torch.from_numpy(kn).to(dev), lin, q_k_lin, params, want=want, first=torch.from_numpy(first).to(dev),
+                                 count=torch.from_numpy(count).to(dev), N=int(count.max()) if len(count) else 0)
+
+    def preintegrate_tiled_host(self, tiles, W, lin, q_k_lin=None, params=None, count=None, pinned=True, out=None):
+        """Mean outputs from tiles held in HOST memory (cpi_preintegrate_tiled_batch_host: chunked upload / kernel /
+        download pipeline).  CPU float64 tensors; returns CPU tensors; synchronous."""
+        params = params or self.make_params()
+        N = tiles.shape[1] - 1
+        for t in (tiles, lin, q_k_lin, count):
+            assert t is None or (not t.is_cuda and t.is_contiguous()), "inputs must be contiguous CPU tensors"
+        assert tiles.shape[0] == (W + 63) // 64 and tiles.shape[2:] == (7, 64)
+        if out is None:
+            out = {name: torch.empty((W,) if n == 1 else (W, n), dtype=torch.float64, pin_memory=pinned)
+                   for name, n in OUT_FIELDS if name in MEAN_FIELDS}
+        o = self._outputs_struct(out)
+        self._sync_stream()
+        self._check(self.lib.cpi_preintegrate_tiled_batch_host(self.ctx, C.byref(params), W, N, _ptr(tiles), _ptr(count), _ptr(lin),
+                                                               _ptr(q_k_lin), C.byref(o)))
+        return out
+
     def preintegrate_tiled(self, tiles, W, lin, q_k_lin=None, params=None, count=None, out=None, bind=False):
         """Mean outputs from the tiled layout (include/cpi_amd.h: cpi_preintegrate_tiled_batch).  bind=True: returns
         (call, out) with the foreign call pre-bound, like bind_preintegrate."""

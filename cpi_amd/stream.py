@@ -10,9 +10,36 @@
                      repeated, after which the front stamp is overwritten by the update time.
 
 Both produce the knot layout of include/cpi_amd.h (knots[K][7] + first[W] + count[W]), ready for
-cpi_preintegrate_batch.  The C++ twin lives in cpi_amd/csrc/cpi_host.hpp.
+cpi_preintegrate_batch -- or, with layout="tiled", the TILED layout of cpi_preintegrate_tiled_batch
+(tiles[ceil(W/64)][N+1][7][64] + count[W]): the mean-only recursion is HBM-bound and that is the layout it streams
+fastest; tile_windows() converts windows a caller already holds.  The C++ twin lives in
+cpi_amd/csrc/cpi_host.hpp; the device-side assembler is cpi_assemble_tiles (Engine.assemble_tiles).
 """
 import numpy as np
+
+
+def tile_windows(knots, first=None, count=None, N=None):
+    """knots [W,N+1,7] (dense) or a shared stream [K,7] with first[W] / count[W]  ->  tiles [ceil(W/64), N+1, 7, 64]:
+    tiles[b, s, k, i] = field k of knot s of window 64 b + i.  Rows past a window's last knot repeat that knot, columns
+    past W repeat window W - 1 (finite padding the kernels never integrate).  Mirrors cpi_tile_windows."""
+    knots = np.asarray(knots, dtype=np.float64)
+    if first is None:
+        W, n1, _ = knots.shape
+        N = n1 - 1 if N is None else N
+        flat = knots.reshape(-1, 7)
+        first = np.arange(W, dtype=np.int64) * n1
+        count = np.full(W, n1 - 1, dtype=np.int64) if count is None else np.asarray(count, dtype=np.int64)
+    else:
+        flat = knots.reshape(-1, 7)
+        first = np.asarray(first, dtype=np.int64)
+        count = np.asarray(count, dtype=np.int64)
+        W = first.shape[0]
+        N = int(count.max()) if N is None else N
+    nb = (W + 63) // 64
+    w = np.minimum(np.arange(nb * 64), W - 1)
+    rows = first[w][:, None] + np.minimum(np.arange(N + 1)[None, :], np.clip(count[w], 0, N)[:, None])   # [nb*64, N+1]
+    g = flat[rows]                                                                                        # [nb*64, N+1, 7]
+    return np.ascontiguousarray(g.reshape(nb, 64, N + 1, 7).transpose(0, 2, 3, 1))
 
 
 def parse_imu_text(text):
@@ -27,10 +54,11 @@ def parse_imu_text(text):
     return np.asarray(rows, dtype=np.float64).reshape(-1, 7)
 
 
-def assemble_windows(stream, update_times):
+def assemble_windows(stream, update_times, layout="csr", N=None):
     """stream [K,7], update_times [U] (non-decreasing) -> (knots [M,7], first [U] int64, count [U] int32).
     Window u covers (previous update time, update_times[u]]; its first knot carries the reading that was at
-    the front of the reference's deque when the window started."""
+    the front of the reference's deque when the window started.
+    layout="tiled": -> (tiles [ceil(U/64), N+1, 7, 64], count [U] int32) with N = the largest count (or the given N)."""
     stream = np.asarray(stream, dtype=np.float64)
     K = stream.shape[0]
     out, first, count = [], [], []
@@ -50,5 +78,9 @@ def assemble_windows(stream, update_times):
             front_t = T
             n += 1
         count.append(n)
-    return (np.asarray(out, dtype=np.float64).reshape(-1, 7), np.asarray(first, dtype=np.int64),
-            np.asarray(count, dtype=np.int32))
+    knots, first, count = (np.asarray(out, dtype=np.float64).reshape(-1, 7), np.asarray(first, dtype=np.int64),
+                           np.asarray(count, dtype=np.int32))
+    if layout == "tiled":
+        return tile_windows(knots, first, count, N), count
+    assert layout == "csr", layout
+    return knots, first, count

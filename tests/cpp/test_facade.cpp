@@ -69,6 +69,21 @@ int main(int argc, char **argv) {
         printf("ERR");
         for (double v : err) printf(" %.17g", v);
         printf("\n");
+        // mean-only flush (models 1 / 2): the recorded windows go straight into the tiled layout with their own interval
+        // counts (skipped dt < 0 intervals make the golden windows differ in length)
+        if (model != 3) {
+            CpiBatch means;
+            for (int w = 0; w < W; w++) { wins[w]->DT = -1; means.add(wins[w]); }
+            means.flush_means(ctx);
+            for (int w = 0; w < W; w++) {
+                const CpiBase &c = *wins[w];
+                printf("MEAN %.17g", c.DT);
+                for (double v : c.alpha_tau) printf(" %.17g", v);
+                for (double v : c.beta_tau) printf(" %.17g", v);
+                for (double v : c.q_k2tau) printf(" %.17g", v);
+                printf("\n");
+            }
+        }
     } catch (const std::exception &e) {
         fprintf(stderr, "cpi_host error: %s\n", e.what());
         return 1;

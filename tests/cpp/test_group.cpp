@@ -9,7 +9,10 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
+
 #include "../../cpi_amd/csrc/cpi_host.hpp"
+#include "../../include/cpi_amd_test.h"
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
@@ -30,7 +33,10 @@ int main(int argc, char **argv) {
     HIP_OK(hipGetDeviceCount(&ndev));
     const int n = argc > 3 ? std::atoi(argv[3]) : ndev;
 
-    cpi_host::DeviceGroup grp(n);
+    const bool shared = argc > 4 && std::strcmp(argv[4], "shared") == 0;
+    cpi_group *raw = nullptr;
+    if (shared && cpi_test_group_create_shared(n, 0, &raw) != CPI_OK) { std::fprintf(stderr, "%s\n", cpi_group_last_error(nullptr)); return 4; }
+    cpi_host::DeviceGroup grp = shared ? cpi_host::DeviceGroup(raw) : cpi_host::DeviceGroup(n);
     cpi_params prm{};
     prm.sigma_w = 0.005; prm.sigma_wb = 4e-6; prm.sigma_a = 0.01; prm.sigma_ab = 2e-4;
     prm.grav[2] = 9.8; prm.model = model; prm.state_transition_jacobians = 1;
@@ -45,8 +51,8 @@ int main(int argc, char **argv) {
         grp.bounds(W, r, lo, hi);
         const int64_t w = hi - lo;
         int dev = -1;
-        // the group's contexts own devices 0 .. n-1 here (devices == nullptr)
-        dev = r;
+        // the group's contexts own devices 0 .. n-1 here (devices == nullptr); "shared": all on device 0
+        dev = shared ? 0 : r;
         HIP_OK(hipSetDevice(dev));
         double *dk = nullptr, *dl = nullptr, *dq = nullptr, *out[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
         if (w > 0) {
@@ -54,10 +60,15 @@ int main(int argc, char **argv) {
             HIP_OK(hipMemcpy(dk, kn.data() + (size_t)lo * (N + 1) * 7, (size_t)w * (N + 1) * 56, hipMemcpyHostToDevice));
             HIP_OK(hipMemcpy(dl, lin.data() + (size_t)lo * 6, (size_t)w * 48, hipMemcpyHostToDevice));
             HIP_OK(hipMemcpy(dq, qk.data() + (size_t)lo * 4, (size_t)w * 32, hipMemcpyHostToDevice));
-            for (int k = 0; k < 5; k++) HIP_OK(hipMalloc((void **)&out[k], (size_t)w * FN[k] * 8));
         }
         cpi_outputs o{};
-        o.DT = out[0]; o.alpha = out[1]; o.beta = out[2]; o.q = out[3]; o.P = out[4];
+        if (w > 0) {   // one slab for the five wanted fields (mask: any non-NULL pointer marks a field as wanted)
+            double dummy = 0;
+            cpi_outputs mask{};
+            mask.DT = mask.alpha = mask.beta = mask.q = mask.P = &dummy;
+            HIP_OK(hipMalloc((void **)&out[0], cpi_outputs_slab_doubles(&mask, w) * 8));
+            if (cpi_outputs_bind_slab(&mask, w, out[0], &o) != CPI_OK) return 5;
+        }
         local[r] = o;
         owned[r] = { dk, dl, dq, out[0], out[1], out[2], out[3], out[4] };
         if (r == root_rank) {
@@ -86,6 +97,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 225; i++) std::printf(" %.17g", P[(size_t)w * 225 + i]);
         std::printf("\n");
     }
-    std::fprintf(stderr, "group of %d device(s), %lld windows gathered on rank %d\n", n, (long long)W, root_rank);
+    std::fprintf(stderr, "group of %d %s, %lld windows gathered on rank %d, %d message(s) per peer\n", n, shared ? "rank(s) on one device" : "device(s)",
+                 (long long)W, root_rank, grp.last_gather_messages());
     return 0;
 }

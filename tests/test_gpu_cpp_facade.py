@@ -49,6 +49,11 @@ def test_cpp_facade_vs_golden(exe, golden_dir, model):
     check_pre(out, ref, v2=(model == 2), label="c++ facade m%d" % model)
     err = np.array([float(x) for x in lines[W].split()[1:]])
     assert err.shape == (15,) and np.abs(err[3:6]).max() == 0 and np.abs(err[9:12]).max() == 0
+    # CpiBatch::flush_means: the same windows written straight into the tiled layout, mean outputs only
+    mrows = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[W + 1:W + 1 + W]])
+    assert mrows.shape == (W, 11) and all(ln.startswith("MEAN") for ln in lines[W + 1:W + 1 + W])
+    means = {"DT": mrows[:, 0], "alpha": mrows[:, 1:4], "beta": mrows[:, 4:7], "q": mrows[:, 7:11]}
+    check_pre(means, ref, what=("mean",), v2=(model == 2), regression=True, label="c++ flush_means m%d" % model)
 
 
 def test_cpp_forster_facade_vs_restatement(exe, golden_dir):

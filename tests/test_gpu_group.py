@@ -1,14 +1,47 @@
-"""Device-set entries of the C-ABI (cpi_group_*, include/cpi_amd.h): on the 1-GPU test box only a set of ONE device can
-be exercised -- block partition, per-rank contexts / streams, the root's own block landing at its offset through the
-gather entry; n > the number of devices is refused.  (RCCL is not even loaded for n = 1.)  The n > 1 exchange pattern is
-covered on CPU by tests/test_dist_gloo.py through the torch.distributed twin of the same code."""
+"""Device-set entries of the C-ABI (cpi_group_*, include/cpi_amd.h).  The test box has ONE GPU, so:
+  * a set of one device runs natively (block partition, per-rank contexts / streams, the root's own block landing at its
+    offset; RCCL is not even loaded for n = 1; n > the number of devices is refused);
+  * the n > 1 code -- ncclCommInitAll, the grouped send / recv gather, the one-slab-per-peer path with its unpack launch,
+    short and empty trailing ranks -- runs with 2..16 ranks that SHARE the device (include/cpi_amd_test.h:
+    cpi_test_group_create_shared) over tests/fake_rccl, a stand-in whose ncclSend / ncclRecv are stream-ordered device
+    copies, and must reproduce the unsharded call bit for bit (tests/tools/group_check.py, own process);
+  * a librccl that cannot be bound is CPI_ERR_RCCL with a readable message, not a crash.
+The torch.distributed twin of the exchange is covered on CPU by tests/test_dist_gloo.py."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_n_rank_device_sets_on_one_device_reproduce_the_unsharded_call_bitwise():
+    from tests import fake_rccl_py
+    env = dict(os.environ, CPI_AMD_RCCL_LIB=fake_rccl_py.lib_path())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "group_check.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and "group_check ok" in p.stdout, p.stdout[-3000:]
+
+
+def test_unloadable_rccl_is_an_error_code_not_a_crash():
+    """the dlopen failure path appended a NULL dlerror() to a std::string.  Own process: the binding is made
+    once per process."""
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from cpi_amd import _lib\nlib = _lib.load()\ng = C.c_void_p()\n"
+            "rc = lib.cpi_test_group_create_shared(2, 0, C.byref(g))\n"
+            "msg = lib.cpi_group_last_error(None).decode()\n"
+            "assert rc == _lib.CPI_ERR_RCCL and not g, rc\n"
+            "assert 'dlopen(/nonexistent/librccl.so.1)' in msg and len(msg) > 40, msg\n"
+            "rc = lib.cpi_test_group_create_shared(2, 0, C.byref(g))\n"       # and again: the failed state is not sticky garbage
+            "assert rc == _lib.CPI_ERR_RCCL\nprint('rccl-load ok:', msg)\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CPI_AMD_RCCL_LIB="/nonexistent/librccl.so.1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "rccl-load ok" in p.stdout, p.stdout[-2000:]
 
 
 def test_shard_bounds_match_the_python_partition():
@@ -141,6 +174,14 @@ def test_cpp_host_sharding_a_batch_over_the_device_set(golden_dir):
         ref = {k[len(key):]: v for k, v in d.items() if k.startswith(key)}
         check_pre(got, ref, what=("mean", "cov"), regression=True)
         assert "gathered on rank 0" in p.stderr
+        # the same binary with 5 ranks sharing the device over the RCCL stand-in: 48 windows -> blocks of 10, 10, 10, 10, 8,
+        # one slab message per peer, identical output text (same kernels on the same windows)
+        from tests import fake_rccl_py
+        p5 = subprocess.run([exe, path, str(model), "5", "shared"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                            env=dict(os.environ, CPI_AMD_RCCL_LIB=fake_rccl_py.lib_path()))
+        assert p5.returncode == 0, p5.stderr
+        assert "group of 5 rank(s) on one device" in p5.stderr and "1 message(s) per peer" in p5.stderr, p5.stderr
+        assert p5.stdout == p.stdout
 
 
 def test_cpp_host_threads_one_context_each(golden_dir):

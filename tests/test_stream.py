@@ -79,6 +79,115 @@ def test_cpp_twins_match_python():
     assert np.array_equal(fc[:, 0], first) and np.array_equal(fc[:, 1], count)
     kk = np.array([[float(x) for x in ln.split()] for ln in out[1 + U:] if ln.strip()])
     assert np.array_equal(kk, knots)
+    # the tiled twin: written straight into tiles[ceil(U/64)][N+1][7][64]; every slot a kernel may read is the CSR knot
+    out = subprocess.run([exe, DATA, upath, "tiled"], stdout=subprocess.PIPE, text=True, check=True).stdout.split("\n")
+    Wt, Nt = (int(x) for x in out[0].split())
+    assert Wt == U and Nt == count.max()
+    assert np.array_equal(np.array([int(x) for x in out[1:1 + U]]), count)
+    tiles = np.array([[float(x) for x in ln.split()] for ln in out[1 + U:] if ln.strip()]).reshape((U + 63) // 64, Nt + 1, 7, 64)
+    for u in range(U):
+        assert np.array_equal(tiles[u // 64, :count[u] + 1, :, u % 64], knots[first[u]:first[u] + count[u] + 1]), u
+
+
+def test_tiled_assembly_places_every_knot_at_its_tile_slot():
+    """cpi_amd.stream: assemble_windows(layout="tiled") / tile_windows against the CSR assembly (which the test above pins to
+    the reference's deque loop), on the reference's own IMU excerpt and on the dense layout."""
+    kn = st.parse_imu_text(open(DATA).read())
+    ut = _updates(kn)
+    knots, first, count = st.assemble_windows(kn, ut)
+    tiles, c2 = st.assemble_windows(kn, ut, layout="tiled")
+    U, N = len(ut), int(count.max())
+    assert np.array_equal(c2, count) and tiles.shape == ((U + 63) // 64, N + 1, 7, 64)
+    for u in range(U):
+        assert np.array_equal(tiles[u // 64, :count[u] + 1, :, u % 64], knots[first[u]:first[u] + count[u] + 1])
+        assert np.array_equal(tiles[u // 64, count[u]:, :, u % 64], np.repeat(knots[first[u] + count[u]][None], N + 1 - count[u], 0))   # finite padding
+    assert np.all(np.isfinite(tiles))
+    dense = np.arange(131 * 10 * 7, dtype=np.float64).reshape(131, 10, 7)
+    t = st.tile_windows(dense)
+    assert t.shape == (3, 10, 7, 64)
+    for w in (0, 63, 64, 130):
+        assert np.array_equal(t[w // 64, :, :, w % 64], dense[w])
+    assert np.array_equal(t[2, :, :, 63], dense[130])                      # columns past W repeat window W - 1
+
+
+def test_device_assembler_closed_form_equals_the_deque_loop():
+    """cpi_assemble_tiles cuts every window independently: for non-decreasing stamps the deque state at the start of a window
+    is a function of the previous update time alone -- front(T) = max(#{t <= T} - 1, 0), stamp(T) = max(T, t_0)
+    (cpi_mean_kernels.hpp).  That closed form, restated in numpy, against the sequential loop: repeated stamps (dt = 0),
+    update times on / off / before / after the IMU grid, repeated update times, streams of one knot."""
+    def closed_form(s, T):
+        t = s[:, 0]
+        rows, cnt = [], []
+        for u in range(len(T)):
+            fp, start = (max(np.searchsorted(t, T[u - 1], side="right") - 1, 0), max(T[u - 1], t[0])) if u else (0, t[0])
+            fu = max(np.searchsorted(t, T[u], side="right") - 1, 0, fp)
+            m = fu - fp
+            front_t = t[fu] if m > 0 else start
+            tail = (T[u] - front_t) > 0
+            r = [np.concatenate([[start], s[fp, 1:]])] + [s[fp + i] for i in range(1, m + 1)]
+            if tail:
+                r.append(np.concatenate([[T[u]], s[fu, 1:]]))
+            rows.append(np.array(r)); cnt.append(m + int(tail))
+        return rows, np.array(cnt)
+    rng = np.random.default_rng(1)
+    for trial in range(200):
+        K = int(rng.integers(1, 60))
+        t = np.cumsum(rng.choice([0.0, 0.005, 0.005, 0.01], K)) + 1.0
+        s = np.concatenate([t[:, None], rng.normal(size=(K, 6))], 1)
+        T = np.sort(rng.choice(np.concatenate([t, t + 0.0025, [t[0] - 0.1, t[-1] + 0.1]]), int(rng.integers(1, 20))))
+        knots, first, count = st.assemble_windows(s, T)
+        rows, c = closed_form(s, T)
+        assert np.array_equal(c, count), trial
+        for u in range(len(T)):
+            assert np.array_equal(rows[u], knots[first[u]:first[u] + count[u] + 1]), (trial, u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [(1, 0, 1), (2, 0, 1), (1, 1, 1)])
+def test_gpu_stream_through_the_tiled_producers_vs_deque_oracle(mode):
+    """The mean-only path a caller shaped like GraphSolver_IMU.cpp:43-75 takes: ONE IMU stream + update times ->
+    cpi_assemble_tiles on the device (no dense / CSR copy, no cpi_tile_knots pass) -> cpi_preintegrate_tiled_batch, against
+    the oracle's literal deque-loop restatement; the device assembler's tiles and counts equal the host assembler's
+    (Python and, through cpi_tile_windows, the CSR layout) slot for slot."""
+    import torch
+    import cpi_amd
+    eng = cpi_amd.Engine()
+    kn = st.parse_imu_text(open(DATA).read())
+    ut = _updates(kn)
+    ut = np.sort(np.concatenate([ut, [kn[0, 0] - 1.0, ut[7], kn[-1, 0] + 0.5]]))     # + before the stream, repeated, past its end
+    knots, first, count = st.assemble_windows(kn, ut)
+    tiles_h, _ = st.assemble_windows(kn, ut, layout="tiled")
+    U, N = len(ut), int(count.max())
+    rng = np.random.default_rng(1)
+    lin = np.concatenate([0.01 * rng.standard_normal((U, 3)), 0.05 * rng.standard_normal((U, 3))], axis=1)
+    q = rng.standard_normal((U, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); q[q[:, 3] < 0] *= -1
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    tiles_d, count_d = eng.assemble_tiles(T(kn), T(ut), N + 2)          # N larger than needed: rows past count stay unwritten
+    tiles_c = eng.tile_windows(T(knots), T(first), T(count), N + 2)
+    torch.cuda.synchronize()
+    assert np.array_equal(count_d.cpu().numpy(), count)
+    td, tc = tiles_d.cpu().numpy(), tiles_c.cpu().numpy()
+    for u in range(U):
+        assert np.array_equal(td[u // 64, :count[u] + 1, :, u % 64], knots[first[u]:first[u] + count[u] + 1]), u
+        assert np.array_equal(tc[u // 64, :count[u] + 1, :, u % 64], tiles_h[u // 64, :count[u] + 1, :, u % 64]), u
+    prm = eng.make_params(*mode)
+    ref = op.oracle().stream(op.make_params(*mode), kn, ut, lin, q)
+    for tiles in (tiles_d, tiles_c, T(tiles_h)):
+        out = eng.preintegrate_tiled(tiles, U, T(lin), T(q), prm, count=T(count))
+        torch.cuda.synchronize()
+        check_pre({k: v.cpu().numpy() for k, v in out.items()}, ref, what=("mean",), v2=(mode[0] == 2), label="tiled stream %s" % (mode,))
+    out = eng.preintegrate_stream(T(kn), T(ut), T(lin), T(q), prm, want=("mean",), N=N)
+    torch.cuda.synchronize()
+    check_pre({k: v.cpu().numpy() for k, v in out.items()}, ref, what=("mean",), v2=(mode[0] == 2))
+    with pytest.raises(ValueError):
+        eng.preintegrate_stream(T(kn), T(ut), T(lin), T(q), prm, want=("mean",), N=N - 1)   # a window does not fit: said, not truncated
+    full = eng.preintegrate_stream(T(kn), T(ut), T(lin), T(q), prm, want=("mean", "jac", "cov"))
+    torch.cuda.synchronize()
+    check_pre({k: v.cpu().numpy() for k, v in full.items()}, ref, v2=(mode[0] == 2))
+    # the same tiles from HOST memory through the chunked pipeline
+    hout = eng.preintegrate_tiled_host(torch.from_numpy(tiles_h), U, torch.from_numpy(lin), torch.from_numpy(q), prm,
+                                       count=torch.from_numpy(count))
+    check_pre({k: v.numpy() for k, v in hout.items()}, ref, what=("mean",), v2=(mode[0] == 2))
 
 
 @pytest.mark.gpu
