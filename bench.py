@@ -6,20 +6,31 @@
 A "step" is one pass of the hot path (one cpi_preintegrate_batch / cpi_factor_eval_batch call) over one batch of
 synthetic windows already resident in HBM.  The default workload is BASELINE.json configs[1]: 10 000 windows x 50
 samples, CPI model 1, mean-only.  Successive steps walk a pool of distinct batches larger than the 256 MiB Infinity
-Cache, so the inputs really stream from HBM.  Prints ONE JSON line (rank 0).
+Cache, so the inputs really stream from HBM.  The K timed steps are replayed as ONE HIP graph (K kernel nodes, captured
+from the same calls; `config.launch_mode` says which mode ran -- eager launches are the fall-back).  Prints ONE JSON line
+(rank 0).
 
 N > 1: one rank per GPU over RCCL.  Launched either by the driver (`python -m torch.distributed.run ... bench.py --gpus N`,
 WORLD_SIZE set) or by itself: with WORLD_SIZE unset `python bench.py --gpus N` re-executes under torch.distributed.run.
 Windows shard with no data-path collective ("weak": every rank runs the per-GPU workload; "strong": the workload's
-windows are split N ways); the one exchange step is the final gather of the last step's output slabs TO RANK 0
-(cpi_amd.dist.gather_to_root: each peer sends straight to the root over its own xGMI link), inside the timed region.
-The rate without the gather is reported beside it.  `--workload cfg5_mean | cfg5_full` is BASELINE configs[4]:
+windows are split N ways); the one exchange step is the gather of the output slabs TO RANK 0 (cpi_amd.dist.gather_to_root:
+each peer sends ONE packed slab straight to the root over its own xGMI link).  Two schedules (`config.gather_schedule`):
+  final      the K steps, then the gather of the last step's slabs (small batches: the headline).  The clock of a rank stops
+             when ITS part is done -- the root's when every slab has arrived -- and the line reports the MAX over ranks; the
+             closing barrier is outside the timed region.
+  pipelined  every step's slab is gathered, on a side stream, while the next step computes (double-buffered outputs and
+             receive buffers): the schedule for steps that last milliseconds (`--scaling strong`, cfg5_*).
+`kernel_ms` (HIP events around the K steps), `gather_ms` (the exposed tail after the last kernel) and the rate without any
+exchange (`value_without_gather`) are reported beside `value`.  `--workload cfg5_mean | cfg5_full` is BASELINE configs[4]:
 1 M windows x 100 samples per GPU, generated on the device.
 
-Every measured row (the headline and each `extra` row) carries its own `roofline` and `cpu_baseline` objects.
+Every measured row (the headline and each `extra` row, incl. the SURVEY 8(f) rows: square-root information, whitened
+evaluateError, Hessian blocks, state prediction, and the tiled layout fed by the device assembler) carries its own
+`roofline` and `cpu_baseline` objects.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import sys
@@ -33,28 +44,45 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernels are VALU / LDS-bound
 MALL_BYTES = 256 << 20
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
-# name -> model, outputs, default units per step, samples, algorithmic HBM bytes per unit at 50 samples (SURVEY.md 8(d):
-# read + write, f64, compulsory traffic only), dominant kernel
+# name -> kind, model, default units per step, samples, algorithmic HBM bytes per unit at 50 samples (SURVEY.md 8(d):
+# read + write, f64, compulsory traffic only), dominant kernel.  kinds: "pre" preintegration (dense layout), "tiled" the
+# mean-only recursion on the tiled layout (batches cut from ONE stream by cpi_assemble_tiles), "factor" the dense
+# evaluateError sweep and its variants, "sqrt_info", "predict".
+IN1, IN2 = 776, 952             # bytes a factor reads: measurement + lin (+ q_k_lin, O_a, O_b) + two states
 WORKLOADS = {
-    "v1_mean": dict(model=1, want=("mean",), W=10000, N=50, bytes=2856 + 88, kernel="cpi_mean_kernel<1,false,false,L>"),
-    "v2_mean": dict(model=2, want=("mean",), W=10000, N=50, bytes=2888 + 88, kernel="cpi_mean_kernel<2,false,false,L>"),
-    "v1_full": dict(model=1, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2856 + 2320, kernel="cpi_cov_kernel<1,false>"),
-    "v2_full": dict(model=2, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2888 + 2392, kernel="cpi_cov_kernel<2,false>"),
+    "v1_mean": dict(kind="pre", model=1, want=("mean",), W=10000, N=50, bytes=2856 + 88, kernel="cpi_mean_kernel<1,false,false,L>"),
+    "v2_mean": dict(kind="pre", model=2, want=("mean",), W=10000, N=50, bytes=2888 + 88, kernel="cpi_mean_kernel<2,false,false,L>"),
+    "v1_full": dict(kind="pre", model=1, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2856 + 2320, kernel="cpi_cov_kernel<1,false>",
+                    useful_lanes=(15, 16)),
+    "v2_full": dict(kind="pre", model=2, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2888 + 2392, kernel="cpi_cov_kernel<2,false>",
+                    useful_lanes=(27, 32)),
     # Forster / GTSAM comparator (CPI_MODEL_FORSTER): same I/O as model 1 full
-    "forster_full": dict(model=3, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2856 + 2320, kernel="cpi_forster_kernel"),
-    "factor_v1": dict(model=1, factor=True, W=1000000, N=50, bytes=776 + 3720, kernel="cpi_factor_kernel<1,false,8>"),
-    "factor_v2": dict(model=2, factor=True, W=1000000, N=50, bytes=952 + 3720, kernel="cpi_factor_kernel<2,false,8>"),
+    "forster_full": dict(kind="pre", model=3, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2856 + 2320, kernel="cpi_forster_kernel",
+                         useful_lanes=(15, 16)),
+    "factor_v1": dict(kind="factor", model=1, W=1000000, N=50, bytes=IN1 + 3720, kernel="cpi_factor_kernel<1,false,8>"),
+    "factor_v2": dict(kind="factor", model=2, W=1000000, N=50, bytes=IN2 + 3720, kernel="cpi_factor_kernel<2,false,8>"),
     # packed evaluateError (state-dependent blocks only, include/cpi_amd.h): NOT the dense GTSAM-shaped output
-    "factor_v1_packed": dict(model=1, factor=True, packed=True, W=1000000, N=50, bytes=776 + 576, kernel="cpi_factor_packed_kernel<1,L>"),
-    "factor_v2_packed": dict(model=2, factor=True, packed=True, W=1000000, N=50, bytes=952 + 576, kernel="cpi_factor_packed_kernel<2,L>"),
-    # the same mean-only recursion on the TILED input layout (knots of 64 windows interleaved per step; include/cpi_amd.h)
-    "v1_mean_tiled": dict(model=1, want=("mean",), W=1000000, N=50, bytes=2856 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<1,false,false,SPLIT>"),
-    "v2_mean_tiled": dict(model=2, want=("mean",), W=1000000, N=50, bytes=2888 + 88, tiled=True, kernel="cpi_mean_tiled_kernel<2,false,false,SPLIT>"),
+    "factor_v1_packed": dict(kind="factor", variant="packed", model=1, W=1000000, N=50, bytes=IN1 + 576, kernel="cpi_factor_packed_kernel<1,L>"),
+    "factor_v2_packed": dict(kind="factor", variant="packed", model=2, W=1000000, N=50, bytes=IN2 + 576, kernel="cpi_factor_packed_kernel<2,L>"),
+    # what GTSAM does right after evaluateError -- whitening by the square-root information, Hessian blocks
+    "sqrt_info": dict(kind="sqrt_info", model=1, W=1000000, N=50, bytes=1800 + 1800, kernel="cpi_sqrt_info_kernel"),
+    "factor_v1_whitened": dict(kind="factor", variant="whitened", model=1, W=1000000, N=50, bytes=IN1 + 1800 + 3720, kernel="cpi_factor_kernel<1,true,16>"),
+    "factor_v2_whitened": dict(kind="factor", variant="whitened", model=2, W=1000000, N=50, bytes=IN2 + 1800 + 3720, kernel="cpi_factor_kernel<2,true,16>"),
+    "factor_v1_hessian": dict(kind="factor", variant="hessian", model=1, W=1000000, N=50, bytes=IN1 + 1800 + 3968, kernel="cpi_factor_hessian_kernel<1>"),
+    "factor_v2_hessian": dict(kind="factor", variant="hessian", model=2, W=1000000, N=50, bytes=IN2 + 1800 + 3968, kernel="cpi_factor_hessian_kernel<2>"),
+    # getpredictedstate_v1 / _v2 -- reads alpha, beta, q, DT (88 B) + a state (128 B), writes a state
+    "predict_v1": dict(kind="predict", model=1, W=1000000, N=50, bytes=88 + 128 + 128, kernel="cpi_predict_kernel<1>"),
+    "predict_v2": dict(kind="predict", model=2, W=1000000, N=50, bytes=88 + 128 + 128, kernel="cpi_predict_kernel<2>"),
+    # the same mean-only recursion on the TILED input layout (knots of 64 windows interleaved per step; include/cpi_amd.h),
+    # the batches cut from one IMU stream by the device assembler (cpi_assemble_tiles) -- no dense copy, no cpi_tile_knots
+    "v1_mean_tiled": dict(kind="tiled", model=1, want=("mean",), W=1000000, N=50, bytes=2856 + 88, kernel="cpi_mean_tiled_kernel<1,false,true,SPLIT>"),
+    "v2_mean_tiled": dict(kind="tiled", model=2, want=("mean",), W=1000000, N=50, bytes=2888 + 88, kernel="cpi_mean_tiled_kernel<2,false,true,SPLIT>"),
     # BASELINE configs[4]: one GPU's share of 8 M windows x 100 samples (EuRoC-rate synthetic IMU), generated on the device
-    "cfg5_mean": dict(model=1, want=("mean",), W=1000000, N=100, bytes=2856 + 88, kernel="cpi_mean_kernel<1,false,false,1>"),
-    "cfg5_full": dict(model=1, want=("mean", "jac", "cov"), W=1000000, N=100, bytes=2856 + 2320, kernel="cpi_cov_kernel<1,false>"),
+    "cfg5_mean": dict(kind="pre", model=1, want=("mean",), W=1000000, N=100, bytes=2856 + 88, kernel="cpi_mean_kernel<1,false,false,1>"),
+    "cfg5_full": dict(kind="pre", model=1, want=("mean", "jac", "cov"), W=1000000, N=100, bytes=2856 + 2320, kernel="cpi_cov_kernel<1,false>",
+                      useful_lanes=(15, 16)),
 }
 # sparse-minimal FP64 flop per 50-sample window (0.35-0.5 M and 0.65-0.8 M; midpoints) -- an ESTIMATE, used
 # only when no counter-derived figure is available for the loaded library
@@ -63,9 +91,9 @@ FLOP_EST = {"v1_full": 0.425e6, "v2_full": 0.725e6}
 
 def bytes_per_unit(workload, samples=50):
     """a window reads samples*56 + 8 + 48 (+32 for q_k_lin) bytes; WORKLOADS holds that figure at 50
-    samples.  Factor workloads do not depend on the window length."""
+    samples.  Factor-shaped workloads do not depend on the window length."""
     w = WORKLOADS[workload]
-    return w["bytes"] if w.get("factor") else w["bytes"] + (samples - 50) * 56
+    return w["bytes"] + (samples - 50) * 56 if w["kind"] in ("pre", "tiled") else w["bytes"]
 
 
 def parse(argv=None):
@@ -79,7 +107,11 @@ def parse(argv=None):
     ap.add_argument("--lanes", type=int, default=0, help="mean kernel lanes per window (0 = auto)")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="N > 1: weak = every rank runs the per-GPU workload; strong = the workload's windows are split N ways")
-    ap.add_argument("--gather", default="root", choices=("root", "all", "none"), help="N > 1: the final exchange step")
+    ap.add_argument("--gather", default="root", choices=("root", "all", "none"), help="N > 1: the exchange step")
+    ap.add_argument("--gather-schedule", default="auto", choices=("auto", "final", "pipelined"),
+                    help="N > 1: final = one gather after the K steps; pipelined = every step's slab, overlapped with the next step "
+                         "(auto: pipelined when a step lasts about a millisecond or more)")
+    ap.add_argument("--eager", action="store_true", help="issue the K timed steps as K launches instead of replaying one HIP graph")
     ap.add_argument("--no-extra", action="store_true", help="skip the additional BASELINE configs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     return ap.parse_args(argv)
@@ -89,126 +121,228 @@ def parse(argv=None):
 class Workload:
     """A pool of resident batches + preallocated outputs + a step() closure."""
 
-    def __init__(self, eng, name, W, N, seed, lanes=0, pool_bytes=MALL_BYTES * 5 // 4):
+    def __init__(self, eng, name, W, N, seed, lanes=0, pool_bytes=MALL_BYTES * 5 // 4, min_out_sets=1):
         from cpi_amd import synth
         spec = WORKLOADS[name]
         self.name, self.W, self.N, self.spec = name, W, N, spec
-        self.model = spec["model"]
-        self.is_factor = bool(spec.get("factor"))
+        self.kind, self.model, self.variant = spec["kind"], spec["model"], spec.get("variant", "dense")
+        self.is_factor = self.kind != "pre" and self.kind != "tiled"       # unit = factor
+        self.eng, self.i, self.assembly = eng, 0, None
         dev = eng.device
-        self.eng = eng
+        f64 = dict(dtype=torch.float64, device=dev)
         if self.is_factor:
             model = self.model
-            self.packed = bool(spec.get("packed"))
+            need_cov = self.kind == "sqrt_info" or self.variant in ("whitened", "hessian")
             kn, lin, q = synth.make_windows(W, N, seed=seed, device=dev)
-            self.meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac"))
+            self.meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac", "cov") if need_cov else ("mean", "jac"))
             torch.cuda.synchronize()
             del kn
-            xi, xj = synth.make_states(self.meas["alpha"], self.meas["beta"], self.meas["q"], self.meas["DT"], lin,
-                                       model, device=dev)
+            xi, xj = synth.make_states(self.meas["alpha"], self.meas["beta"], self.meas["q"], self.meas["DT"], lin, model, device=dev)
             self.states = torch.cat([xi, xj[-1:]], dim=0).contiguous()   # chained states: idx_i=f, idx_j=f+1
             self.lin, self.q = lin, (q if model == 2 else None)
-            if self.packed:
-                self.out = torch.empty((W, 72), dtype=torch.float64, device=dev)
+            self.R = eng.sqrt_information(self.meas["P"]) if need_cov else None
+            if self.kind == "sqrt_info":
+                self.P = self.meas["P"]
+                self.out = self.R
+            elif self.kind == "predict":
+                self.out = torch.empty((W, 16), **f64)
+            elif self.variant == "packed":
+                self.out = torch.empty((W, 72), **f64)
+            elif self.variant == "hessian":
+                self.out = torch.empty((W, 496), **f64)
+                self.meas = {k: v for k, v in self.meas.items() if k != "P"}
             else:
-                self.out = {"err": torch.empty((W, 15), dtype=torch.float64, device=dev),
-                            "H1": torch.empty((W, 225), dtype=torch.float64, device=dev),
-                            "H2": torch.empty((W, 225), dtype=torch.float64, device=dev)}
-            self.nbatch = 1   # 4.5 GB per sweep: far beyond the Infinity Cache by itself
+                self.out = {"err": torch.empty((W, 15), **f64), "H1": torch.empty((W, 225), **f64), "H2": torch.empty((W, 225), **f64)}
+                if need_cov:
+                    self.meas = {k: v for k, v in self.meas.items() if k != "P"}
+            torch.cuda.synchronize()
+            self.nbatch = 1   # gigabytes per sweep: far beyond the Infinity Cache by itself
             return
         self.want = spec["want"]
         self.prm = eng.make_params(self.model, lanes_per_window=lanes)
         batch_bytes = W * (N + 1) * 56
         self.nbatch = max(1, min(64, -(-pool_bytes // batch_bytes)))
-        self.batches = [synth.make_windows(W, N, seed=seed + 101 * b, device=dev) for b in range(self.nbatch)]
-        # one flat buffer per output set: a rank's outputs are one contiguous slab, so the multi-GPU gather is ONE collective
+        # one flat buffer per output set: a rank's outputs are one contiguous slab, so the multi-GPU gather is ONE message per peer
         out_bytes = W * sum(n for _, n in eng.alloc_outputs(1, self.want, self.model, packed=True)["_fields"]) * 8
-        self.outs = [eng.alloc_outputs(W, self.want, self.model, packed=True)
-                     for _ in range(1 if out_bytes > (1 << 30) else min(self.nbatch, 4))]
-        self.i = 0
-        self.tiled = bool(spec.get("tiled"))
-        import math
-        if self.tiled:   # the batches converted once, untimed: the timed step reads tiles only
-            self.tiles = [eng.tile_knots(b[0]) for b in self.batches]
-            torch.cuda.synchronize()
-            for bi in range(self.nbatch):
-                self.batches[bi] = (self.batches[bi][0][:64].clone(), self.batches[bi][1], self.batches[bi][2])   # the dense copy is dropped (lin / q stay)
-        # every (batch, output set) pair of the walk pre-bound: a step is one foreign call (Engine.bind_preintegrate)
-        period = self.nbatch * len(self.outs) // math.gcd(self.nbatch, len(self.outs))
+        nsets = max(min_out_sets, 1 if out_bytes > (1 << 30) else min(self.nbatch, 4))
+        self.outs = [eng.alloc_outputs(W, self.want, self.model, packed=True) for _ in range(nsets)]
+        period = self.nbatch * nsets // math.gcd(self.nbatch, nsets)
         self.calls = []
+        if self.kind == "tiled":
+            # every batch is ONE IMU stream + W update times (one every N samples, on the IMU grid: N whole intervals per
+            # window) cut by the DEVICE ASSEMBLER straight into tiles: the producer a caller shaped like
+            # GraphSolver_IMU.cpp:50-69 uses.  Its cost is measured here, once per batch, and reported beside the row.
+            self.batches, ev = [], []
+            for b in range(self.nbatch):
+                stream, upd, lin, q = synth.make_stream(W, N, seed=seed + 101 * b, device=dev)
+                tiles = torch.empty(((W + 63) // 64, N + 1, 7, 64), **f64)
+                count = torch.empty((W,), dtype=torch.int32, device=dev)
+                eng.assemble_tiles(stream, upd, N, tiles=tiles, count=count)          # warm (first launch, page faults)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); eng.assemble_tiles(stream, upd, N, tiles=tiles, count=count); e1.record()
+                torch.cuda.synchronize()
+                ev.append(e0.elapsed_time(e1))
+                assert int(count.max().item()) == N and int(count.min().item()) == N, "the bench stream must cut into N-interval windows"
+                self.batches.append((tiles, count, lin, q))
+                del stream, upd
+            ms = sorted(ev)[len(ev) // 2]
+            self.assembly = {"what": "cpi_assemble_tiles: ONE stream of W x N + 1 readings + W update times -> tiles + count (device, one launch per batch)",
+                             "ms_per_batch": ms, "GBs": (W * N * 56 + W * 8 + W * (N + 1) * 56 + W * 4) / (ms * 1e-3) / 1e9,
+                             "share_of_step": None}
+            for i in range(period):
+                tiles, count, lin, q = self.batches[i % self.nbatch]
+                call, _ = eng.preintegrate_tiled(tiles, W, lin, q, self.prm, count=count, out=self.outs[i % nsets], bind=True)
+                self.calls.append(call)
+            return
+        self.batches = [synth.make_windows(W, N, seed=seed + 101 * b, device=dev) for b in range(self.nbatch)]
+        # every (batch, output set) pair of the walk pre-bound: a step is one foreign call (Engine.bind_preintegrate)
         for i in range(period):
             kn, lin, q = self.batches[i % self.nbatch]
-            if self.tiled:
-                call, _ = eng.preintegrate_tiled(self.tiles[i % self.nbatch], W, lin, q, self.prm, out=self.outs[i % len(self.outs)], bind=True)
-            else:
-                call, _ = eng.bind_preintegrate(kn, lin, q if self.model != 3 else None, self.prm, want=self.want,
-                                                out=self.outs[i % len(self.outs)])
+            call, _ = eng.bind_preintegrate(kn, lin, q if self.model != 3 else None, self.prm, want=self.want, out=self.outs[i % nsets])
             self.calls.append(call)
+
+    def out_of(self, i):
+        """The outputs step number i writes."""
+        return self.out if self.is_factor else self.outs[i % len(self.outs)]
 
     def step(self):
         if self.is_factor:
-            if self.packed:
-                self.eng.factor_eval_packed(self.model, self.meas, self.lin, self.q, self.states, out=self.out)
-                return {"packed": self.out}
-            self.eng.factor_eval(self.model, self.meas, self.lin, self.q, self.states, out=self.out)
+            e = self.eng
+            if self.kind == "sqrt_info":
+                e._sync_stream()
+                e._check(e.lib.cpi_sqrt_information_batch(e.ctx, self.W, self.P.data_ptr(), self.R.data_ptr()))
+            elif self.kind == "predict":
+                e.predict(self.model, self.meas, self.states, out=self.out)
+            elif self.variant == "packed":
+                e.factor_eval_packed(self.model, self.meas, self.lin, self.q, self.states, out=self.out)
+            elif self.variant == "hessian":
+                e.factor_hessian(self.model, self.meas, self.lin, self.q, self.states, self.R, out=self.out)
+            elif self.variant == "whitened":
+                e.factor_eval(self.model, self.meas, self.lin, self.q, self.states, out=self.out, sqrt_info=self.R)
+            else:
+                e.factor_eval(self.model, self.meas, self.lin, self.q, self.states, out=self.out)
+            self.i += 1
             return self.out
         out = self.outs[self.i % len(self.outs)]
         self.calls[self.i % len(self.calls)]()
         self.i += 1
         return out
 
+    def capture(self, steps):
+        """The next `steps` steps as ONE HIP graph (a kernel node per launch; "V1 full" forks its side stream inside the
+        capture).  Returns the graph, or None when this workload / runtime cannot be captured (eager launches then)."""
+        i0 = self.i
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.step()                                  # warm-up on a side stream, as graph capture requires
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.i = i0
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(steps):
+                    self.step()
+            self.i = i0
+            return g
+        except Exception as ex:                              # pragma: no cover - depends on the runtime
+            sys.stderr.write("bench.py: HIP graph capture failed (%r): eager launches\n" % (ex,))
+            self.i = i0
+            torch.cuda.synchronize()
+            return None
+
 
 # ------------------------------------------------------------------------------------------------ multi-GPU exchange
 def final_gather(out, W_local, mode="root", dst=0, recv=None):
-    """The path's one exchange step: the per-rank output slabs of the last step.  mode "root": to rank `dst` only
+    """The path's one exchange step: the per-rank output slabs of a step.  mode "root": to rank `dst` only
     (every peer sends straight to the root); "all": all-gather.  Returns the gathered blocks
     (name -> [world, W_local, n]) on the ranks that hold them, else None.  Works on any backend (gloo in the CPU tests)."""
     from cpi_amd.dist import gather_packed, gather_to_root
     if mode == "none":
         return None
-    assert "_flat" in out, "the final gather moves ONE packed slab per rank (Engine.alloc_outputs(packed=True))"
+    assert "_flat" in out, "the gather moves ONE packed slab per rank (Engine.alloc_outputs(packed=True))"
     if mode == "all":
         return gather_packed(out["_flat"], out["_fields"], W_local)
     return gather_to_root(out["_flat"], out["_fields"], W_local, dst=dst, out=recv)
 
 
-def time_steps(wl, steps, warmup, dist_on=False, gather="root"):
-    """W untimed warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize on both sides.
-    Returns (wall seconds, kernel milliseconds by HIP events on the launch stream)."""
+def time_steps(wl, steps, warmup, dist_on=False, gather="root", schedule="final", graph=True):
+    """W untimed warm-up steps, then EXACTLY `steps` timed steps.  Both sides of the timed region are bracketed by
+    barrier + synchronize; a rank's clock stops when its own part (steps + its share of the exchange) is complete, BEFORE
+    the closing barrier -- the caller reduces the wall times with MAX over ranks.
+    Returns dict(wall seconds, kernel_ms = HIP events around the K steps on the launch stream, gather_ms = the exposed
+    exchange tail after the last kernel, mode = "graph" | "eager")."""
     import torch.distributed as dist
     out = None
     for _ in range(warmup):
         out = wl.step()
     torch.cuda.synchronize()
-    recv = None
     do_gather = dist_on and gather != "none" and not wl.is_factor
+    pipelined = do_gather and schedule == "pipelined" and len(wl.outs) >= 2
+    g = wl.capture(steps) if (graph and not pipelined) else None
+    if g is not None:
+        g.replay()                                           # untimed: the first replay of a graph uploads it
+        torch.cuda.synchronize()
+    recv, side = [None, None], None
     if dist_on:
-        if do_gather and out is None:
-            out = wl.step()
         if do_gather:
-            # untimed: first use of the collective (RCCL channel set-up), and the root's receive buffer
+            if out is None:
+                out = wl.step()
+            # untimed: first use of the collective (RCCL channel set-up), and the root's receive buffers
             if gather == "root" and dist.get_rank() == 0:
-                recv = torch.empty((dist.get_world_size(), out["_flat"].numel()), dtype=torch.float64, device=out["_flat"].device)
-            final_gather(out, wl.W, gather, recv=recv)
+                shape = (dist.get_world_size(), out["_flat"].numel())
+                recv = [torch.empty(shape, dtype=torch.float64, device=out["_flat"].device) for _ in range(2 if pipelined else 1)]
+                if not pipelined:
+                    recv = recv * 2
+            final_gather(out, wl.W, gather, recv=recv[0])
             torch.cuda.synchronize()
+            if pipelined:
+                side = torch.cuda.Stream()
         dist.barrier()
         torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    i0 = wl.i
     t0 = time.perf_counter()
     e0.record()
-    out = None
-    for _ in range(steps):
-        out = wl.step()
-    e1.record()                                  # HIP events on the launch stream: kernel time only
-    gathered = final_gather(out, wl.W, gather, recv=recv) if do_gather else None
+    if pipelined:
+        # step k's slab travels on the side stream while step k + 1 computes into the other output set; a set is rewritten
+        # only after its gather has drained (ev_done), the root's receive buffers alternate likewise
+        cur = torch.cuda.current_stream()
+        ev_done = [None, None]
+        for k in range(steps):
+            if ev_done[k & 1] is not None:
+                cur.wait_event(ev_done[k & 1])
+            out = wl.step()
+            ready = torch.cuda.Event(); ready.record(cur)
+            if k == steps - 1:
+                e1.record(cur)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                final_gather(out, wl.W, gather, recv=recv[k & 1])
+                done = torch.cuda.Event(); done.record(side)
+            ev_done[k & 1] = done
+        cur.wait_stream(side)
+        e2.record(cur)
+    else:
+        if g is not None:
+            g.replay()
+            wl.i = i0 + steps
+        else:
+            for _ in range(steps):
+                wl.step()
+        e1.record()                                  # HIP events on the launch stream: kernel time only
+        gathered = final_gather(wl.out_of(i0 + steps - 1), wl.W, gather, recv=recv[0]) if do_gather else None
+        e2.record()
     torch.cuda.synchronize()
+    wall = time.perf_counter() - t0                  # this rank's part is complete (the root: every slab has arrived)
     if dist_on:
-        dist.barrier()
+        dist.barrier()                               # closing barrier: outside the timed region
         torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    kern_ms = e0.elapsed_time(e1)
-    del gathered
-    return wall, kern_ms
+    gathered = None
+    return {"wall": wall, "kernel_ms": e0.elapsed_time(e1), "gather_ms": e1.elapsed_time(e2) if do_gather else 0.0,
+            "mode": ("pipelined-eager" if pipelined else ("graph" if g is not None else "eager"))}
 
 
 # ------------------------------------------------------------------------------------------------ CPU legs
@@ -233,42 +367,100 @@ def usable_cpus():
     return n
 
 
+def _cpu_factor_rows(wl, min_seconds, cores):
+    """CPU legs of the factor-shaped rows (kind "port": the reference's factor TUs need GTSAM, which is absent).
+    evaluateError itself = the C restatement, threaded over factors; what GTSAM does next (square-root information,
+    whitening, Hessian blocks) = numpy / LAPACK on one core, as the tests' checker does it."""
+    import numpy as np
+    from oracle import oracle_py as op
+    orc = op.oracle()
+    F = min(wl.W, 20000)
+    meas = {k: v[:F].cpu().numpy() for k, v in wl.meas.items() if k != "P"}
+    rec = op.factor_records(meas, wl.lin[:F].cpu().numpy(), wl.q[:F].cpu().numpy() if wl.q is not None else None)
+    st = wl.states[:F + 1].cpu().numpy()
+    xi, xj = np.ascontiguousarray(st[:-1]), np.ascontiguousarray(st[1:])
+    if wl.kind == "predict":
+        n = min(F, 20000)
+        orc.predict(wl.model, rec[:64], xi[:64])
+        t0, done = time.perf_counter(), 0
+        while True:
+            orc.predict(wl.model, rec[:n], xi[:n])
+            done += n
+            el = time.perf_counter() - t0
+            if el >= min_seconds:
+                break
+        return {"value": done / el, "unit": "factors/s", "cores": 1, "kind": "port", "single_core_value": done / el,
+                "sample": "%d passes over %d of the row's factors through the C restatement of getpredictedstate_v%d "
+                          "(GraphSolver_IMU.cpp:263-307), one thread" % (done // n, n, wl.model)}
+    if wl.kind == "sqrt_info":
+        n = min(F, 4000)
+        P = wl.P[:n].cpu().numpy().reshape(n, 15, 15)
+        t0, done = time.perf_counter(), 0
+        while True:
+            np.linalg.cholesky(np.linalg.inv(P))             # R^T (GTSAM: Covariance -> Information(P^-1) -> LLT)
+            done += n
+            el = time.perf_counter() - t0
+            if el >= min_seconds:
+                break
+        return {"value": done / el, "unit": "factors/s", "cores": 1, "kind": "port", "single_core_value": done / el,
+                "sample": "%d passes over %d of the row's covariances through numpy / LAPACK: chol(inv(P)), batched, one thread "
+                          "(GTSAM's Gaussian::Covariance is not in the reference tree)" % (done // n, n)}
+    buf = (np.ones((F, 15)), np.ones((F, 225)), np.ones((F, 225)))
+    orc.factor_batch(wl.model, rec[:256], xi[:256], xj[:256], nthreads=cores)
+    extra = None
+    if wl.variant in ("whitened", "hessian"):
+        nR = min(F, 4000)
+        R = wl.R[:nR].cpu().numpy().reshape(nR, 15, 15).transpose(0, 2, 1)
+
+        def extra(e, H1, H2):
+            A1, A2, b = R @ H1[:nR].reshape(nR, 15, 15).transpose(0, 2, 1), R @ H2[:nR].reshape(nR, 15, 15).transpose(0, 2, 1), -(R @ e[:nR, :, None])
+            if wl.variant == "hessian":
+                A = np.concatenate([A1, A2, b], axis=2)
+                return A.transpose(0, 2, 1) @ A
+            return A1
+    t0, done, t_extra, n_extra = time.perf_counter(), 0, 0.0, 0
+    while True:
+        orc.factor_batch(wl.model, rec, xi, xj, nthreads=cores, out=buf)
+        done += F
+        if extra is not None:
+            t1 = time.perf_counter(); extra(*buf); t_extra += time.perf_counter() - t1; n_extra += min(F, 4000)
+        el = time.perf_counter() - t0
+        if el >= min_seconds:
+            break
+    per_factor = (el - t_extra) / done + (t_extra / n_extra if n_extra else 0.0)
+    fs = min(F, 5000)
+    t1 = time.perf_counter(); orc.factor_batch(wl.model, rec[:fs], xi[:fs], xj[:fs], nthreads=1); t1 = time.perf_counter() - t1
+    what = {"dense": "", "packed": "", "whitened": " + numpy whitening (R e, R H1, R H2; one thread, %d factors per pass)" % min(F, 4000),
+            "hessian": " + numpy whitening and [A1 A2 b]^T [A1 A2 b] (one thread, %d factors per pass)" % min(F, 4000)}[wl.variant]
+    return {"value": 1.0 / per_factor, "unit": "factors/s", "cores": cores, "kind": "port", "single_core_value": fs / t1,
+            "sample": "%d passes over %d of the sweep's factors (residual + dense H1 / H2, the C restatement of "
+                      "ImuFactorCPIv%d::evaluateError -- the reference's factor TUs need GTSAM), %d threads%s"
+                      % (done // F, F, wl.model, cores, what)}
+
+
 def cpu_baseline(wl, min_seconds=8.0):
     """The CPU path timed beside a row, on this box's host cores, on a bounded sample of the SAME inputs.
     Preintegration rows: the reference's own CpiV1 / CpiV2 (oracle/_ref, kind "reference") -- which always integrates means
     + bias Jacobians + covariance, so it is like-for-like for the *_full rows and does MORE than the GPU for the
-    mean-only rows (the reference has no mean-only mode; said in `sample`).  Forster comparator and the evaluateError
-    sweep: the C restatement (kind "port"; GTSAM / the factor TUs cannot be built here)."""
+    mean-only rows (the reference has no mean-only mode; said in `sample`).  Forster comparator, the evaluateError
+    sweeps and the SURVEY 8(f) rows: the C restatement / numpy (kind "port"; GTSAM / the factor TUs cannot be built here)."""
     import numpy as np
     from oracle import oracle_py as op
     from oracle.oracle_py import OUT_DOUBLES
     cores = usable_cpus()
     if wl.is_factor:
-        F = min(wl.W, 20000)
-        meas = {k: v[:F].cpu().numpy() for k, v in wl.meas.items()}
-        rec = op.factor_records(meas, wl.lin[:F].cpu().numpy(), wl.q[:F].cpu().numpy() if wl.q is not None else None)
-        st = wl.states[:F + 1].cpu().numpy()
-        xi, xj = np.ascontiguousarray(st[:-1]), np.ascontiguousarray(st[1:])
-        buf = (np.ones((F, 15)), np.ones((F, 225)), np.ones((F, 225)))
-        orc = op.oracle()
-        orc.factor_batch(wl.model, rec[:256], xi[:256], xj[:256], nthreads=cores)
-        t0, done = time.perf_counter(), 0
-        while True:
-            orc.factor_batch(wl.model, rec, xi, xj, nthreads=cores, out=buf)
-            done += F
-            el = time.perf_counter() - t0
-            if el >= min_seconds:
-                break
-        fs = min(F, 5000)
-        t1 = time.perf_counter(); orc.factor_batch(wl.model, rec[:fs], xi[:fs], xj[:fs], nthreads=1); t1 = time.perf_counter() - t1
-        return {"value": done / el, "unit": "factors/s", "cores": cores, "kind": "port", "single_core_value": fs / t1,
-                "sample": "%d passes over %d of the sweep's factors (residual + dense H1 / H2, the C restatement of "
-                          "ImuFactorCPIv%d::evaluateError -- the reference's factor TUs need GTSAM), %d threads" % (done // F, F, wl.model, cores)}
+        return _cpu_factor_rows(wl, min_seconds, cores)
     ref = op.reference()
     lib, kind = (ref, "reference") if ref is not None else (op.oracle(), "port")
     if wl.model == 3:   # the Forster comparator lives in GTSAM (absent): only the restatement exists
         lib, kind = op.oracle(), "port"
-    kn, lin, q = [t[:10000].cpu().numpy() for t in wl.batches[0]]
+    if wl.kind == "tiled":   # the CPU leg reads the same windows in the dense order: un-tile the first tiles of batch 0
+        tiles, _, lin, q = wl.batches[0]
+        nb = min(tiles.shape[0], 157)
+        kn = tiles[:nb].permute(0, 3, 1, 2).reshape(nb * 64, wl.N + 1, 7)[:min(wl.W, nb * 64)].contiguous().cpu().numpy()
+        lin, q = lin[:kn.shape[0]].cpu().numpy(), q[:kn.shape[0]].cpu().numpy()
+    else:
+        kn, lin, q = [t[:10000].cpu().numpy() for t in wl.batches[0]]
     Wc = kn.shape[0]
     prm = op.make_params(wl.model, 0, 1)
     raw = np.ones((Wc, OUT_DOUBLES))                               # reused, already touched output buffer
@@ -335,10 +527,9 @@ def sparse_port_rate(wl, kn, lin, q, cores, seconds):
             "sample": "%d window evaluations (%d passes) over %d threads; %d windows on one thread" % (Wp, passes, cores, n1)}
 
 
-
 # ------------------------------------------------------------------------------------------------ counters
 def load_pmc(build_id):
-    """profiles/r02_pmc.json: rocprofv3 --pmc passes of tools/pmc_collect.sh, stamped with the build id of the library
+    """profiles/r03_pmc.json: rocprofv3 --pmc passes of tools/pmc_collect.sh, stamped with the build id of the library
     they were collected on.  Used only when that stamp equals the LOADED library's cpi_build_id(); otherwise the
     counter-derived fields are null (the file is stale for this library)."""
     try:
@@ -361,6 +552,7 @@ def roofline_of(name, W, N, launch_s, pmc_rows, pmc_note):
          "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes; " + pmc_note,
          "algorithmic_bytes_per_launch": bpu * W, "algorithmic_bytes_per_unit": bpu,
          "kernel": WORKLOADS[name]["kernel"], "launch_us": launch_s * 1e6}
+    ul = WORKLOADS[name].get("useful_lanes")
     if row and row.get("fp64_flop"):
         # FP64 work counted by the SQ instruction counters of the same library: (2 FMA + MUL + ADD + TRANS) x 64 lanes
         tf = row["fp64_flop"] / launch_s / 1e12
@@ -371,6 +563,13 @@ def roofline_of(name, W, N, launch_s, pmc_rows, pmc_note):
         tf = FLOP_EST[name] * W / launch_s / 1e12
         r["fp64"] = {"TFLOPs": tf, "peak": FP64_PEAK_TFLOPS, "frac": tf / FP64_PEAK_TFLOPS,
                      "source": "estimate (SURVEY.md 8(d) sparse-minimal flop midpoints; no counters for this build)"}
+    if ul and "fp64" in r and r["fp64"]["source"] == "counters":
+        # the instruction counters count 64 lanes per instruction; the column-lane recursion keeps ul[0] of every ul[1]
+        # lanes on a useful column (the rest run as harmless zero columns): the useful share of the counted work
+        r["fp64"]["useful_lanes"] = "%d of %d" % ul
+        r["fp64"]["useful_frac"] = r["fp64"]["frac"] * ul[0] / ul[1]
+        if name in ("v1_full", "cfg5_full"):
+            r["fp64"]["useful_note"] = "applied to the whole row: a lower bound -- the analytic-Jacobian kernel of this row keeps all lanes busy"
     return r
 
 
@@ -424,6 +623,17 @@ def preramp(wl, ms):
         torch.cuda.synchronize()
 
 
+EXTRA_ROWS = (("v1_mean", 30000, 1000), ("v1_mean", 100000, 300), ("v1_mean", 1000000, 40),
+              ("v1_full", 100000, 30), ("v2_full", 100000, 30), ("forster_full", 100000, 30),
+              ("factor_v1", 1000000, 40), ("factor_v2", 1000000, 40),
+              ("factor_v1_packed", 1000000, 40), ("factor_v2_packed", 1000000, 40),
+              ("sqrt_info", 1000000, 20), ("factor_v1_whitened", 1000000, 20), ("factor_v2_whitened", 1000000, 20),
+              ("factor_v1_hessian", 1000000, 20), ("factor_v2_hessian", 1000000, 20),
+              ("predict_v1", 1000000, 40), ("predict_v2", 1000000, 40),
+              ("cfg5_mean", 1000000, 10), ("cfg5_full", 1000000, 3),
+              ("v1_mean_tiled", 1000000, 40), ("v2_mean_tiled", 1000000, 40), ("v1_mean_tiled", 10000, 1000))
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -465,27 +675,37 @@ def main():
     else:
         W = W_job
         total_units = W_job * world
-    wl = Workload(eng, a.workload, W, N, seed=20190101 + 7919 * rank, lanes=a.lanes)
+    is_factor = spec["kind"] not in ("pre", "tiled")
+    do_gather = dist_on and a.gather != "none" and not is_factor
+    # schedule of the exchange: per-step, overlapped gathers pay when a step lasts long enough to hide one (>= ~1 ms:
+    # covariance rows, million-window batches); the 10 k-window headline keeps the single final gather
+    step_bytes = bytes_per_unit(a.workload, N) * W
+    schedule = a.gather_schedule
+    if schedule == "auto":
+        schedule = "pipelined" if (do_gather and a.gather == "root" and ("cov" in spec.get("want", ()) or step_bytes > (256 << 20))) else "final"
+    wl = Workload(eng, a.workload, W, N, seed=20190101 + 7919 * rank, lanes=a.lanes, min_out_sets=2 if (do_gather and schedule == "pipelined") else 1)
     PRERAMP_MS = 60.0
     preramp(wl, PRERAMP_MS)
-    wall, kern_ms = time_steps(wl, a.steps, a.warmup, dist_on, a.gather)
+    tm = time_steps(wl, a.steps, a.warmup, dist_on, a.gather, schedule, graph=not a.eager)
+    wall, kern_ms, gather_ms = tm["wall"], tm["kernel_ms"], tm["gather_ms"]
     wall_ng = None
-    if dist_on and a.gather != "none" and not wl.is_factor:     # the same K steps without the exchange step, beside it
-        wall_ng, _ = time_steps(wl, a.steps, min(a.warmup, 5), dist_on, "none")
+    if do_gather:     # the same K steps without the exchange step, beside it
+        wall_ng = time_steps(wl, a.steps, min(a.warmup, 5), dist_on, "none", "final", graph=not a.eager)["wall"]
     if dist_on:
         import torch.distributed as dist
-        t = torch.tensor([wall, kern_ms, wall_ng or 0.0], dtype=torch.float64, device="cpu" if rehearsal else eng.device)
+        t = torch.tensor([wall, kern_ms, gather_ms, wall_ng or 0.0], dtype=torch.float64, device="cpu" if rehearsal else eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kern_ms, wall_ng = t[0].item(), t[1].item(), (t[2].item() if wall_ng is not None else None)
+        wall, kern_ms, gather_ms, wall_ng = t[0].item(), t[1].item(), t[2].item(), (t[3].item() if wall_ng is not None else None)
     value = total_units * a.steps / wall
     launch_s = kern_ms * 1e-3 / a.steps
-    is_factor = wl.is_factor
     unit = "factors" if is_factor else "windows"
     cfg_note = ""
     if a.workload == "v1_mean" and W_job == 10000 and N == 50:
         cfg_note = ", CPI model 1, mean-only (BASELINE.json configs[1])"
     elif a.workload.startswith("cfg5"):
         cfg_note = ", BASELINE.json configs[4]: 8 M windows x 100 samples over 8 GPUs = this per-GPU share, generated on the device"
+    sched_txt = {"final": "one gather of the LAST step's output slabs, after the K steps",
+                 "pipelined": "EVERY step's output slab, on a side stream, overlapped with the next step (double-buffered)"}[schedule]
     res = {
         "metric": "evaluateError factors/sec" if is_factor else "preintegration windows/sec (%d-sample windows)" % N,
         "value": value, "unit": unit + "/s",
@@ -494,13 +714,22 @@ def main():
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo exchange -- not a measurement)",
         "config": {"workload": "%s: %d %s x %d samples per GPU per step%s" % (a.workload, W, unit, N, cfg_note),
                    "pool_batches": wl.nbatch, "clock_preramp_ms": PRERAMP_MS, "library_build": build_id,
+                   "launch_mode": {"graph": "the %d timed steps replayed as ONE HIP graph (one kernel node per step)" % a.steps,
+                                   "eager": "%d eager launches" % a.steps,
+                                   "pipelined-eager": "%d eager launches, each followed by its gather on a side stream" % a.steps}[tm["mode"]],
                    "parallelism": ("1 GPU" if world == 1 else
-                                   "%s scaling: %d windows per step on each of %d GPUs, no data-path collective; final gather of the "
-                                   "last step's outputs %s, inside the timed region" % (
-                                       a.scaling, W, world, {"root": "to rank 0 (each peer sends straight to the root)",
-                                                             "all": "to every rank (all_gather)", "none": "skipped"}[a.gather]))},
+                                   "%s scaling: %d windows per step on each of %d GPUs, no data-path collective; exchange = %s, %s; "
+                                   "value = MAX over ranks of each rank's own wall time (the root's ends when every slab has arrived), "
+                                   "closing barrier outside the timed region" % (
+                                       a.scaling, W, world, {"root": "gather to rank 0 (each peer sends ONE packed slab straight to the root)",
+                                                             "all": "all_gather to every rank", "none": "skipped"}[a.gather], sched_txt))},
         "roofline": roofline_of(a.workload, W, N, launch_s, pmc_rows, pmc_note),
     }
+    if dist_on:
+        res["config"]["gather_schedule"] = schedule if do_gather else "none"
+        res["config"]["kernel_ms"] = kern_ms
+        res["config"]["gather_ms"] = gather_ms
+        res["config"]["wall_ms"] = wall * 1e3
     if wall_ng is not None:
         res["config"]["value_without_gather"] = total_units * a.steps / wall_ng
         res["config"]["ms_final_gather"] = max(0.0, (wall - wall_ng) * 1e3)
@@ -510,21 +739,21 @@ def main():
         extra = []
         del wl
         torch.cuda.empty_cache()
-        for name, Wx, steps in (("v1_mean", 30000, 1000), ("v1_mean", 100000, 300), ("v1_mean", 1000000, 40),
-                                ("v1_full", 100000, 30), ("v2_full", 100000, 30), ("forster_full", 100000, 30),
-                                ("factor_v1", 1000000, 40), ("factor_v2", 1000000, 40),
-                                ("factor_v1_packed", 1000000, 40), ("factor_v2_packed", 1000000, 40),
-                                ("cfg5_mean", 1000000, 10), ("cfg5_full", 1000000, 3), ("v1_mean_tiled", 1000000, 40),
-                                ("v1_mean_tiled", 10000, 1000)):
+        for name, Wx, steps in EXTRA_ROWS:
             try:
                 Nx = WORKLOADS[name]["N"]
                 w2 = Workload(eng, name, Wx, Nx, seed=4242)
-                wall2, k2 = time_steps(w2, steps, max(2, steps // 10))
-                ls = k2 * 1e-3 / steps
-                row = {"workload": name, "units_per_step": Wx, "samples": Nx, "value": Wx * steps / wall2,
-                       "unit": ("factors" if w2.is_factor else "windows") + "/s", "launch_ms": ls * 1e3,
+                t2 = time_steps(w2, steps, max(2, steps // 10), graph=not a.eager)
+                ls = t2["kernel_ms"] * 1e-3 / steps
+                row = {"workload": name, "units_per_step": Wx, "samples": Nx, "value": Wx * steps / t2["wall"],
+                       "unit": ("factors" if w2.is_factor else "windows") + "/s", "launch_ms": ls * 1e3, "launch_mode": t2["mode"],
                        "roofline": roofline_of(name, Wx, Nx, ls, pmc_rows, pmc_note)}
-                if not a.no_cpu and not name.endswith("_packed") and not name.endswith("_tiled") and not (name == "v1_mean" and Wx != 1000000):
+                if w2.assembly:
+                    asm = dict(w2.assembly)
+                    asm["share_of_step"] = asm["ms_per_batch"] / (ls * 1e3)
+                    row["assembly"] = asm
+                skip_cpu = name.endswith("_packed") or (name == "v1_mean" and Wx != 1000000) or (name.endswith("_tiled") and Wx != 1000000)
+                if not a.no_cpu and not skip_cpu:
                     row["cpu_baseline"] = cpu_baseline(w2, 2.5)     # bounded: ~2.5 s of CPU work per row
                 extra.append(row)
                 del w2

@@ -342,9 +342,9 @@ class Engine:
                                                       _ptr(sqrt_info), _ptr(out)))
         return out
 
-    def predict(self, model, meas, states_i, idx_i=None, grav=DEFAULT_GRAV):
+    def predict(self, model, meas, states_i, idx_i=None, grav=DEFAULT_GRAV, out=None):
         F = meas["DT"].shape[0]
-        xj = torch.empty((F, 16), dtype=torch.float64, device=self.device)
+        xj = out if out is not None else torch.empty((F, 16), dtype=torch.float64, device=self.device)
         m = self._outputs_struct(meas)
         g = (C.c_double * 3)(*grav)
         self._sync_stream()

@@ -73,6 +73,38 @@ def make_windows(W, N, seed=BASE_SEED, rate=200.0, device="cpu", edge_cases=True
     return knots, lin, q
 
 
+def make_stream(W, N, seed=BASE_SEED, rate=200.0, device="cpu", phase=0.0):
+    """ONE IMU stream of W * N + 1 readings at `rate` (same signal model as make_windows) and W update times, one every N
+    samples: stream [K, 7], update_times [W], lin [W, 6], q_k_lin [W, 4].  phase = 0: the update times fall ON the IMU grid
+    (every window has exactly N whole intervals, no tail -- the shape BASELINE's "N-sample windows" are quoted on);
+    0 < phase < 1: that fraction of a sample period later (N whole intervals + the partial tail interval of
+    GraphSolver_IMU.cpp:64-69, the first window excepted)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    f64 = dict(dtype=torch.float64, device=device)
+    K = W * N + 1
+    dt = 1.0 / rate
+    t = 1275.1 + torch.arange(K, **f64) / rate
+    U = lambda lo, hi: lo + (hi - lo) * torch.rand((1, 3), generator=g, **f64)
+    A_w, A_a, f_w, f_a = U(0.0, 2.5), U(0.0, 3.0), U(0.2, 3.0), U(0.2, 3.0)
+    p_w, p_a = U(0.0, 2 * math.pi), U(0.0, 2 * math.pi)
+    b_g = 0.01 * torch.randn((1, 3), generator=g, **f64)
+    b_a = 0.05 * torch.randn((1, 3), generator=g, **f64)
+    stream = torch.empty((K, 7), **f64)
+    stream[:, 0] = t
+    tt = t.unsqueeze(-1)
+    stream[:, 1:4] = A_w * torch.sin(2 * math.pi * f_w * tt + p_w) + b_g + (SIGMA_G / math.sqrt(dt)) * torch.randn((K, 3), generator=g, **f64)
+    stream[:, 4:7] = A_a * torch.sin(2 * math.pi * f_a * tt + p_a) + b_a + (SIGMA_A / math.sqrt(dt)) * torch.randn((K, 3), generator=g, **f64)
+    stream[:, 6] += GRAV[2]
+    del tt
+    update = t[N::N].clone() + phase * dt
+    lin = torch.cat([b_g + 1e-3 * torch.randn((W, 3), generator=g, **f64), b_a + 1e-2 * torch.randn((W, 3), generator=g, **f64)], dim=1).contiguous()
+    q = torch.randn((W, 4), generator=g, **f64)
+    q = q / q.norm(dim=1, keepdim=True)
+    q = torch.where(q[:, 3:4] < 0, -q, q).contiguous()
+    return stream, update.contiguous(), lin, q
+
+
 def make_states(out_alpha, out_beta, out_q, out_DT, lin, model, seed=BASE_SEED + 7, device="cpu",
                 grav=GRAV):
     """State pairs for the evaluateError sweep (SURVEY.md 8(d) cfg 4): state_i random with biases

@@ -105,7 +105,8 @@ _cache = {}
 def oracle():
     if "o" not in _cache:
         build()
-        _cache["o"] = _OracleLib(os.path.join(_HERE, "liboracle.so"))
+        # CPI_ORACLE_LIB: an instrumented build of the same sources (tests/tools/sanitize.sh)
+        _cache["o"] = _OracleLib(os.environ.get("CPI_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so"))
     return _cache["o"]
 
 

@@ -18,7 +18,7 @@ def lib():
         if (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < max(os.path.getmtime(_SRC), os.path.getmtime(_HDR)):
             subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                                    "-ffp-contract=off", "-o", _LIB, _SRC])
-        _cache["l"] = C.CDLL(_LIB)
+        _cache["l"] = C.CDLL(os.environ.get("CPI_HOSTSIM_LIB") or _LIB)   # env: an instrumented build (tests/tools/sanitize.sh)
     return _cache["l"]
 
 

@@ -228,6 +228,12 @@ def test_bench_gpus_2_end_to_end_rehearsal_on_one_gpu():
         line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")][-1]
         d = json.loads(line)
         assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 5
-        assert "value_without_gather" in d["config"] and d["config"]["value_without_gather"] >= d["value"] * 0.5
+        c = d["config"]
+        assert "value_without_gather" in c and c["value_without_gather"] >= d["value"] * 0.5
         assert d["scaling"] == ("strong" if extra else "weak")
         assert "REHEARSAL" in d["data"]
+        # the exchange is timed on its own, the schedule is named: one final gather for the 10 k-window headline, every
+        # step's slab overlapped with the next step for the covariance row
+        assert c["gather_schedule"] == ("pipelined" if extra else "final") and c["kernel_ms"] > 0 and c["gather_ms"] > 0
+        assert c["wall_ms"] >= c["kernel_ms"] * 0.99 and abs(d["ms_per_step"] * 5 - c["wall_ms"]) < 1e-6 * c["wall_ms"]
+        assert ("graph" in c["launch_mode"]) == (not extra)

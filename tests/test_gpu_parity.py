@@ -310,10 +310,12 @@ def test_config2_size_composition_property(eng):
         assert torch.equal(again[k], ref[k])
 
 
-def test_config3_size_structure_properties(eng):
+def test_config3_size_structure_properties(eng, orc):
     """BASELINE configs[2] (100k x 50, model 2, covariance + bias Jacobians): structural invariants of
     the reference (P symmetric PSD, theta/b_a and b_w/b_a blocks exactly zero, b_w and b_a blocks
-    sigma^2 * DT * I), agreement of the covariance kernel's means with the mean kernel, determinism."""
+    sigma^2 * DT * I), agreement of the covariance kernel's means with the mean kernel, determinism -- and, at the full
+    size, a strided sample of 128 windows against the compiled reference (all 299 outputs, regression gates) plus
+    slice independence (a slice re-run on its own equals the big run bit for bit)."""
     W = 100000
     kn, lin, q = synth.make_windows(W, 50, seed=41, device=eng.device)
     prm = eng.make_params(2)
@@ -342,6 +344,20 @@ def test_config3_size_structure_properties(eng):
     # model 1 on the same windows: identical rotation, covariance of the same magnitude
     o1 = eng.preintegrate(kn, lin, q, eng.make_params(1), want=("mean", "cov"))
     assert (o1["q"] - out["q"]).abs().max().item() < 1e-12
+    # the full-size launch against the compiled reference on a strided sample (every 787th window: all tiles of the grid,
+    # both halves of a wavefront), all 299 doubles of a window
+    pick = torch.arange(0, W, 787, device=eng.device)[:128]
+    assert pick.numel() == 128
+    ref, from_ref = _cpu(orc, (2, 0, 1), kn[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
+    check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, ref, v2=True, label="configs[2] full-size sample", regression=from_ref)
+    # slice independence: the covariance kernel gives one lane group to a window whatever the batch, so a slice re-run on its
+    # own -- from the middle of the batch, not aligned to a wavefront -- reproduces the big run bit for bit
+    for lo, n in ((0, 4096), (50001, 4096), (W - 777, 777)):
+        sl = slice(lo, lo + n)
+        o = eng.preintegrate(kn[sl].contiguous(), lin[sl].contiguous(), q[sl].contiguous(), prm)
+        torch.cuda.synchronize()
+        for k in o:
+            assert torch.equal(o[k], out[k][sl]), (k, lo)
 
 
 @pytest.mark.parametrize("model", [1, 2])

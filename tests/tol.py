@@ -52,3 +52,23 @@ def check_pre(out, ref, what=("mean", "jac", "cov"), v2=False, label="", regress
         if not e <= tol_cov:
             msgs.append("%s P rel err %.3e" % (label, e))
     assert not msgs, "; ".join(msgs)
+
+
+def sqrt_info_longdouble(P):
+    """R = chol_upper(P^-1) = B^-1 with P = B B^T, B upper triangular, in numpy longdouble (x87: 64-bit mantissa), vectorised
+    over the batch: the best available reference for GTSAM's Gaussian::Covariance -> Information(P^-1) -> LLT::matrixU on
+    the realistic covariances, whose condition numbers (~1e8) put LAPACK's own f64 result ~1e-9 away from the true R.
+    P [F, 15, 15] -> R [F, 15, 15] (float64, [row][col])."""
+    A = np.array(P, dtype=np.longdouble)
+    F, n = A.shape[0], A.shape[1]
+    B = np.zeros_like(A)
+    for k in range(n - 1, -1, -1):                  # reverse Cholesky: P = B B^T, B upper triangular
+        B[:, k, k] = np.sqrt(A[:, k, k])
+        B[:, :k, k] = A[:, :k, k] / B[:, k, k][:, None]
+        A[:, :k, :k] -= B[:, :k, k][:, :, None] * B[:, :k, k][:, None, :]
+    U = np.zeros_like(B)                            # U = B^-1 (upper triangular), by back substitution
+    for j in range(n):
+        U[:, j, j] = 1 / B[:, j, j]
+        for i in range(j - 1, -1, -1):
+            U[:, i, j] = -(B[:, i, i + 1:j + 1] * U[:, i + 1:j + 1, j]).sum(axis=1) / B[:, i, i]
+    return np.asarray(U, dtype=np.float64)

@@ -1,0 +1,82 @@
+#!/bin/bash
+# host sanitizer pass over everything that runs on the CPU side of the boundary.
+#   tests/tools/sanitize.sh cpu    (here, no GPU)   the C restatement (oracle/*.c), the host emulation of the kernel arithmetic
+#                                                   (tests/hostsim) and the C++ facade's CPU-only parts (parse / assemble twins)
+#                                                   under AddressSanitizer + UndefinedBehaviorSanitizer, driven by the pytest
+#                                                   modules that exercise them
+#   tests/tools/sanitize.sh gpu    (GPU box)        the C-ABI's host translation unit (cpi_abi.hip: contexts, device sets, the
+#                                                   slab gather, the three-stream host pipeline) rebuilt with ASan + UBSan and
+#                                                   linked with the ordinary kernel objects into libcpi_amd_asan.so; the C++
+#                                                   hosts (tests/cpp/test_facade / test_group incl. the 5-rank shared mode /
+#                                                   test_threads) compiled with the same runtime against it; ThreadSanitizer on
+#                                                   test_threads
+# Writes gpurun_out/sanitize_<part>.txt; exit code 0 = no sanitizer report.
+set -u
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
+R=$PWD
+PART=${1:-cpu}
+mkdir -p gpurun_out build/san
+OUT=gpurun_out/sanitize_$PART.txt
+: > $OUT
+FAIL=0
+say() { echo "$@" | tee -a $OUT; }
+run() {   # run <label> <cmd...>: a sanitizer report (or a non-zero exit) fails the pass
+  local label=$1; shift
+  local log=build/san/$(echo "$label" | tr ' /' '__').log
+  "$@" > $log 2>&1; local rc=$?
+  if [ $rc -ne 0 ] || grep -qE "ERROR: AddressSanitizer|runtime error:|WARNING: ThreadSanitizer|ERROR: LeakSanitizer" $log; then
+    say "FAIL  $label (rc=$rc)"; grep -E "Sanitizer|runtime error" $log | head -5 | tee -a $OUT; tail -3 $log | tee -a $OUT; FAIL=1
+  else
+    say "clean $label   [$(tail -1 $log | cut -c1-100)]"
+  fi
+}
+if [ "$PART" = cpu ]; then
+  SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g"
+  gcc -std=c99 -O1 $SAN -fPIC -shared -ffp-contract=off -o build/san/liboracle_asan.so oracle/cpi_oracle.c oracle/forster_oracle.c -lm -lpthread || exit 2
+  g++ -std=c++17 -O1 $SAN -fPIC -shared -Wno-unknown-pragmas -ffp-contract=off -o build/san/libhostsim_asan.so tests/hostsim/hostsim.cpp || exit 2
+  g++ -std=c++17 -O1 $SAN tests/cpp/test_stream.cpp -o build/san/test_stream_asan -Lcpi_amd -lcpi_amd -Wl,-rpath,$R/cpi_amd -Wl,-rpath,/opt/rocm/lib || exit 2
+  PRE=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)
+  export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1
+  run "oracle/*.c under pytest (golden vectors, factor, Forster, stream, quat_ops)" env LD_PRELOAD=$PRE CPI_ORACLE_LIB=$R/build/san/liboracle_asan.so \
+      python -m pytest -x -q -p no:cacheprovider tests/test_oracle_golden.py tests/test_factor_oracle.py tests/test_forster_oracle.py tests/test_stream.py tests/test_quat_ops.py -m "not gpu"
+  run "tests/hostsim (cpi_math.hpp on the host) under pytest" env LD_PRELOAD=$PRE CPI_HOSTSIM_LIB=$R/build/san/libhostsim_asan.so \
+      python -m pytest -x -q -p no:cacheprovider tests/test_hostsim.py -m "not gpu"
+  printf '%s\n' 1275.06 1275.4 1276.0 1277.5 > build/san/ut.txt
+  run "cpi_host.hpp parse_imu_text + assemble_windows" build/san/test_stream_asan tests/golden/imu_gazebo200_excerpt.dat build/san/ut.txt
+  run "cpi_host.hpp assemble_windows_tiled" build/san/test_stream_asan tests/golden/imu_gazebo200_excerpt.dat build/san/ut.txt tiled
+else
+  CXX=/opt/rocm/lib/llvm/bin/clang++
+  SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -shared-libsan"
+  RT=$(dirname $($CXX -print-file-name=libclang_rt.asan-x86_64.so))
+  python -m cpi_amd.build > /dev/null || exit 2
+  BID=$(python -c "from cpi_amd import build; print(build.source_id())")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC $SAN -fno-gpu-sanitize -DCPI_BUILD_ID=\"$BID\" -c -o build/san/cpi_abi_asan.o cpi_amd/csrc/cpi_abi.hip || exit 2
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $SAN -o build/san/libcpi_amd.so build/san/cpi_abi_asan.o cpi_amd/csrc/_obj/cpi_mean.o cpi_amd/csrc/_obj/cpi_cov.o cpi_amd/csrc/_obj/cpi_factor.o -ldl || exit 2
+  LNK="-Lbuild/san -lcpi_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$R/build/san -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,$RT"
+  for t in test_facade test_group test_threads; do
+    $CXX -std=c++17 -O1 $SAN -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/cpp/$t.cpp -o build/san/${t}_asan $LNK || exit 2
+  done
+  export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:protect_shadow_gap=0 UBSAN_OPTIONS=print_stacktrace=1
+  python - <<'PY'
+import numpy as np, sys
+sys.path.insert(0, '.')
+from cpi_amd import synth
+d = dict(np.load('tests/golden/pre_w48.npz'))
+with open('build/san/w48.bin', 'wb') as f:
+    np.array([d['knots'].shape[0], d['knots'].shape[1] - 1], dtype=np.float64).tofile(f); d['knots'].tofile(f); d['lin'].tofile(f); d['q_k_lin'].tofile(f)
+kn, lin, q = synth.make_windows(70001, 10, seed=77)
+with open('build/san/thr.bin', 'wb') as f:
+    np.array([70001, 10], dtype=np.float64).tofile(f); kn.numpy().tofile(f); lin.numpy().tofile(f); q.numpy().tofile(f)
+PY
+  FAKE=$(python -c "from tests import fake_rccl_py as f; print(f.lib_path())")
+  for m in 1 2 3; do run "test_facade model $m (ASan+UBSan: facade, C-ABI host code, host pipeline)" build/san/test_facade_asan build/san/w48.bin $m; done
+  run "test_group 1 device" build/san/test_group_asan build/san/w48.bin 1 1
+  run "test_group 5 ranks on one device (slab gather, RCCL stand-in)" env CPI_AMD_RCCL_LIB=$FAKE build/san/test_group_asan build/san/w48.bin 2 5 shared
+  run "test_threads 4 host threads (ASan+UBSan)" build/san/test_threads_asan build/san/thr.bin 4
+  # ThreadSanitizer: the facade + test are instrumented, the HIP runtime is not (its internal threads are invisible to TSan)
+  $CXX -std=c++17 -O1 -fsanitize=thread -g -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/cpp/test_threads.cpp -o build/san/test_threads_tsan \
+      -Lcpi_amd -lcpi_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$R/cpi_amd -Wl,-rpath,/opt/rocm/lib 2>> $OUT || say "TSan build failed"
+  [ -x build/san/test_threads_tsan ] && run "test_threads 4 host threads (ThreadSanitizer)" env TSAN_OPTIONS=report_signal_unsafe=0 build/san/test_threads_tsan build/san/thr.bin 4
+fi
+say "sanitize $PART: $([ $FAIL = 0 ] && echo PASS || echo FAIL)"
+exit $FAIL
