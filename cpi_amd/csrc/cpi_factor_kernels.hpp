@@ -380,92 +380,129 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
 //     [A1 A2 b]^T [A1 A2 b]  =  [ G  g ]      G = A^T A (30x30),  g = A^T b,  f = b^T b
 //                               [ g^T f ]
 // 31x31 symmetric, written as its packed upper triangle (column-major packed, LAPACK 'U': entry (i, d), i <= d, at
-// i + d (d + 1) / 2), 496 doubles per factor.  Fused into the whitened sweep: the 31 whitened columns never leave the
-// chip.  16 lanes per factor: lane q < 15 produces columns q of A1 and of A2 (as cpi_factor_kernel), lane 15 the b column;
-// lane q then owns columns q and 30 - q of the result (lane 15: column 15): every lane forms 32 dot products' worth of
-// useful output from two columns held in registers against the 31 columns broadcast from LDS.
+// i + d (d + 1) / 2), 496 doubles per factor.  The whitened Jacobians never exist: with Lam = R^T R the matrix is
+// Hc^T Lam Hc, Hc = [H1 H2 -e], and H1 / H2 are sparse in 3x3 blocks (13 of 25 and the diagonal), so rows of Z = Lam H1
+// and columns of the result are short chains of 3-vector x block products (cpi_math.hpp: hsn).
+// 16 lanes (one DPP row) per factor, 4 factors per wavefront.  Lane q < 15: row q of Lam (from R, broadcast reads) and of
+// Z into the exchange arrays, then packed columns q and 15 + q; lane 15: column 30 by the same code applied to -y.  The
+// packed triangle is written WITHOUT predicates: a lane stores all 15 entries of its runs, what lies beyond its diagonal
+// falls into a later column's space and is overwritten by its owner, who stores later (hsn / tests/hostsim pin the order).
+// 18.8 KB of LDS and <= 256 registers per wavefront: two wavefronts per SIMD.  History: round 2 formed 31 whitened columns
+// and 496 length-15 dot products (4 362 instructions per wavefront of 4 factors, 1 wavefront per SIMD: 3.4 ms per 1 M
+// factors); a first block version with 5 lanes per factor and 12 factors per wavefront was correct and cut the arithmetic
+// 2.3x but sat at one wavefront per SIMD with 154 doubles of results per lane (2.17 ms).
 constexpr int HESS_PACKED = 496;
+// Row q of Lam = R^T R with lane q of a 16-lane DPP row holding column q of R (own[k] = R[k][q], zeros below the diagonal):
+// Lam[q][c] = sum_{k <= c} R[k][q] R[k][c], and R[k][c] is register own[k] of lane c -- a DPP row_share broadcast (two
+// v_mov_b32_dpp) instead of 120 LDS reads per lane: the LDS pipe of a CU, shared by its eight wavefronts, is what bounds
+// this kernel.  Same terms in the same order as hsn::lambda_row (the host twin).
+template <int C>
+__device__ __forceinline__ void lambda_row_dpp(const double (&own)[15], double (&l)[15]) {
+    if constexpr (C < 15) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k <= C; k++) a = fma(own[k], row_share<C>(own[k]), a);
+        l[C] = a;
+        lambda_row_dpp<C + 1>(own, l);
+    }
+}
 template <int MODEL>
-__global__ __launch_bounds__(64, 1) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
-    constexpr int LPF = 16, FPW = 4, IN_D = fin::IN_D, CP = 16;   // CP: LDS pitch of a whitened column (15 used, 16-B aligned)
-    // the packed output stage re-uses the input records and the R matrices: both are dead once the whitened columns sit
-    // in sA (one wavefront per workgroup: program order + the LDS fence below order the re-use) -- 32 KB instead of 43
-    constexpr int IO_D = (FPW * IN_D + FPW * 225 > FPW * HESS_PACKED) ? FPW * IN_D + FPW * 225 : FPW * HESS_PACKED;
-    __shared__ __attribute__((aligned(16))) double sIO[IO_D];
-    __shared__ __attribute__((aligned(16))) double sA[FPW * 31 * CP];   // [factor][column][row]
-    double *sIn = sIO, *sR = sIO + FPW * IN_D, *sP = sIO;
+__global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
+    using namespace hsn;
+    constexpr int FPW = 4, IN_D = fin::IN_D;
+    // [input records -> R -> zx] | lam | block tables; at the end everything is dead and becomes the output stage
+    constexpr int U1 = FPW * MAT_D;
+    static_assert(FPW * IN_D <= U1 && FPW * 225 <= U1, "the exchange area re-uses the input records and the R matrices");
+    __shared__ __attribute__((aligned(16))) double sAll[2 * U1 + FPW * BLK_D];
+    __shared__ double sDummy[2];
+    static_assert(FPW * HESS_PACKED + 64 <= 2 * U1 + FPW * BLK_D, "stage area");
+    double *sU1 = sAll, *sLam = sAll + U1, *sBlk = sAll + 2 * U1;
     const int lane = threadIdx.x;
-    const int q = lane % LPF, fl = lane / LPF;
     const long long f0 = (long long)blockIdx.x * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
-    factor_fetch_inputs<MODEL, FPW, true>(A, f0, nf, lane, sIn, sR);
+    const int q = lane & 15, f = min(lane >> 4, nf - 1);     // missing factors shadow the last one (same values, same slots)
+    const int qr = min(q, 14);                               // lane 15 shadows row 14 in the row phase
+
+    // ---- the input records (one round trip).  R follows after the block tables: its 30 registers would not survive the
+    // shared algebra at two wavefronts per SIMD, and the neighbour wavefront covers the second round trip
+    constexpr int RT = (FPW * 225 + 63) / 64;
+    factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sU1, sDummy);
     __syncthreads();
-    const double *in = sIn + fl * IN_D;
-    const FactorMeas m = factor_meas_of(in, A.grav);
-    const double *Rf = sR + fl * 225;
-    double *Af = sA + fl * 31 * CP;
-    auto whiten_col = [&](double *h) {   // in place: out[i] = sum_{k >= i} R[i][k] h[k]  (R upper triangular, column-major)
-#pragma unroll
-        for (int i = 0; i < 15; i++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int k = i; k < 15; k++) acc = fma(Rf[k * 15 + i], h[k], acc);
-            h[i] = acc;
-        }
-    };
-    FactorShared S;
+
+    // ---- block table of the factor: the state-dependent blocks (three column tasks), the measurement's bias Jacobians,
+    // the residual
+    double *blk = sBlk + f * BLK_D;
     {
+        const FactorMeas m = factor_meas_of(sU1 + f * IN_D, A.grav);
+        FactorShared S;
         V3 e5[5];
         factor_shared_core<MODEL>(m, S, e5);
-        if (q == 15) {   // b = -R e
-            double h[15];
+        if (q < 3) state_blocks_column<MODEL>(S, m, q, blk);
+        else if (q == 3) {
+            stb(blk + B_JB, ldcm(m.J_beta)); stb(blk + B_JA, ldcm(m.J_alpha));
+            stb(blk + B_HB, ldcm(m.H_beta)); stb(blk + B_HA, ldcm(m.H_alpha));
+        } else if (q == 4) {
 #pragma unroll
-            for (int b = 0; b < 5; b++) { h[3 * b] = -e5[b].x; h[3 * b + 1] = -e5[b].y; h[3 * b + 2] = -e5[b].z; }
-            whiten_col(h);
-#pragma unroll
-            for (int i = 0; i < 15; i++) Af[30 * CP + i] = h[i];
+            for (int a = 0; a < 5; a++) { blk[B_ERR + 3 * a] = e5[a].x; blk[B_ERR + 3 * a + 1] = e5[a].y; blk[B_ERR + 3 * a + 2] = e5[a].z; }
+            blk[B_DT] = m.dt[0];
         }
-    }
-    if (q < 15) {
-        const Q4 qi = ldq(m.xi);
-        double h[15];
-        S.bc = q / 3; S.cc = q - 3 * S.bc;
-        S.u = unit(S.cc);
-        S.rku = qrot(qi, S.u);
-        factor_H1_column<MODEL>(S, m, h);
-        whiten_col(h);
-#pragma unroll
-        for (int i = 0; i < 15; i++) Af[q * CP + i] = h[i];
-        factor_H2_column(S, h);
-        whiten_col(h);
-#pragma unroll
-        for (int i = 0; i < 15; i++) Af[(15 + q) * CP + i] = h[i];
     }
     wave_lds_fence();
-    // ---- lane q: columns d1 = q and d2 = 30 - q (lane 15: d1 = d2 = 15) against every column c, broadcast from LDS
-    const int d1 = q, d2 = 30 - q;
-    double c1[15], c2[15];
+    // the input records are dead: the R matrices of the wavefront (900 doubles, coalesced) take their place
+    {
+        double rr[RT];
 #pragma unroll
-    for (int i = 0; i < 15; i++) { c1[i] = Af[d1 * CP + i]; c2[i] = Af[d2 * CP + i]; }
-    double *Pf = sP + fl * HESS_PACKED;
-    const int o1 = d1 * (d1 + 1) / 2, o2 = d2 * (d2 + 1) / 2;
+        for (int t = 0; t < RT; t++) rr[t] = A.sqrt_info[f0 * 225 + min(lane + 64 * t, nf * 225 - 1)];
 #pragma unroll
-    for (int c = 0; c < 31; c++) {
-        double a1 = 0.0, a2 = 0.0;
+        for (int t = 0; t < RT; t++)
+            if (lane + 64 * t < FPW * 225) sU1[lane + 64 * t] = rr[t];
+    }
+    wave_lds_fence();
+
+    // ---- row phase: row q of Lam and of Z, y_q
+    double *lam = sLam + f * MAT_D, *zx = sU1 + f * MAT_D;
+    {
+        double l[15], z[15], y, own[15];
 #pragma unroll
-        for (int i = 0; i < 15; i++) {
-            const double x = Af[c * CP + i];   // same address for the 16 lanes of a factor: LDS broadcast
-            if (c <= 15) a1 = fma(x, c1[i], a1);   // column d1 <= 15 ends at its diagonal: rows 16..30 belong to other lanes
-            a2 = fma(x, c2[i], a2);
-        }
-        // results go to the packed output stage at once (62 accumulators would not fit the register file)
-        if (c <= d1) Pf[o1 + c] = a1;
-        if (c <= d2 && q != 15) Pf[o2 + c] = a2;
+        for (int k = 0; k < 15; k++) own[k] = sU1[f * 225 + qr * 15 + k];
+        lambda_row_dpp<0>(own, l);
+        z_row(l, blk, z, y);
+        wave_lds_fence();     // every lane has read R before the area becomes zx
+#pragma unroll
+        for (int c = 0; c < 15; c++) { lam[qr * ROWP + c] = l[c]; zx[qr * ROWP + c] = z[c]; }
+        zx[qr * ROWP + 15] = y;
+    }
+    wave_lds_fence();
+
+    // ---- column phase: everything the lane stores, into registers (the exchange arrays and the block table die here)
+    double g[15], u[15], t[15], fq;
+    lane_columns(q, lam, zx, blk, g, u, t, fq);
+    wave_lds_fence();
+
+    // ---- out through the stage: the four factors' packed triangles are one contiguous 15.9 KB run of the output
+    double *st = sAll + f * HESS_PACKED;
+    double *trash = sAll + FPW * HESS_PACKED + lane;
+    {
+        double *pg = st + ((q < 15) ? pk(0, q) : pk(0, 30));
+        double *pt = st + ((q < 15) ? pk(15, 15 + q) : pk(15, 30));
+        double *pu = (q < 15) ? st + pk(0, 15 + q) : trash;
+#pragma unroll
+        for (int r = 14; r >= 0; r--) pg[r] = g[r];        // descending: the owner of an entry stores it after every trespasser
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 15; r++) pt[r] = t[r];
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 15; r++) (q < 15 ? pu + r : trash)[0] = u[r];
+        *((q == 15) ? st + pk(30, 30) : trash) = fq;
     }
     wave_lds_fence();
     struct __attribute__((packed, aligned(8))) d2u { double a, b; };
     d2u *dst = reinterpret_cast<d2u *>(hess + f0 * HESS_PACKED);
-    for (int i = lane; i < nf * (HESS_PACKED / 2); i += 64) { d2u v; v.a = sP[2 * i]; v.b = sP[2 * i + 1]; dst[i] = v; }
+    for (int idx = lane; idx < nf * (HESS_PACKED / 2); idx += 64) {
+        d2u v; v.a = sAll[2 * idx]; v.b = sAll[2 * idx + 1];
+        dst[idx] = v;
+    }
 }
 
 template <int MODEL>

@@ -28,6 +28,17 @@
 #else
 #define CPI_SCHED_FENCE() ((void)0)
 #endif
+// A fence that PINS results: instruction selection orders only memory operations along fences, the arithmetic
+// between them floats (hipcc issued the loads of every step of hsn::h1t_vec first -- the whole block table, 216
+// registers -- and all the arithmetic after the last fence).  An asm statement that takes a step's results as in / out
+// operands must follow their computation and, being volatile with a memory clobber, precedes the next step's loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CPI_PIN3(a, b, c) do { asm volatile("" : "+v"(a), "+v"(b), "+v"(c) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CPI_PIN1(a) do { asm volatile("" : "+v"(a) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CPI_PIN3(a, b, c) ((void)0)
+#define CPI_PIN1(a) ((void)0)
+#endif
 
 namespace cpi {
 
@@ -1136,6 +1147,188 @@ CPI_HD void factor_eval_col(const FactorMeas &f, int c, double &err_c, double h1
     factor_H1_column<MODEL>(S, f, h1);
     factor_H2_column(S, h2);
 }
+
+// ---- Hessian blocks of a factor by 3x3 BLOCK algebra (cpi_factor_hessian_kernel) ----------------
+// What a GTSAM HessianFactor built from the linearised factor holds: M = [A1 A2 b]^T [A1 A2 b], A = R H, b = -R e
+// (include/cpi_amd.h: cpi_factor_hessian_batch).  With Lam = R^T R (the information matrix P^-1) this is
+//     M = Hc^T Lam Hc,   Hc = [H1 H2 -e]  (15 x 31),
+// and the Jacobians are SPARSE in 3x3 blocks (ImuFactorCPIv1.cpp:109-143,169-185; rows / columns theta, b_g, v, b_a, p):
+//     H1 = [ B    C     0      0     0  ]        H2 = blkdiag(A, I, Rk, I, Rk)
+//          [ 0   -I     0      0     0  ]        B = H1(0,0)  C = H1(0,3)  E = H1(6,0)  F = H1(12,0)  A = H2(0,0)
+//          [ E   -Jb   -Rk    -Hb    0  ]        Rk = R(q_GtoK); Jb, Ja, Hb, Ha = the measurement's bias Jacobians
+//          [ 0    0     0     -I     0  ]
+//          [ F   -Ja  -dt Rk  -Ha   -Rk ]
+// so a row of Z = Lam H1 costs ten 3-vector x block products (90 FMAs) instead of 225, a column of G11 = H1^T Z another ten,
+// the columns of G12 = (Lam H1)^T H2 and G22 = H2^T Lam H2 are combinations of three rows of Z / Lam with one column of a
+// diagonal block of H2: ~3.5 k FMAs per factor where the dense route (31 whitened columns, 496 length-15 dot products)
+// spends 11 k.
+// ONE LANE PER ROW / COLUMN: lane q < 15 of a factor owns row q of Lam and of Z, then packed columns q and 15 + q of the
+// result; lane 15 owns column 30 (g, f), which is the SAME arithmetic applied to -y = -Lam e instead of a column of Z.  The
+// exchange (rows -> columns) goes through the arrays lam / zx (LDS on the device, host memory in tests/hostsim): 15 rows
+// pitched 16 doubles, column 15 of zx holds y.  The functions below are a lane's arithmetic; block table `blk` per factor:
+namespace hsn {
+static const int B_B = 0, B_C = 9, B_E = 18, B_F = 27, B_A = 36, B_RK = 45, B_JB = 54, B_JA = 63, B_HB = 72, B_HA = 81,
+                 B_ERR = 90, B_DT = 105, BLK_D = 108;       // 3x3 blocks ROW-major; residual e[15]; dt; 2 of padding
+static const int ROWP = 18, MAT_D = 15 * ROWP;              // lam / zx: 15 rows pitched 18 doubles = 36 dwords.  Rows stay 16-byte aligned, the
+                                                            // sixteen lanes of a factor WRITE their rows to sixteen different 4-bank groups (q * 36 mod
+                                                            // 64: pitch 16 put them on two -- an 8-way conflict), the five block rows a column phase reads
+                                                            // start on different banks, and the four factors of a wavefront (270 doubles = 28 mod 64 apart) too
+static const int OUT_D = 496;
+
+CPI_HD M3 ldb(const double *p) {
+    M3 A;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) A.m[r][c] = p[r * 3 + c];
+    return A;
+}
+CPI_HD void stb(double *p, const M3 &A) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) p[r * 3 + c] = A.m[r][c];
+}
+// The state-dependent blocks, one column at a time: column cc of B, C, E, F, A and Rk (what factor_H1_column /
+// factor_H2_column put into columns cc and 3 + cc of H1 and column cc of H2), written into the row-major block table.
+template <int MODEL>
+CPI_HD void state_blocks_column(const FactorShared &S0, const FactorMeas &f, int cc, double *blk) {
+    const V3 u = unit(cc);
+    const V3 rku = qrot(ldq(f.xi), u);
+    const V3 qnv = mk(S0.q_n.x, S0.q_n.y, S0.q_n.z), qmv = mk(S0.q_m.x, S0.q_m.y, S0.q_m.z);
+    const V3 tt = -(qLmul(S0.q_n, -1.0, qLmul(S0.q_m, -1.0, u)) + dot(qmv, u) * qnv);       // H1(0,0)
+    const V3 tg = qLmul(S0.q_rminus, -1.0, colcm(f.J_q, cc));                               // H1(0,3)
+    V3 vt = cross(S0.Rb, u), pt = cross(S0.Ra, u);                                          // H1(6,0), H1(12,0)
+    if (MODEL == 2) {
+        const V3 Lu = qLmul(S0.q_kR, +1.0, u);
+        vt = vt - mulcm(f.O_beta, Lu);
+        pt = pt - mulcm(f.O_alpha, Lu);
+    }
+    const V3 ta = qLmul(S0.q_r, +1.0, u);                                                   // H2(0,0)
+    const V3 col[6] = { tt, tg, vt, pt, ta, rku };
+    const int at[6] = { B_B, B_C, B_E, B_F, B_A, B_RK };
+#pragma unroll
+    for (int k = 0; k < 6; k++) { blk[at[k] + cc] = col[k].x; blk[at[k] + 3 + cc] = col[k].y; blk[at[k] + 6 + cc] = col[k].z; }
+}
+// row q of Lam = R^T R; R column-major 15 x 15, upper triangular WITH its zeros stored (the contract of
+// cpi_sqrt_information_batch): Lam[q][c] = sum_{k <= c} R[k][q] R[k][c], the terms k > q vanish with R[k][q]
+CPI_HD void lambda_row(const double *R, int q, double l[15]) {
+    double own[15];
+#pragma unroll
+    for (int k = 0; k < 15; k++) own[k] = R[q * 15 + k];
+#pragma unroll
+    for (int c = 0; c < 15; c++) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k <= c; k++) a = fma(own[k], R[c * 15 + k], a);     // R[c * 15 + k]: the same address for the lanes of a factor
+        l[c] = a;
+    }
+}
+// v^T M as a vector (= M^T v), M a row-major block in memory
+CPI_HD V3 vTm(V3 v, const double *M) { return mulT(ldb(M), v); }
+// row q of Z = Lam H1 from row q of Lam, and y_q = (Lam e)_q
+CPI_HD void z_row(const double l[15], const double *blk, double z[15], double &y) {
+    const V3 lt = ldv(l), lg = ldv(l + 3), lv = ldv(l + 6), la = ldv(l + 9), lp = ldv(l + 12);
+    put3(z + 0, vTm(lt, blk + B_B) + vTm(lv, blk + B_E) + vTm(lp, blk + B_F));
+    CPI_PIN3(z[0], z[1], z[2]);
+    put3(z + 3, (vTm(lt, blk + B_C) - lg) - (vTm(lv, blk + B_JB) + vTm(lp, blk + B_JA)));
+    CPI_PIN3(z[3], z[4], z[5]);
+    {
+        const M3 Rk = ldb(blk + B_RK);
+        put3(z + 6, -mulT(Rk, axpy(blk[B_DT], lp, lv)));
+        put3(z + 12, -mulT(Rk, lp));
+    }
+    CPI_PIN3(z[6], z[7], z[8]);
+    CPI_PIN3(z[12], z[13], z[14]);
+    put3(z + 9, -((vTm(lv, blk + B_HB) + vTm(lp, blk + B_HA)) + la));
+    CPI_PIN3(z[9], z[10], z[11]);
+    const double *e = blk + B_ERR;
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 15; c++) acc = fma(l[c], e[c], acc);
+    y = acc;
+}
+// g = H1^T v for a 15-vector v (a column of Z: that column of G11; -y: the g1 part of column 30)
+CPI_HD void h1t_vec(const double v[15], const double *blk, double g[15]) {
+    const V3 vt = ldv(v), vg = ldv(v + 3), vv = ldv(v + 6), va = ldv(v + 9), vp = ldv(v + 12);
+    put3(g + 0, mulT(ldb(blk + B_B), vt) + mulT(ldb(blk + B_E), vv) + mulT(ldb(blk + B_F), vp));
+    CPI_PIN3(g[0], g[1], g[2]);
+    put3(g + 3, (mulT(ldb(blk + B_C), vt) - vg) - (mulT(ldb(blk + B_JB), vv) + mulT(ldb(blk + B_JA), vp)));
+    CPI_PIN3(g[3], g[4], g[5]);
+    {
+        const M3 Rk = ldb(blk + B_RK);
+        put3(g + 6, -mulT(Rk, axpy(blk[B_DT], vp, vv)));
+        put3(g + 12, -mulT(Rk, vp));
+    }
+    CPI_PIN3(g[6], g[7], g[8]);
+    CPI_PIN3(g[12], g[13], g[14]);
+    put3(g + 9, -((mulT(ldb(blk + B_HB), vv) + mulT(ldb(blk + B_HA), vp)) + va));
+    CPI_PIN3(g[9], g[10], g[11]);
+}
+// column n of the diagonal block D_j of H2 (A, I, Rk, I, Rk)
+CPI_HD V3 h2_diag_col(const double *blk, int j, int n) {
+    const double *Ab = blk + B_A, *Rb = blk + B_RK;
+    const V3 a = mk(Ab[n], Ab[3 + n], Ab[6 + n]), r = mk(Rb[n], Rb[3 + n], Rb[6 + n]), u = unit(n);
+    return (j == 0) ? a : (((j & 1) != 0) ? u : r);
+}
+// out[c] = sum_m d[m] rows[(3 j + m) * ROWP + c]: column n of (block row j of a matrix)^T D_j -- applied to Z: a column
+// of G12; applied to Lam: the vector w below
+CPI_HD void rows_comb(const double *mat, int j, V3 d, double out[15]) {
+    const double *r0 = mat + (3 * j) * ROWP, *r1 = r0 + ROWP, *r2 = r1 + ROWP;
+#pragma unroll
+    for (int c0 = 0; c0 < 15; c0 += 5) {      // five columns at a time: 15 doubles of rows in flight, not 45
+#pragma unroll
+        for (int c = c0; c < c0 + 5; c++) out[c] = fma(d.z, r2[c], fma(d.y, r1[c], d.x * r0[c]));
+        CPI_PIN3(out[c0], out[c0 + 1], out[c0 + 2]);
+        CPI_PIN1(out[c0 + 3]); CPI_PIN1(out[c0 + 4]);
+    }
+}
+// t[3 i + m] = (D_i^T w_i)[m]: from w = (D_j^T Lam_j.)[n, :] the column of G22; from w = -y the g2 part of column 30
+CPI_HD void h2t_vec(const double w[15], const double *blk, double t[15]) {
+    put3(t + 0, mulT(ldb(blk + B_A), ldv(w)));
+    CPI_PIN3(t[0], t[1], t[2]);
+    put3(t + 3, ldv(w + 3));
+    const M3 Rk = ldb(blk + B_RK);
+    put3(t + 6, mulT(Rk, ldv(w + 6)));
+    put3(t + 9, ldv(w + 9));
+    put3(t + 12, mulT(Rk, ldv(w + 12)));
+    CPI_PIN3(t[6], t[7], t[8]);
+    CPI_PIN3(t[12], t[13], t[14]);
+}
+// position of entry (r, d), r <= d, in the packed upper triangle
+CPI_HD int pk(int r, int d) { return r + d * (d + 1) / 2; }
+// Everything lane q (0 .. 15) stores, from the exchange arrays: g[15] = rows 0 .. 14 of packed column q (q = 15: of column
+// 30), u[15] = rows 0 .. 14 of packed column 15 + q (unused for q = 15), t[15] = rows 15 .. 29 of that column (q = 15: of
+// column 30), f = entry (30, 30) (meaningful for q = 15 only).  Of g and t a lane q < 15 owns the entries r <= q.
+CPI_HD void lane_columns(int q, const double *lam, const double *zx, const double *blk, double g[15], double u[15], double t[15], double &f) {
+    const int j = (q < 15) ? q / 3 : 0, n = (q < 15) ? q - 3 * j : 0;
+    const double sgn = (q == 15) ? -1.0 : 1.0;
+    // Three independent results, fenced apart, the one with the largest temporaries (three blocks of H1 at a time) FIRST,
+    // while nothing else is live: computed last it pushed the kernel past 256 registers (476 bytes of scratch per lane, and
+    // scratch at this scale is HBM traffic: 10 GB per million factors with the first version).
+    {
+        double zc[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) zc[k] = sgn * zx[k * ROWP + q];       // column q of Z; for q = 15: -y
+        h1t_vec(zc, blk, g);
+        const double *e = blk + B_ERR;
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 15; c++) acc = fma(e[c], zc[c], acc);
+        f = -acc;
+        CPI_PIN1(f);
+    }
+    const V3 d = h2_diag_col(blk, j, n);
+    {
+        double w[15];
+        rows_comb(lam, j, d, w);
+#pragma unroll
+        for (int c = 0; c < 15; c++) w[c] = (q == 15) ? -zx[c * ROWP + 15] : w[c];      // lane 15: w = -y
+        h2t_vec(w, blk, t);
+    }
+    rows_comb(zx, j, d, u);
+}
+}  // namespace hsn
 
 // State prediction (GraphSolver_IMU.cpp:263-281 / 289-307).
 template <int MODEL>

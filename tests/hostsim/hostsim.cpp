@@ -286,6 +286,55 @@ extern "C" void hs_factor(int model, long F, const double *rec, const double *xi
         }
     }
 }
+// Hessian blocks by 3x3 block algebra (cpi_math.hpp: hsn), the sixteen lanes of a factor run one after the other exactly
+// as cpi_factor_hessian_kernel runs them side by side: block table from the shared algebra, rows of Lam and Z into the
+// exchange arrays, then a packed column (or two) per lane, stored with the kernel's own "no predicate" order.
+// R [F][225] column-major upper triangular; out [F][496] packed upper triangle.
+template <int MODEL>
+static void hessian_factor(const FactorMeas &f, const double *R, double *out) {
+    using namespace hsn;
+    double blk[BLK_D] = {0}, lam[MAT_D], zx[MAT_D];
+    FactorShared S;
+    V3 e5[5];
+    factor_shared_core<MODEL>(f, S, e5);
+    for (int cc = 0; cc < 3; cc++) state_blocks_column<MODEL>(S, f, cc, blk);
+    stb(blk + B_JB, ldcm(f.J_beta)); stb(blk + B_JA, ldcm(f.J_alpha)); stb(blk + B_HB, ldcm(f.H_beta)); stb(blk + B_HA, ldcm(f.H_alpha));
+    for (int a = 0; a < 5; a++) { blk[B_ERR + 3 * a] = e5[a].x; blk[B_ERR + 3 * a + 1] = e5[a].y; blk[B_ERR + 3 * a + 2] = e5[a].z; }
+    blk[B_DT] = f.dt[0];
+    for (int q = 0; q < 15; q++) {
+        double l[15], z[15], y;
+        lambda_row(R, q, l);
+        z_row(l, blk, z, y);
+        for (int c = 0; c < 15; c++) { lam[q * ROWP + c] = l[c]; zx[q * ROWP + c] = z[c]; }
+        lam[q * ROWP + 15] = 0.0; zx[q * ROWP + 15] = y;
+    }
+    double g[16][15], u[16][15], t[16][15], fq[16];
+    for (int q = 0; q < 16; q++) lane_columns(q, lam, zx, blk, g[q], u[q], t[q], fq[q]);
+    double trash[64];
+    // the store order of the kernel: a lane writes ALL 15 entries of its triangular runs; what lies beyond its diagonal
+    // lands in a later column's space and is overwritten by the owner, who stores afterwards (descending rows for g; the
+    // t runs before the u runs)
+    for (int r = 14; r >= 0; r--)
+        for (int q = 0; q < 16; q++) out[(q < 15 ? pk(0, q) : pk(0, 30)) + r] = g[q][r];
+    for (int r = 0; r < 15; r++)
+        for (int q = 0; q < 16; q++) out[(q < 15 ? pk(15, 15 + q) : pk(15, 30)) + r] = t[q][r];
+    for (int r = 0; r < 15; r++)
+        for (int q = 0; q < 16; q++) (q < 15 ? out + pk(0, 15 + q) : trash)[r] = u[q][r];
+    out[pk(30, 30)] = fq[15];
+}
+extern "C" void hs_hessian(int model, long F, const double *rec, const double *xi, const double *xj, const double *R, double *out) {
+    for (long k = 0; k < F; k++) {
+        const double *r = rec + k * 87;
+        FactorMeas f;
+        f.alpha = r; f.beta = r + 3; f.q_KtoK1 = r + 6;
+        double lin6[6] = { r[13], r[14], r[15], r[10], r[11], r[12] };
+        f.lin = lin6;
+        f.J_q = r + 16; f.J_beta = r + 25; f.J_alpha = r + 34; f.H_beta = r + 43; f.H_alpha = r + 52;
+        f.dt = r + 61; f.grav = ld3(r + 62); f.q_K_lin = r + 65; f.O_beta = r + 69; f.O_alpha = r + 78;
+        f.xi = xi + k * 16; f.xj = xj + k * 16;
+        if (model == 1) hessian_factor<1>(f, R + k * 225, out + k * 496); else hessian_factor<2>(f, R + k * 225, out + k * 496);
+    }
+}
 extern "C" void hs_predict(int model, long F, const double *rec, const double *xi, double *xj) {
     for (long k = 0; k < F; k++) {
         const double *r = rec + k * 87, *p = xi + k * 16;

@@ -51,6 +51,14 @@ def factor(model, rec, xi, xj):
     return err, H1, H2
 
 
+def hessian(model, rec, xi, xj, R):
+    """[F, 496] packed upper triangle of [A1 A2 b]^T [A1 A2 b] by the kernel's 3x3 block algebra; R [F, 225] column-major."""
+    F = rec.shape[0]
+    out = np.full((F, 496), np.nan)
+    lib().hs_hessian(model, C.c_long(F), dp(rec), dp(xi), dp(xj), dp(np.ascontiguousarray(R)), dp(out))
+    return out
+
+
 def predict(model, rec, xi):
     xj = np.zeros_like(xi)
     lib().hs_predict(model, C.c_long(rec.shape[0]), dp(rec), dp(xi), dp(xj))

@@ -43,10 +43,9 @@ def test_comparator_vs_restatement_on_the_golden_inputs(eng, orc, golden_dir, fn
     assert set(out) == {"DT", "alpha", "beta", "q", "J_q", "J_a", "J_b", "H_a", "H_b", "P"}
     ref = orc.oracle().run(orc.make_params(FORSTER), d["knots"], d["lin"])
     check_pre(out, ref, label=fname)
-    # same algorithm, different operation order / block order: far inside the gates
-    for k in ("DT", "alpha", "beta", "q", "J_q", "J_a", "J_b", "H_a", "H_b"):
-        assert np.abs(out[k] - ref[k]).max() < 1e-12, k
-    assert cov_rel_err(out["P"], ref["P"]) < 1e-11
+    # same algorithm, different operation order / block order: the regression gates ("nothing moved": 100 x the floor
+    # measured on MI355X, tests/tol.py) -- the restatement is what pins this row (GTSAM is absent: parity unpinned)
+    check_pre(out, ref, label=fname + " (regression)", regression="forster")
 
 
 @pytest.mark.parametrize("W,N", [(1, 1), (3, 16), (5, 17), (257, 50), (64, 100), (7, 333)])
@@ -54,7 +53,7 @@ def test_comparator_vs_restatement_seeded_shapes(eng, orc, W, N):
     kn, lin, _ = synth.make_windows(W, N, seed=900 + W + N)
     out = _host(eng.preintegrate(kn.to(eng.device), lin.to(eng.device), None, eng.make_params(FORSTER)))
     ref = orc.oracle().run(orc.make_params(FORSTER), kn.numpy(), lin.numpy())
-    check_pre(out, ref, label="W%d N%d" % (W, N))
+    check_pre(out, ref, label="W%d N%d" % (W, N), regression="forster")
 
 
 def test_partial_outputs_and_other_sigmas(eng, orc):

@@ -41,6 +41,11 @@ def test_sqrt_information_and_whitened_sweep(eng, model):
     Rn = np.stack([np.linalg.cholesky(np.linalg.inv(P[f])).T for f in range(F)])
     scale = np.abs(Rn).max(axis=(1, 2))[:, None, None]
     assert (np.abs(Rg - Rn) / scale).max() < 1e-6
+    # (3b) regression gate ("nothing moved"): against the same factorisation carried out in longdouble, relative to the
+    # largest entry of the factor's R -- measured floor 3.5e-16 on MI355X (LAPACK's f64 result itself: 2.3e-16)
+    from tests.tol import REG_SQRT_INFO, sqrt_info_longdouble
+    Rl = sqrt_info_longdouble(P)
+    assert (np.abs(Rg - Rl) / np.abs(Rl).max(axis=(1, 2))[:, None, None]).max() < REG_SQRT_INFO
     # (4) whitened sweep = R @ unwhitened sweep
     e = plain["err"].cpu().numpy(); H1 = plain["H1"].cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1)
     H2 = plain["H2"].cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1)
@@ -67,9 +72,40 @@ def test_sqrt_information_well_conditioned_and_not_positive_definite(eng):
     Rg = R.cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1)
     ok = [f for f in range(F) if f != 6]
     Rn = np.stack([np.linalg.cholesky(np.linalg.inv(P[f])).T for f in ok])
-    assert np.abs(Rg[ok] - Rn).max() < 1e-13
+    assert np.abs(Rg[ok] - Rn).max() < 1e-13                # well-conditioned: LAPACK is the reference, to rounding
     assert np.array_equal(Rg[4], np.eye(15))
     assert np.isnan(Rg[6]).any()
+
+
+@pytest.mark.parametrize("F", [1, 5, 12, 13, 700])
+def test_hessian_blocks_ragged_grid_and_unwritten_neighbours(eng, F):
+    """Twelve factors per wavefront, the last wavefront ragged: every factor complete, nothing written past F (the output
+    buffer is allocated larger and pre-filled), chained states, both models; equal to the F = whole-batch run bit for bit."""
+    kn, lin, q = synth.make_windows(F, 20, seed=300 + F, device=eng.device, edge_cases=False)
+    for model in (1, 2):
+        meas = eng.preintegrate(kn, lin, q, eng.make_params(model))
+        R = eng.sqrt_information(meas["P"])
+        xi, xj = synth.make_states(meas["alpha"], meas["beta"], meas["q"], meas["DT"], lin, model, device=eng.device)
+        states = torch.cat([xi, xj[-1:]], dim=0).contiguous()
+        qq = q if model == 2 else None
+        big = torch.full((F + 3, 496), -7.0, dtype=torch.float64, device=eng.device)
+        eng.factor_hessian(model, meas, lin, qq, states, R, out=big[:F])
+        white = eng.factor_eval(model, meas, lin, qq, states, sqrt_info=R)
+        torch.cuda.synchronize()
+        assert torch.all(big[F:] == -7.0)
+        A1 = white["H1"].cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1)
+        A2 = white["H2"].cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1)
+        Ab = np.concatenate([A1, A2, -white["err"].cpu().numpy()[:, :, None]], axis=2)
+        ref = np.einsum("fki,fkj->fij", Ab, Ab)
+        want = np.stack([ref[:, i, d] for d in range(31) for i in range(d + 1)], axis=1)
+        got = big[:F].cpu().numpy()
+        assert (np.abs(got - want) / np.abs(want).max(axis=1, keepdims=True)).max() < 1e-12, (model, F)
+        if F > 12:      # a factor's result does not depend on where it sits in the wavefront
+            sl = slice(7, F)
+            part = eng.factor_hessian(model, {k: v[sl].contiguous() for k, v in meas.items()}, lin[sl].contiguous(),
+                                      None if qq is None else qq[sl].contiguous(), states[7:].contiguous(), R[sl].contiguous())
+            torch.cuda.synchronize()
+            assert torch.equal(part, big[7:F])
 
 
 @pytest.mark.parametrize("model", [1, 2])

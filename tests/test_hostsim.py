@@ -91,3 +91,29 @@ def test_nan_separated_windows_kernel_math(model, avg):
     if model == 1:
         out = op.split_out(hs.mean(1, 1, avg, 1, kn, lin, q))
         check_pre(out, ref, what=("mean", "jac"), regression=True)
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_hessian_block_algebra_equals_the_dense_definition(model):
+    """cpi_factor_hessian_kernel's arithmetic (cpi_math.hpp: hsn -- Lam = R^T R by row blocks, Z = Lam H1 through H1's 13
+    non-zero 3x3 blocks, G11 = H1^T Z, G12 / G22 through H2's block diagonal) run lane by lane on the host, against the
+    dense definition [R H1, R H2, -R e]^T [R H1, R H2, -R e] built from the column functions of the dense sweep: the block
+    table (signs, transposes, the dt Rk block) and the packed indexing are pinned here, on the golden factor cases."""
+    import os
+    d = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "factor_256.npz")))
+    rec, xi, xj = d["v%d_rec" % model], d["v%d_xi" % model], d["v%d_xj" % model]
+    F = rec.shape[0]
+    rng = np.random.default_rng(7 + model)
+    A = rng.standard_normal((F, 15, 15))
+    P = A @ A.transpose(0, 2, 1) + 15.0 * np.eye(15)
+    R = np.stack([np.linalg.cholesky(np.linalg.inv(P[f])).T for f in range(F)])          # upper triangular, [row][col]
+    Rcm = np.ascontiguousarray(R.transpose(0, 2, 1)).reshape(F, 225)                      # column-major
+    err, H1, H2 = hs.factor(model, rec, xi, xj)
+    H1 = H1.reshape(F, 15, 15).transpose(0, 2, 1); H2 = H2.reshape(F, 15, 15).transpose(0, 2, 1)
+    Ab = np.concatenate([R @ H1, R @ H2, -(R @ err[:, :, None])], axis=2)                 # [F, 15, 31]
+    M = np.einsum("fki,fkj->fij", Ab, Ab)
+    want = np.stack([M[:, i, dd] for dd in range(31) for i in range(dd + 1)], axis=1)
+    got = hs.hessian(model, rec, xi, xj, Rcm)
+    assert got.shape == (F, 496) and np.all(np.isfinite(got))
+    scale = np.abs(want).max(axis=1, keepdims=True)
+    assert (np.abs(got - want) / scale).max() < 1e-13

@@ -16,6 +16,15 @@ REG_MEAN = 2e-13
 REG_COV = 2e-13
 REG_JAC = 3e-11
 REG_FACTOR = 1e-12   # evaluateError on the golden cases vs the restatement (measured floor 2e-14 on O(10) entries)
+# SURVEY 8(f) rows (round 3; floors measured on MI355X with tests/tools/measure_floors.py, gates = ~100 x):
+#   f4 Forster comparator, HIP (sparse, permuted, one exchange) vs the dense restatement oracle/forster_oracle.c on the
+#      golden + seeded inputs: means <= 8.9e-15, bias Jacobians <= 2.9e-15, covariance <= 9.7e-15 relative
+#   f1 square-root information on the realistic covariances (cond ~1e8), HIP vs the longdouble restatement
+#      (sqrt_info_longdouble below), relative to max |R| of the factor: 3.5e-16 (LAPACK's own f64 result: 2.3e-16)
+REG_FORSTER_MEAN = 1e-12
+REG_FORSTER_JAC = 3e-13
+REG_FORSTER_COV = 1e-12
+REG_SQRT_INFO = 5e-14
 
 
 def cov_rel_err(P, Pref):
@@ -34,8 +43,11 @@ def cov_rel_err(P, Pref):
 
 def check_pre(out, ref, what=("mean", "jac", "cov"), v2=False, label="", regression=False):
     """regression=True: the expected values come from the compiled reference on realistic inputs -- apply the
-    regression gates (100 x the measured floor) instead of the contractual ones."""
+    regression gates (100 x the measured floor) instead of the contractual ones.  regression="forster": the Forster
+    comparator against its restatement (its own measured floor)."""
     tol_mean, tol_jac, tol_cov = (REG_MEAN, REG_JAC, REG_COV) if regression else (TOL_MEAN, TOL_JAC, TOL_COV)
+    if regression == "forster":
+        tol_mean, tol_jac, tol_cov = REG_FORSTER_MEAN, REG_FORSTER_JAC, REG_FORSTER_COV
     msgs = []
     if "mean" in what:
         for k in ("DT", "alpha", "beta", "q"):
