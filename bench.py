@@ -79,6 +79,14 @@ WORKLOADS = {
     # the batches cut from one IMU stream by the device assembler (cpi_assemble_tiles) -- no dense copy, no cpi_tile_knots
     "v1_mean_tiled": dict(kind="tiled", model=1, want=("mean",), W=1000000, N=50, bytes=2856 + 88, kernel="cpi_mean_tiled_kernel<1,false,true,SPLIT>"),
     "v2_mean_tiled": dict(kind="tiled", model=2, want=("mean",), W=1000000, N=50, bytes=2888 + 88, kernel="cpi_mean_tiled_kernel<2,false,true,SPLIT>"),
+    # the zero-copy stream entry (cpi_preintegrate_stream): ONE resident IMU stream of W x N + 1 readings + W update times, the
+    # kernels cut the windows in place.  A window reads N new readings (the boundary reading is shared), its update time,
+    # lin, and its 28-byte workspace record twice (written by the cut kernel, read by the preintegration kernel)
+    "v1_mean_stream": dict(kind="stream", model=1, want=("mean",), W=1000000, N=50, bytes=2800 + 8 + 48 + 56 + 88, kernel="cpi_mean_kernel<1,false,false,L> (+ cpi_cut_windows_kernel)"),
+    "v1_full_stream": dict(kind="stream", model=1, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2800 + 8 + 48 + 56 + 2320, kernel="cpi_cov_kernel<1,false> (+ cut, Jacobian kernels)",
+                           useful_lanes=(15, 16)),
+    "v2_full_stream": dict(kind="stream", model=2, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2800 + 8 + 80 + 56 + 2392, kernel="cpi_cov_kernel<2,false> (+ cut kernel)",
+                           useful_lanes=(27, 32)),
     # BASELINE configs[4]: one GPU's share of 8 M windows x 100 samples (EuRoC-rate synthetic IMU), generated on the device
     "cfg5_mean": dict(kind="pre", model=1, want=("mean",), W=1000000, N=100, bytes=2856 + 88, kernel="cpi_mean_kernel<1,false,false,1>"),
     "cfg5_full": dict(kind="pre", model=1, want=("mean", "jac", "cov"), W=1000000, N=100, bytes=2856 + 2320, kernel="cpi_cov_kernel<1,false>",
@@ -93,7 +101,7 @@ def bytes_per_unit(workload, samples=50):
     """a window reads samples*56 + 8 + 48 (+32 for q_k_lin) bytes; WORKLOADS holds that figure at 50
     samples.  Factor-shaped workloads do not depend on the window length."""
     w = WORKLOADS[workload]
-    return w["bytes"] + (samples - 50) * 56 if w["kind"] in ("pre", "tiled") else w["bytes"]
+    return w["bytes"] + (samples - 50) * 56 if w["kind"] in ("pre", "tiled", "stream") else w["bytes"]
 
 
 def parse(argv=None):
@@ -126,7 +134,7 @@ class Workload:
         spec = WORKLOADS[name]
         self.name, self.W, self.N, self.spec = name, W, N, spec
         self.kind, self.model, self.variant = spec["kind"], spec["model"], spec.get("variant", "dense")
-        self.is_factor = self.kind != "pre" and self.kind != "tiled"       # unit = factor
+        self.is_factor = self.kind not in ("pre", "tiled", "stream")       # unit = factor
         self.eng, self.i, self.assembly = eng, 0, None
         dev = eng.device
         f64 = dict(dtype=torch.float64, device=dev)
@@ -194,6 +202,17 @@ class Workload:
                 tiles, count, lin, q = self.batches[i % self.nbatch]
                 call, _ = eng.preintegrate_tiled(tiles, W, lin, q, self.prm, count=count, out=self.outs[i % nsets], bind=True)
                 self.calls.append(call)
+            return
+        if self.kind == "stream":
+            # phase 0.4: every window ends in a partial tail interval (N whole intervals + the tail = N + 1 per window,
+            # the reference's general case); a step = cut kernel + preintegration kernel(s), nothing copied
+            self.batches = [synth.make_stream(W, N, seed=seed + 101 * b, device=dev, phase=0.4) for b in range(self.nbatch)]
+            self.ws = [eng.stream_workspace(W) for _ in range(self.nbatch)]
+            for i in range(period):
+                stream, upd, lin, q = self.batches[i % self.nbatch]
+                o, w_ = self.outs[i % nsets], self.ws[i % self.nbatch]
+                self.calls.append(lambda stream=stream, upd=upd, lin=lin, q=q, o=o, w_=w_: eng.preintegrate_stream(
+                    stream, upd, lin, q, self.prm, want=self.want, N=N + 1, out=o, check_counts=False, workspace=w_))
             return
         self.batches = [synth.make_windows(W, N, seed=seed + 101 * b, device=dev) for b in range(self.nbatch)]
         # every (batch, output set) pair of the walk pre-bound: a step is one foreign call (Engine.bind_preintegrate)
@@ -631,7 +650,8 @@ EXTRA_ROWS = (("v1_mean", 30000, 1000), ("v1_mean", 100000, 300), ("v1_mean", 10
               ("factor_v1_hessian", 1000000, 20), ("factor_v2_hessian", 1000000, 20),
               ("predict_v1", 1000000, 40), ("predict_v2", 1000000, 40),
               ("cfg5_mean", 1000000, 10), ("cfg5_full", 1000000, 3),
-              ("v1_mean_tiled", 1000000, 40), ("v2_mean_tiled", 1000000, 40), ("v1_mean_tiled", 10000, 1000))
+              ("v1_mean_tiled", 1000000, 40), ("v2_mean_tiled", 1000000, 40), ("v1_mean_tiled", 10000, 1000),
+              ("v1_mean_stream", 1000000, 40), ("v1_full_stream", 100000, 30), ("v2_full_stream", 100000, 30))
 
 
 def main():
@@ -675,7 +695,7 @@ def main():
     else:
         W = W_job
         total_units = W_job * world
-    is_factor = spec["kind"] not in ("pre", "tiled")
+    is_factor = spec["kind"] not in ("pre", "tiled", "stream")
     do_gather = dist_on and a.gather != "none" and not is_factor
     # schedule of the exchange: per-step, overlapped gathers pay when a step lasts long enough to hide one (>= ~1 ms:
     # covariance rows, million-window batches); the 10 k-window headline keeps the single final gather
@@ -752,7 +772,7 @@ def main():
                     asm = dict(w2.assembly)
                     asm["share_of_step"] = asm["ms_per_batch"] / (ls * 1e3)
                     row["assembly"] = asm
-                skip_cpu = name.endswith("_packed") or (name == "v1_mean" and Wx != 1000000) or (name.endswith("_tiled") and Wx != 1000000)
+                skip_cpu = name.endswith("_packed") or name.endswith("_stream") or (name == "v1_mean" and Wx != 1000000) or (name.endswith("_tiled") and Wx != 1000000)
                 if not a.no_cpu and not skip_cpu:
                     row["cpu_baseline"] = cpu_baseline(w2, 2.5)     # bounded: ~2.5 s of CPU work per row
                 extra.append(row)

@@ -50,7 +50,7 @@ def load():
     lib.cpi_abi_version.restype = C.c_int
     if lib.cpi_abi_version() != ABI_VERSION:
         raise ImportError("cpi_amd: %s has ABI version %d, this binding expects %d (stale build?)" % (LIB_PATH, lib.cpi_abi_version(), ABI_VERSION))
-    missing = [n for n in ("cpi_assemble_tiles", "cpi_tile_windows", "cpi_outputs_bind_slab", "cpi_preintegrate_tiled_batch_host")
+    missing = [n for n in ("cpi_preintegrate_stream", "cpi_assemble_tiles", "cpi_tile_windows", "cpi_outputs_bind_slab", "cpi_preintegrate_tiled_batch_host")
                if not hasattr(lib, n)]
     if missing:
         raise ImportError("cpi_amd: %s lacks %s (a build from before round 3: run python -m cpi_amd.build --force)" % (LIB_PATH, ", ".join(missing)))
@@ -77,6 +77,12 @@ def load():
     lib.cpi_preintegrate_batch.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, vp, dp, dp, C.POINTER(CpiOutputs)]
     lib.cpi_preintegrate_tiled_batch.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, dp, dp, C.POINTER(CpiOutputs)]
     lib.cpi_tile_knots.argtypes = [vp, i64, i32, dp, dp]
+    lib.cpi_stream_workspace_bytes.argtypes = [i64]
+    lib.cpi_stream_workspace_bytes.restype = C.c_size_t
+    lib.cpi_stream_counts.argtypes = [vp, i64]
+    lib.cpi_stream_counts.restype = C.c_void_p
+    lib.cpi_preintegrate_stream.argtypes = [vp, C.POINTER(CpiParams), i64, dp, i64, dp, i32, dp, dp, vp, C.POINTER(CpiOutputs)]
+    lib.cpi_preintegrate_stream.restype = C.c_int
     lib.cpi_tile_windows.argtypes = [vp, i64, i32, dp, vp, vp, dp]
     lib.cpi_assemble_tiles.argtypes = [vp, i64, dp, i64, dp, i32, dp, vp]
     lib.cpi_preintegrate_tiled_batch_host.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, dp, dp, C.POINTER(CpiOutputs)]

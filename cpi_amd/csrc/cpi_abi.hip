@@ -205,9 +205,17 @@ static PreArgs shift_windows(const PreArgs &a, long long w0) {
 }
 #endif
 
+static int preintegrate_impl(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *knots, const int64_t *first,
+                             const int32_t *count, const double *tstart, const double *tend, const double *lin,
+                             const double *q_k_lin, const cpi_outputs *out);
 extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
                                       const double *knots, const int64_t *first, const int32_t *count,
                                       const double *lin, const double *q_k_lin, const cpi_outputs *out) {
+    return preintegrate_impl(ctx, prm, W, N, knots, first, count, nullptr, nullptr, lin, q_k_lin, out);
+}
+static int preintegrate_impl(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *knots, const int64_t *first,
+                             const int32_t *count, const double *tstart, const double *tend, const double *lin,
+                             const double *q_k_lin, const cpi_outputs *out) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (!prm || !out) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: prm/out is NULL");
     if (prm->model != CPI_MODEL_V1 && prm->model != CPI_MODEL_V2 && prm->model != CPI_MODEL_FORSTER)
@@ -232,7 +240,7 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     PreArgs a;
     memset(&a, 0, sizeof a);
     a.W = W; a.N = N; a.knots = knots; a.first = (const long long *)first; a.count = count;
-    a.lin = lin; a.qk = q_k_lin;
+    a.lin = lin; a.qk = q_k_lin; a.tstart = tstart; a.tend = tend;
     for (int i = 0; i < 3; i++) a.grav[i] = prm->grav[i];
     a.q4[0] = prm->sigma_w * prm->sigma_w; a.q4[1] = prm->sigma_wb * prm->sigma_wb;
     a.q4[2] = prm->sigma_a * prm->sigma_a; a.q4[3] = prm->sigma_ab * prm->sigma_ab;
@@ -307,6 +315,43 @@ extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64
     }
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
+}
+
+// Replaces the caller-side loop of GraphSolver::createimufactor_cpi_v1 / _v2 (GraphSolver_IMU.cpp:43-75, 97-130) for ALL the
+// windows of a trajectory at once, with ZERO copies of the IMU data: cpi_cut_windows_kernel finds, per update time, where the
+// reference's deque would stand (28 bytes per window into the caller's workspace), and the preintegration kernels read the
+// stream in place, patching the first knot's stamp and building a partial tail interval from its predecessor in flight.
+static size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
+extern "C" size_t cpi_stream_workspace_bytes(int64_t U) {
+    if (U <= 0) return 16;
+    return align16((size_t)U * 8) * 3 + align16((size_t)U * 4);
+}
+extern "C" const int32_t *cpi_stream_counts(const void *workspace, int64_t U) {
+    if (!workspace || U <= 0) return nullptr;
+    return reinterpret_cast<const int32_t *>(static_cast<const char *>(workspace) + align16((size_t)U * 8) * 3);
+}
+extern "C" int cpi_preintegrate_stream(cpi_ctx *ctx, const cpi_params *prm, int64_t K, const double *stream, int64_t U,
+                                       const double *update_times, int32_t N, const double *lin, const double *q_k_lin,
+                                       void *workspace, const cpi_outputs *out) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (K < 0 || U < 0 || N < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: negative size");
+    if (U == 0) return CPI_OK;
+    if (K == 0) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: the stream is empty");
+    if (!stream || !update_times || !workspace) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: NULL argument");
+    if (((uintptr_t)workspace & 15) != 0) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: the workspace must be 16-byte aligned");
+    if (!grid_ok(U)) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: U exceeds 2^31 - 1 windows per call");
+    char *ws = static_cast<char *>(workspace);
+    long long *first = reinterpret_cast<long long *>(ws);
+    double *tstart = reinterpret_cast<double *>(ws + align16((size_t)U * 8));
+    double *tend = reinterpret_cast<double *>(ws + 2 * align16((size_t)U * 8));
+    int *count = reinterpret_cast<int *>(ws + 3 * align16((size_t)U * 8));
+    {
+        DeviceGuard guard_;
+        CPI_HIP(ctx, guard_.enter(ctx->device));
+        launch::cut_windows((long long)K, stream, (long long)U, update_times, (int)N, first, count, tstart, tend, ctx->stream);
+        CPI_HIP(ctx, hipGetLastError());
+    }
+    return preintegrate_impl(ctx, prm, U, N, stream, reinterpret_cast<const int64_t *>(first), count, tstart, tend, lin, q_k_lin, out);
 }
 
 // ============================================================================================

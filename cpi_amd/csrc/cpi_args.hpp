@@ -25,6 +25,12 @@ struct PreArgs {
     const int *count;
     const double *lin;
     const double *qk;
+    // Windows cut out of ONE IMU stream in flight (cpi_preintegrate_stream; GraphSolver_IMU.cpp:50-69): knots = the stream,
+    // first[w] = the front reading of window w, count[w] = whole intervals + the partial tail interval; knot 0 of the window
+    // carries the stamp tstart[w] instead of its own, and when tend[w] is not NaN the last interval is the tail
+    // [stamp of the last real knot, tend[w]] with that knot's reading held.  Both NULL: plain knots.
+    const double *tstart;
+    const double *tend;
     double grav[3];
     double q4[4];      // sigma^2 of the four diagonal blocks of Q_c (CpiBase.h:54-57)
     int write_means;   // kernel writes DT/alpha/beta/q
@@ -96,6 +102,8 @@ void mean(int model, bool jac, bool avg, int L, const PreArgs &a, hipStream_t st
 hipError_t mean_tiled(int model, bool avg, bool counted, int S, const TiledArgs &a, hipStream_t st, unsigned *big_lds_set);
 void tile_knots(long long W, int N, const double *knots, const long long *first, const int *count, double *tiles, hipStream_t st);
 void assemble_tiles(const AssembleArgs &a, hipStream_t st);
+void cut_windows(long long K, const double *stream, long long U, const double *update, int N, long long *first, int *count,
+                 double *tstart, double *tend, hipStream_t st);
 // ---- cpi_cov.hip
 void cov(int model, bool avg, const PreArgs &a, hipStream_t st);
 void forster(const PreArgs &a, hipStream_t st);

@@ -39,6 +39,9 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     const int n = A.count ? min(max(A.count[w], 0), A.N) : A.N;
     const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
     const int nmax = wave_max(n);
+    // windows cut out of a stream in flight (PreArgs::tstart / tend): see the knot loads of phase A
+    const bool cut = A.tstart != nullptr;
+    const bool tail = cut && (A.tend[w] == A.tend[w]) && (A.count[w] <= A.N);
 
     const double q4[4] = { A.q4[0], A.q4[1], A.q4[2], A.q4[3] };
 
@@ -75,8 +78,18 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                 const double *ka = A.knots + (k0 + s) * 7;
                 const V3 bw = ldv3(A.lin + wq * 6), ba = ldv3(A.lin + wq * 6 + 3);
                 double a[14];
+                if (!cut) {
 #pragma unroll
-                for (int i = 0; i < 14; i++) a[i] = ka[i];
+                    for (int i = 0; i < 14; i++) a[i] = ka[i];
+                } else {
+                    // the closing knot of a tail interval does not exist in memory: the opening reading held until tend
+                    const bool tl = tail && s == n - 1;
+                    const double *kb = tl ? ka : ka + 7;
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { a[i] = ka[i]; a[7 + i] = kb[i]; }
+                    if (s == 0) a[0] = A.tstart[wq];
+                    if (tl) a[7] = A.tend[wq];
+                }
                 r = make_sample_rec<MODEL, AVG>(a[0], a[7], mk(a[1], a[2], a[3]), mk(a[4], a[5], a[6]),
                                                 mk(a[8], a[9], a[10]), mk(a[11], a[12], a[13]), bw, ba);
             } else {  // padding: an exact no-op interval
@@ -261,6 +274,20 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
     const int n = A.count ? min(max(A.count[w], 0), A.N) : A.N;
     const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
     const int nmax = wave_max(n);
+    // windows cut out of a stream in flight (PreArgs::tstart / tend): the stamps of the first knot and of a tail interval's
+    // closing knot (which does not exist in memory) are patched where the knots are loaded
+    const bool cut = A.tstart != nullptr;
+    const bool tail = cut && (A.tend[w] == A.tend[w]) && (A.count[w] <= A.N);
+    auto load_knot = [&](double (&k)[8], int s) {      // reading of knot s and the stamp of knot s + 1
+        const double *ka = A.knots + (k0 + s) * 7;
+#pragma unroll
+        for (int i = 0; i < 7; i++) k[i] = ka[i];
+        if (!cut) { k[7] = ka[7]; return; }
+        const bool tl = tail && s == n - 1;
+        const double tnext = ka[tl ? 0 : 7];        // a tail interval has no closing knot in memory: the address stays inside
+        k[7] = tl ? A.tend[w] : tnext;
+        if (s == 0) k[0] = A.tstart[w];
+    };
 
     const double q4[4] = { A.q4[0], A.q4[1], A.q4[2], A.q4[3] };
     // per-lane constant vectors instead of selects inside the recursion
@@ -294,11 +321,7 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
     double kn[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) kn[i] = 0.0;
-    if (j < CH && j < n) {
-        const double *ka = A.knots + (k0 + j) * 7;
-#pragma unroll
-        for (int i = 0; i < 8; i++) kn[i] = ka[i];
-    }
+    if (j < CH && j < n) load_knot(kn, j);
     for (int base = 0; base < nmax; base += CH) {
         if (j < CH) {   // ---- phase A: lane (g, j) builds the record of interval base + j of its window
             const int s = base + j;
@@ -309,11 +332,7 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
                 r.dt = 0; r.qs = 0; r.a = mk(0, 0, 0); r.E = eye(); r.JD = zero3();
             }
             fsd::put_rec(irs + (g * CH + j) * IRD, r);
-            if (s + CH < n) {
-                const double *ka = A.knots + (k0 + s + CH) * 7;
-#pragma unroll
-                for (int i = 0; i < 8; i++) kn[i] = ka[i];
-            }
+            if (s + CH < n) load_knot(kn, s + CH);
         }
         wave_lds_fence();
 

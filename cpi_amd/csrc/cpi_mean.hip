@@ -87,6 +87,12 @@ void tile_knots(long long W, int N, const double *knots, const long long *first,
     hipLaunchKernelGGL(cpi_tile_knots_kernel, dim3(nb), dim3(256), 0, st, W, N, knots, first, count, tiles, ts, ss);
 }
 
+void cut_windows(long long K, const double *stream, long long U, const double *update, int N, long long *first, int *count,
+                 double *tstart, double *tend, hipStream_t st) {
+    (void)N;
+    hipLaunchKernelGGL(cpi_cut_windows_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, K, stream, U, update, first, count, tstart, tend);
+}
+
 void assemble_tiles(const AssembleArgs &a, hipStream_t st) {
     const unsigned nb = (unsigned)((a.U + 63) / 64);
     hipLaunchKernelGGL(cpi_assemble_tiles_kernel, dim3(nb), dim3(64), 0, st, a);

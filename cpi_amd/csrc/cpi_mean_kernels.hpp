@@ -36,10 +36,22 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
     const int s0 = min(n, l * per), s1 = min(n, s0 + per);
     const int len = s1 - s0;
     const int maxlen = __builtin_amdgcn_readfirstlane(wave_max(len));   // wave-uniform: loop control stays scalar
+    // Windows cut out of a stream in flight (PreArgs::tstart / tend): the window's first knot takes the stamp tstart, and a
+    // partial tail interval has NO knot in memory -- it is the last real knot's reading held until tend.  The lane that owns
+    // the tail fetches one knot less and builds that knot from its predecessor when it gets there.
+    const bool cut = A.tstart != nullptr;                               // wave-uniform
+    double t_start = 0.0, t_end = 0.0;
+    bool tail = false, tailseg = false;
+    if (cut) {
+        t_start = A.tstart[w]; t_end = A.tend[w];
+        tail = (t_end == t_end) && (A.count[w] <= A.N);                  // NaN = no tail; a truncated window has lost it
+        tailseg = tail && (s1 == n) && (len > 0);
+    }
+    const int len_f = len - (tailseg ? 1 : 0);                          // knots after the segment's first that exist in memory
 
     // (Deriving the descriptors of a dense layout arithmetically instead of through LDS was measured: +0.35 us per
     // 13 us launch -- the 64-bit integer arithmetic costs more than the shuffle reduction and the LDS round trip.)
-    segdesc[lane] = ((unsigned long long)((k0 + s0) * 7) << 16) | (unsigned long long)(unsigned)len;
+    segdesc[lane] = ((unsigned long long)((k0 + s0) * 7) << 16) | (unsigned long long)(unsigned)len_f;
 
     const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
     V3 gk = mk(0, 0, 0);
@@ -47,9 +59,12 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
 
     double pk[7];
     {
-        const double *kb = A.knots + (k0 + s0) * 7;
+        // knot s0 always exists (a window owns count + 1 knots) -- except a virtual tail knot, which only an empty trailing
+        // segment can start on (its pk is never consumed)
+        const double *kb = A.knots + (k0 + ((tail && s0 == n && n > 0) ? s0 - 1 : s0)) * 7;
 #pragma unroll
-        for (int i = 0; i < 7; i++) pk[i] = kb[i];  // knot s0 always exists (a window owns count+1 knots)
+        for (int i = 0; i < 7; i++) pk[i] = kb[i];
+        if (cut && s0 == 0) pk[0] = t_start;
     }
     MeanState<JAC> st;
     mean_init(st);
@@ -71,7 +86,7 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
         const double *kp = A.knots + (k0 + s0) * 7;
         double nx[7];
         {
-            const double *kb = kp + 7 * min(1, len);
+            const double *kb = kp + 7 * min(1, len_f);
 #pragma unroll
             for (int i = 0; i < 7; i++) nx[i] = kb[i];
         }
@@ -80,9 +95,15 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
 #pragma unroll
             for (int i = 0; i < 7; i++) q[i] = nx[i];
             {
-                const double *kb = kp + 7 * min(sidx + 2, len);   // knot s0 + len is the window segment's last: always valid
+                const double *kb = kp + 7 * min(sidx + 2, len_f);   // knot s0 + len_f is the segment's last one in memory: always valid
 #pragma unroll
                 for (int i = 0; i < 7; i++) nx[i] = kb[i];
+            }
+            if (cut) {      // the tail knot: the predecessor's reading under the update time
+                const bool here = tailseg && sidx == len - 1;
+                q[0] = here ? t_end : q[0];
+#pragma unroll
+                for (int i = 1; i < 7; i++) q[i] = here ? pk[i] : q[i];
             }
             mean_step<MODEL, JAC, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
                                        mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, sidx < len);
@@ -168,6 +189,12 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
             double q[7];
 #pragma unroll
             for (int i = 0; i < 7; i++) q[i] = nk[i];
+            if (cut) {      // the tail knot: the predecessor's reading under the update time
+                const bool here = tailseg && s == len - 1;
+                q[0] = here ? t_end : q[0];
+#pragma unroll
+                for (int i = 1; i < 7; i++) q[i] = here ? pk[i] : q[i];
+            }
             if constexpr (GSEG)
                 mean_step_v2seg<AVG>(st, ga, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
                                      mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, s < len);
@@ -426,6 +453,28 @@ __device__ __forceinline__ long long knots_not_after(const double *stream, long 
         if (stream[mid * 7] <= T) lo = mid + 1; else hi = mid;
     }
     return lo;
+}
+// The same cut WITHOUT moving a knot (cpi_preintegrate_stream): per window the front reading's index, the interval count
+// (whole + tail), the start stamp and the update time of a tail interval (NaN: none) -- 28 bytes per window; the
+// preintegration kernels then read the stream in place (PreArgs::tstart / tend).
+__global__ __launch_bounds__(256) void cpi_cut_windows_kernel(long long K, const double *stream, long long U, const double *update,
+                                                              long long *first, int *count, double *tstart, double *tend) {
+    const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= U) return;
+    const double t0 = stream[0], T = update[u];
+    long long fp = 0;
+    double start_t = t0;
+    if (u > 0) {
+        const double Tp = update[u - 1];
+        fp = max(knots_not_after(stream, K, Tp) - 1, 0ll);
+        start_t = fmax(Tp, t0);
+    }
+    const long long fu = max(max(knots_not_after(stream, K, T) - 1, 0ll), fp);
+    const int m = (int)min(fu - fp, (long long)0x3fffffff);
+    const double front_t = (m > 0) ? stream[fu * 7] : start_t;
+    const bool tail = (T - front_t) > 0;
+    first[u] = fp; count[u] = m + (tail ? 1 : 0); tstart[u] = start_t;
+    tend[u] = tail ? T : __builtin_nan("");
 }
 __global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) {
     const int lane = threadIdx.x;

@@ -193,25 +193,39 @@ class Engine:
         self._check(self.lib.cpi_assemble_tiles(self.ctx, K, _ptr(stream), U, _ptr(update_times), N, _ptr(tiles), _ptr(count)))
         return tiles, count
 
-    def preintegrate_stream(self, stream, update_times, lin, q_k_lin=None, params=None, want=("mean",), N=None):
-        """One IMU stream cut at update times and preintegrated (the caller-side loop of GraphSolver_IMU.cpp:43-75 for all
-        windows at once; stream / update_times CUDA tensors, stamps non-decreasing).  Mean-only requests -- the HBM-bound
-        case -- go through the device assembler and the tiled kernel; requests with Jacobians / covariance (FP64-bound) cut
-        the windows on the host (cpi_amd.stream.assemble_windows) and use the ragged layout of cpi_preintegrate_batch."""
+    def preintegrate_stream(self, stream, update_times, lin, q_k_lin=None, params=None, want=("mean", "jac", "cov"), N=None, out=None,
+                            return_counts=False, check_counts=True, workspace=None):
+        """One IMU stream cut at update times and preintegrated IN PLACE (cpi_preintegrate_stream: the caller-side loop of
+        GraphSolver_IMU.cpp:43-75 for all windows at once, zero copies of the IMU data, every model and output).
+        stream [K, 7] with non-decreasing stamps, update_times [U] non-decreasing, lin [U, 6], q_k_lin [U, 4]: CUDA float64.
+        N = upper bound of the intervals per window (default: the whole stream -- safe, give a tight one for speed: the
+        kernels' loops run to N); with check_counts (one synchronisation) raises when a window holds more."""
         params = params or self.make_params()
-        if tuple(want) == ("mean",) and params.model in (1, 2):
-            if N is None:
-                # a safe bound without a pass over the data: no window holds more whole intervals than the stream has knots
-                raise ValueError("preintegrate_stream(mean-only): give N, an upper bound of the intervals per window")
-            tiles, count = self.assemble_tiles(stream, update_times, N)
-            if int(count.max().item()) > N:
-                raise ValueError("preintegrate_stream: a window has %d intervals, more than N = %d" % (int(count.max().item()), N))
-            return self.preintegrate_tiled(tiles, update_times.shape[0], lin, q_k_lin, params, count=count)
-        from .stream import assemble_windows
-        kn, first, count = assemble_windows(stream.cpu().numpy(), update_times.cpu().numpy())
-        dev = self.device
-        return self.preintegrate(torch.from_numpy(kn).to(dev), lin, q_k_lin, params, want=want, first=torch.from_numpy(first).to(dev),
-                                 count=torch.from_numpy(count).to(dev), N=int(count.max()) if len(count) else 0)
+        K, U = stream.shape[0], update_times.shape[0]
+        for t in (stream, update_times, lin, q_k_lin):
+            assert t is None or (t.is_cuda and t.is_contiguous() and t.dtype == torch.float64), "inputs must be contiguous CUDA float64 tensors"
+        if N is None:
+            N = min(int(K), 65535)
+        if out is None:
+            out = self.alloc_outputs(U, want, params.model)
+        ws = workspace if workspace is not None else self.stream_workspace(U)
+        o = self._outputs_struct(out)
+        self._sync_stream()
+        self._check(self.lib.cpi_preintegrate_stream(self.ctx, C.byref(params), K, _ptr(stream), U, _ptr(update_times), int(N), _ptr(lin),
+                                                     _ptr(q_k_lin), _ptr(ws), C.byref(o)))
+        cptr = self.lib.cpi_stream_counts(_ptr(ws), U)
+        counts = torch.empty((U,), dtype=torch.int32, device=self.device)
+        if U:
+            off = (cptr - ws.data_ptr()) // 4
+            counts = ws.view(torch.int32)[off:off + U]
+            if check_counts and int(counts.max().item()) > N:
+                raise ValueError("preintegrate_stream: a window has %d intervals, more than N = %d" % (int(counts.max().item()), N))
+        out["_workspace"] = ws      # keeps the 28 bytes per window alive while the kernels run
+        return (out, counts) if return_counts else out
+
+    def stream_workspace(self, U):
+        """Device workspace of preintegrate_stream for U windows (28 bytes per window; re-usable across calls)."""
+        return torch.empty((self.lib.cpi_stream_workspace_bytes(U) // 8 + 1,), dtype=torch.float64, device=self.device)
 
     def preintegrate_tiled_host(self, tiles, W, lin, q_k_lin=None, params=None, count=None, pinned=True, out=None):
         """Mean outputs from tiles held in HOST memory (cpi_preintegrate_tiled_batch_host: chunked upload / kernel /

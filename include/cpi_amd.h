@@ -34,7 +34,8 @@ extern "C" {
 
 #define CPI_ABI_VERSION 2   /* 2: state count S in the factor / predict entries; device-set entries (cpi_group_*);
                                additions within 2 (new symbols only): tiled layout entries, cpi_host_alloc / _free;
-                               round 3: cpi_tile_windows, cpi_assemble_tiles, cpi_preintegrate_tiled_batch_host,
+                               round 3: cpi_preintegrate_stream (+ _workspace_bytes, _counts), cpi_tile_windows,
+                               cpi_assemble_tiles, cpi_preintegrate_tiled_batch_host,
                                cpi_outputs_slab_doubles / _bind_slab, cpi_group_last_gather_messages */
 
 enum { CPI_OK = 0, CPI_ERR_INVALID = 1, CPI_ERR_HIP = 2, CPI_ERR_NO_DEVICE = 3, CPI_ERR_RCCL = 4 };
@@ -121,6 +122,27 @@ int cpi_ctx_synchronize(cpi_ctx *ctx);
 int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
                            const double *knots, const int64_t *first, const int32_t *count,
                            const double *lin, const double *q_k_lin, const cpi_outputs *out);
+
+/* Replaces: the whole caller side of GraphSolver::createimufactor_cpi_v1 / _v2 (GraphSolver_IMU.cpp:43-75, 97-130) for every
+ * window of a trajectory at once, reading ONE IMU stream IN PLACE: no knot is copied, for any model and any output.
+ *   stream        [K][7] knot records {t, w[3], a[3]} in arrival order, stamps NON-DECREASING (device memory)
+ *   update_times  [U] non-decreasing: window u covers (update_times[u-1], update_times[u]] exactly as the reference cuts it
+ *                 (GraphSolver_IMU.cpp:50-69): whole intervals while imu_times[1] <= updatetime, then the partial tail interval
+ *                 with the front reading held, after which the front stamp is overwritten by the update time; window 0 starts
+ *                 at the stream's first reading
+ *   N             upper bound of the intervals of a window (whole + tail); a longer window is truncated to N intervals --
+ *                 check cpi_stream_counts, which holds the TRUE counts after the call
+ *   lin, q_k_lin  per window, as in cpi_preintegrate_batch
+ *   workspace     cpi_stream_workspace_bytes(U) bytes of device memory, 16-byte aligned (28 bytes per window: where the
+ *                 reference's deque stands at each update, found by binary search because the stamps are sorted)
+ * The kernels patch the first knot's stamp and build the tail interval's closing knot from its predecessor in flight.
+ * Results are bit-identical to cpi_preintegrate_batch on the knots / first / count that the host assemblers
+ * (cpi_amd/stream.py, cpi_host::assemble_windows) produce from the same stream. */
+size_t cpi_stream_workspace_bytes(int64_t U);
+int cpi_preintegrate_stream(cpi_ctx *ctx, const cpi_params *prm, int64_t K, const double *stream, int64_t U,
+                            const double *update_times, int32_t N, const double *lin, const double *q_k_lin,
+                            void *workspace, const cpi_outputs *out);
+const int32_t *cpi_stream_counts(const void *workspace, int64_t U);   /* device pointer into the workspace: count[U] */
 
 /* The same loop for the mean outputs (DT, alpha, beta, q) on the TILED layout: the knots of 64 consecutive windows
  * interleaved per step,

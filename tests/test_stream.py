@@ -176,18 +176,84 @@ def test_gpu_stream_through_the_tiled_producers_vs_deque_oracle(mode):
         out = eng.preintegrate_tiled(tiles, U, T(lin), T(q), prm, count=T(count))
         torch.cuda.synchronize()
         check_pre({k: v.cpu().numpy() for k, v in out.items()}, ref, what=("mean",), v2=(mode[0] == 2), label="tiled stream %s" % (mode,))
-    out = eng.preintegrate_stream(T(kn), T(ut), T(lin), T(q), prm, want=("mean",), N=N)
-    torch.cuda.synchronize()
-    check_pre({k: v.cpu().numpy() for k, v in out.items()}, ref, what=("mean",), v2=(mode[0] == 2))
     with pytest.raises(ValueError):
         eng.preintegrate_stream(T(kn), T(ut), T(lin), T(q), prm, want=("mean",), N=N - 1)   # a window does not fit: said, not truncated
-    full = eng.preintegrate_stream(T(kn), T(ut), T(lin), T(q), prm, want=("mean", "jac", "cov"))
-    torch.cuda.synchronize()
-    check_pre({k: v.cpu().numpy() for k, v in full.items()}, ref, v2=(mode[0] == 2))
     # the same tiles from HOST memory through the chunked pipeline
     hout = eng.preintegrate_tiled_host(torch.from_numpy(tiles_h), U, torch.from_numpy(lin), torch.from_numpy(q), prm,
                                        count=torch.from_numpy(count))
     check_pre({k: v.numpy() for k, v in hout.items()}, ref, what=("mean",), v2=(mode[0] == 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [(1, 0, 1), (2, 0, 1), (1, 1, 1), (2, 1, 1), (2, 0, 0)])
+def test_gpu_stream_entry_reads_the_stream_in_place(mode):
+    """cpi_preintegrate_stream: ONE resident IMU stream + update times, every output, NO knot copied -- the kernels cut
+    the windows themselves.  Against the oracle's literal deque-loop restatement on the reference's own IMU excerpt (update
+    times before the stream, on and off the IMU grid, repeated, past the end), and BIT FOR BIT against cpi_preintegrate_batch
+    on the knots / first / count the host assembler makes from the same stream, for every lane split of the mean kernel."""
+    import torch
+    import cpi_amd
+    eng = cpi_amd.Engine()
+    kn = st.parse_imu_text(open(DATA).read())
+    ut = _updates(kn)
+    ut = np.sort(np.concatenate([ut, [kn[0, 0] - 1.0, ut[7], kn[-1, 0] + 0.5]]))
+    knots, first, count = st.assemble_windows(kn, ut)
+    U, N = len(ut), int(count.max())
+    rng = np.random.default_rng(1)
+    lin = np.concatenate([0.01 * rng.standard_normal((U, 3)), 0.05 * rng.standard_normal((U, 3))], axis=1)
+    q = rng.standard_normal((U, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); q[q[:, 3] < 0] *= -1
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    ref = op.oracle().stream(op.make_params(*mode), kn, ut, lin, q)
+    dk, du, dl, dq = T(kn), T(ut), T(lin), T(q)
+    ck, cf, cc = T(knots), T(first), T(count)
+    for lanes in (0, 1, 2, 3, 5, 8, 16, 64):
+        prm = eng.make_params(mode[0], bool(mode[1]), bool(mode[2]), lanes_per_window=lanes)
+        for want in (("mean", "jac", "cov"), ("mean",), ("mean", "jac")):
+            out, cnt = eng.preintegrate_stream(dk, du, dl, dq, prm, want=want, N=N, return_counts=True)
+            csr = eng.preintegrate(ck, dl, dq, prm, want=want, first=cf, count=cc, N=N)
+            torch.cuda.synchronize()
+            assert np.array_equal(cnt.cpu().numpy(), count)
+            for k in csr:
+                assert torch.equal(out[k], csr[k]), (lanes, want, k)
+            check_pre({k: v.cpu().numpy() for k, v in out.items()}, ref, what=want, v2=(mode[0] == 2), label="stream entry %s L%d" % (mode, lanes))
+    # a looser bound on the window length changes nothing; the default bound is the stream's length
+    prm = eng.make_params(mode[0], bool(mode[1]), bool(mode[2]))
+    a = eng.preintegrate_stream(dk, du, dl, dq, prm, N=N)
+    b = eng.preintegrate_stream(dk, du, dl, dq, prm, N=N + 37)
+    c = eng.preintegrate_stream(dk, du, dl, dq, prm)
+    torch.cuda.synchronize()
+    for k in ("DT", "alpha", "beta", "q", "P"):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+    with pytest.raises(ValueError):
+        eng.preintegrate_stream(dk, du, dl, dq, prm, N=N - 1)          # a window does not fit: said, not truncated
+
+
+@pytest.mark.gpu
+def test_gpu_stream_entry_forster_and_many_windows():
+    """The same entry for the Forster comparator, and on a synthetic stream cut into thousands of windows (every window ends
+    in a partial tail interval; wavefronts of the covariance kernels mix windows of different lengths): bit for bit equal to
+    the host-assembled ragged layout."""
+    import torch
+    import cpi_amd
+    from cpi_amd import synth
+    eng = cpi_amd.Engine()
+    stream, upd, lin, q = synth.make_stream(3001, 17, seed=5, phase=0.37)
+    upd = upd.clone(); upd[100:200] += 0.02; upd = torch.sort(upd).values      # a few longer / shorter windows
+    knots, first, count = st.assemble_windows(stream.numpy(), upd.numpy())
+    N = int(count.max())
+    T = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(eng.device)
+    ds, du, dl, dq, ck, cf, cc = T(stream), T(upd), T(lin), T(q), T(knots), T(first), T(count)
+    for model in (1, 2, 3):
+        prm = eng.make_params(model)
+        qq = dq if model != 3 else None
+        out = eng.preintegrate_stream(ds, du, dl, qq, prm, N=N)
+        csr = eng.preintegrate(ck, dl, qq, prm, first=cf, count=cc, N=N)
+        torch.cuda.synchronize()
+        for k in csr:
+            assert torch.equal(out[k], csr[k]), (model, k)
+        ref = op.oracle().run(op.make_params(model, 0, 1), knots[first[5]:first[5] + count[5] + 1][None], lin[5:6].numpy(), q[5:6].numpy())
+        for k in ("DT", "alpha", "beta", "q"):
+            assert np.abs(out[k][5].cpu().numpy() - ref[k][0]).max() < 1e-12, (model, k)
 
 
 @pytest.mark.gpu

@@ -4,7 +4,7 @@
 # pass per counter group (kernel-trace / stats domains are NOT combined with --pmc), and writes profiles-style JSON stamped
 # with the library's build id.  A row is <workload>:<W>:<N>.
 R=$PWD; OUT=$1; shift
-ROWS=${@:-"v1_mean:10000:50 v1_mean:1000000:50 v1_full:100000:50 v2_full:100000:50 forster_full:100000:50 factor_v1:1000000:50 factor_v2:1000000:50 factor_v1_packed:1000000:50 factor_v2_packed:1000000:50 sqrt_info:1000000:50 factor_v1_whitened:1000000:50 factor_v2_whitened:1000000:50 factor_v1_hessian:1000000:50 factor_v2_hessian:1000000:50 predict_v1:1000000:50 predict_v2:1000000:50 cfg5_mean:1000000:100 cfg5_full:1000000:100 v1_mean_tiled:1000000:50 v2_mean_tiled:1000000:50 v1_mean_tiled:10000:50"}
+ROWS=${@:-"v1_mean:10000:50 v1_mean:1000000:50 v1_full:100000:50 v2_full:100000:50 forster_full:100000:50 factor_v1:1000000:50 factor_v2:1000000:50 factor_v1_packed:1000000:50 factor_v2_packed:1000000:50 sqrt_info:1000000:50 factor_v1_whitened:1000000:50 factor_v2_whitened:1000000:50 factor_v1_hessian:1000000:50 factor_v2_hessian:1000000:50 predict_v1:1000000:50 predict_v2:1000000:50 cfg5_mean:1000000:100 cfg5_full:1000000:100 v1_mean_tiled:1000000:50 v2_mean_tiled:1000000:50 v1_mean_tiled:10000:50 v1_mean_stream:1000000:50 v1_full_stream:100000:50 v2_full_stream:100000:50"}
 export TMPDIR=/tmp
 D=/tmp/pmc_$$; mkdir -p $D; cd /tmp
 BID=$(python -c "import sys; sys.path.insert(0,'$R'); from cpi_amd import _lib; print(_lib.load().cpi_build_id().decode())")
@@ -21,6 +21,9 @@ for row in $ROWS; do
     v1_mean|cfg5_mean) K="cpi_mean_kernel<1, false";;
     v2_mean) K="cpi_mean_kernel<2, false";;
     v1_mean_tiled) K="cpi_mean_tiled_kernel<1";;
+    v1_mean_stream) K="cpi_mean_kernel<1, false;cpi_cut_windows_kernel";;
+    v1_full_stream) K="cpi_cov_kernel<1;cpi_mean_kernel<1, true;cpi_cut_windows_kernel";;
+    v2_full_stream) K="cpi_cov_kernel<2;cpi_cut_windows_kernel";;
     v2_mean_tiled) K="cpi_mean_tiled_kernel<2";;
     sqrt_info) K="cpi_sqrt_info_kernel";;
     factor_v1_whitened) K="cpi_factor_kernel<1, true";;
