@@ -28,10 +28,12 @@ bool mean_lanes_supported(int L) {
 
 template <int MODEL, bool JAC, bool AVG>
 static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
+    const bool cut = a.tstart != nullptr;
 #define CPI_LAUNCH_L(LL)                                                                         \
     case LL: {                                                                                   \
         const long long nb = (a.W + (64 / LL) - 1) / (64 / LL);                                  \
-        hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL>), dim3((unsigned)nb), dim3(64), 0, st, a); \
+        if (cut) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL, true>), dim3((unsigned)nb), dim3(64), 0, st, a); \
+        else hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL, false>), dim3((unsigned)nb), dim3(64), 0, st, a); \
     } break;
     if constexpr (MODEL == 2 && JAC) { switch (L) { CPI_LAUNCH_L(1) default: break; } } else
     switch (L) {
