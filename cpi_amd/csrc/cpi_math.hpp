@@ -1,7 +1,7 @@
 // cpi_math.hpp -- per-lane arithmetic of the MI355X continuous-preintegration kernels.
 //
 // Everything here is straight-line f64 code on 3-vectors / 3x3 blocks that lives in VGPRs: the
-// contractions are far too small for MFMA.  The kernels (cpi_kernels.hip) own the lane mapping,
+// contractions are far too small for MFMA.  The kernels (cpi_mean / cpi_cov / cpi_factor .hip) own the lane mapping,
 // LDS staging and cross-lane exchange; this header owns the mathematics so that it can also be
 // compiled for the host by tests/hostsim (a lane-by-lane emulator used ONLY by the CPU test suite
 // to validate kernel logic where no GPU is available -- it is not reachable from the C-ABI).
