@@ -312,10 +312,23 @@ __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, dou
 // Input and output pass through LDS so that HBM sees full consecutive 16-byte pieces (see cpi_factor_kernel).
 template <int K>
 __device__ __forceinline__ double row_share(double v) {   // all 16 lanes of a DPP row read lane K of that row
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int nlo = __builtin_amdgcn_mov_dpp(lo, 0x150 + K, 0xf, 0xf, false);
-    const int nhi = __builtin_amdgcn_mov_dpp(hi, 0x150 + K, 0xf, 0xf, false);
-    return __hiloint2double(nhi, nlo);
+    // gfx90a+ moves 64 bits at once when the control is a row broadcast: ONE v_mov_b64_dpp row_newbcast:K
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, false);
+}
+// The VOP2 double-precision multiply-add of gfx90a+ takes a row broadcast as an operand modifier: acc += bcast_K(b) * x in
+// ONE instruction.  hipcc does not fold a v_mov_b64_dpp into its user, hence the assembler text.  The hazard recogniser does
+// not see through inline assembly ("a VALU write of a VGPR followed by a DPP read of it needs two wait states"): use these
+// only with a broadcast source that comes out of memory / LDS or was pinned long before -- tests/test_abi.py
+// (test_dpp_sources_are_not_fresh_valu_results) checks that rule on the disassembly of the shipped library.
+template <int K>
+__device__ __forceinline__ void dpp_fmac(double &acc, double b, double x) {      // acc += bcast_K(b) * x
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ double dpp_mul(double b, double x) {   // v_mul_f64 is VOP3-only (no DPP form): a chain starts from zero
+    double r = 0.0;
+    dpp_fmac<K>(r, b, x);
+    return r;
 }
 template <int K>
 __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], double (&acc)[15], int j) {
@@ -399,55 +412,114 @@ constexpr int HESS_PACKED = 496;
 template <int C>
 __device__ __forceinline__ void lambda_row_dpp(const double (&own)[15], double (&l)[15]) {
     if constexpr (C < 15) {
-        double a = 0.0;
+        double a = dpp_mul<C>(own[0], own[0]);
 #pragma unroll
-        for (int k = 0; k <= C; k++) a = fma(own[k], row_share<C>(own[k]), a);
+        for (int k = 1; k <= C; k++) dpp_fmac<C>(a, own[k], own[k]);
         l[C] = a;
         lambda_row_dpp<C + 1>(own, l);
     }
+}
+// The block table of a factor (hsn: B_B .. B_DT, 106 doubles) spread over the factor's 16 lanes: entry i is register i >> 4
+// of lane i & 15, so a product with a table entry is ONE double-precision DPP instruction (dpp_mul / dpp_fmac) -- no LDS
+// read, no register for the entry, and the three-blocks-at-a-time loads that set the register budget of the first version
+// are gone.  The table passes through LDS once (five lanes produce it, sixteen pick up their seven entries).
+constexpr int TAB_R = 7, TAB_D = 16 * TAB_R;
+struct BlkTab { double r[TAB_R]; };
+template <int I> __device__ __forceinline__ double tmul(const BlkTab &T, double x) { return dpp_mul<(I & 15)>(T.r[I >> 4], x); }
+template <int I> __device__ __forceinline__ void tfmac(double &acc, const BlkTab &T, double x) { dpp_fmac<(I & 15)>(acc, T.r[I >> 4], x); }
+// M^T v for the row-major block at table offset OFF (hsn::vTm / mulT(ldb(.), v)): same terms, same order
+template <int OFF>
+__device__ __forceinline__ V3 tab_mulT(const BlkTab &T, V3 v) {
+    V3 o;
+    o.x = tmul<OFF + 0>(T, v.x); tfmac<OFF + 3>(o.x, T, v.y); tfmac<OFF + 6>(o.x, T, v.z);
+    o.y = tmul<OFF + 1>(T, v.x); tfmac<OFF + 4>(o.y, T, v.y); tfmac<OFF + 7>(o.y, T, v.z);
+    o.z = tmul<OFF + 2>(T, v.x); tfmac<OFF + 5>(o.z, T, v.y); tfmac<OFF + 8>(o.z, T, v.z);
+    return o;
+}
+template <int OFF>
+__device__ __forceinline__ void tab_mulT_acc(V3 &o, const BlkTab &T, V3 v) {
+    tfmac<OFF + 0>(o.x, T, v.x); tfmac<OFF + 3>(o.x, T, v.y); tfmac<OFF + 6>(o.x, T, v.z);
+    tfmac<OFF + 1>(o.y, T, v.x); tfmac<OFF + 4>(o.y, T, v.y); tfmac<OFF + 7>(o.y, T, v.z);
+    tfmac<OFF + 2>(o.z, T, v.x); tfmac<OFF + 5>(o.z, T, v.y); tfmac<OFF + 8>(o.z, T, v.z);
+}
+// g = H1^T v (hsn::h1t_vec; with v = a row of Lam: hsn::z_row), the sums of block products as running accumulations
+__device__ __forceinline__ void tab_h1t(const double (&v)[15], const BlkTab &T, double (&g)[15]) {
+    using namespace hsn;
+    const V3 vt = ldv(v), vg = ldv(v + 3), vv = ldv(v + 6), va = ldv(v + 9), vp = ldv(v + 12);
+    V3 a = tab_mulT<B_B>(T, vt); tab_mulT_acc<B_E>(a, T, vv); tab_mulT_acc<B_F>(a, T, vp);
+    put3(g + 0, a);
+    V3 b = tab_mulT<B_JB>(T, vv); tab_mulT_acc<B_JA>(b, T, vp);
+    V3 c = -vg; tab_mulT_acc<B_C>(c, T, vt);
+    put3(g + 3, c - b);
+    V3 s = vv;                                                        // dt vp + vv
+    tfmac<B_DT>(s.x, T, vp.x); tfmac<B_DT>(s.y, T, vp.y); tfmac<B_DT>(s.z, T, vp.z);
+    put3(g + 6, -tab_mulT<B_RK>(T, s));
+    put3(g + 12, -tab_mulT<B_RK>(T, vp));
+    V3 h = va; tab_mulT_acc<B_HB>(h, T, vv); tab_mulT_acc<B_HA>(h, T, vp);
+    put3(g + 9, -h);
+}
+template <int C>
+__device__ __forceinline__ void tab_edot(double &acc, const double (&v)[15], const BlkTab &T) {   // + e . v
+    if constexpr (C < 15) { tfmac<hsn::B_ERR + C>(acc, T, v[C]); tab_edot<C + 1>(acc, v, T); }
+}
+// hsn::h2t_vec
+__device__ __forceinline__ void tab_h2t(const double (&w)[15], const BlkTab &T, double (&t)[15]) {
+    using namespace hsn;
+    put3(t + 0, tab_mulT<B_A>(T, ldv(w)));
+    put3(t + 3, ldv(w + 3));
+    put3(t + 6, tab_mulT<B_RK>(T, ldv(w + 6)));
+    put3(t + 9, ldv(w + 9));
+    put3(t + 12, tab_mulT<B_RK>(T, ldv(w + 12)));
 }
 template <int MODEL>
 __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
     using namespace hsn;
     constexpr int FPW = 4, IN_D = fin::IN_D;
-    // [input records -> R -> zx] | lam | block tables; at the end everything is dead and becomes the output stage
+    // [input records -> R -> zx] | [block tables -> lam]; at the end everything is dead and becomes the output stage
     constexpr int U1 = FPW * MAT_D;
-    static_assert(FPW * IN_D <= U1 && FPW * 225 <= U1, "the exchange area re-uses the input records and the R matrices");
-    __shared__ __attribute__((aligned(16))) double sAll[2 * U1 + FPW * BLK_D];
+    static_assert(FPW * IN_D <= U1 && FPW * 225 <= U1 && FPW * TAB_D <= U1 && BLK_D <= TAB_D, "the areas are re-used");
+    __shared__ __attribute__((aligned(16))) double sAll[2 * U1];
     __shared__ double sDummy[2];
-    static_assert(FPW * HESS_PACKED + 64 <= 2 * U1 + FPW * BLK_D, "stage area");
-    double *sU1 = sAll, *sLam = sAll + U1, *sBlk = sAll + 2 * U1;
+    static_assert(FPW * HESS_PACKED + 64 <= 2 * U1, "stage area");
+    double *sU1 = sAll, *sLam = sAll + U1;
     const int lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     const int q = lane & 15, f = min(lane >> 4, nf - 1);     // missing factors shadow the last one (same values, same slots)
     const int qr = min(q, 14);                               // lane 15 shadows row 14 in the row phase
 
-    // ---- the input records (one round trip).  R follows after the block tables: its 30 registers would not survive the
-    // shared algebra at two wavefronts per SIMD, and the neighbour wavefront covers the second round trip
+    // ---- the input records (one round trip).  R follows after the block tables: the neighbour wavefront covers the second
+    // round trip
     constexpr int RT = (FPW * 225 + 63) / 64;
     factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sU1, sDummy);
     __syncthreads();
 
     // ---- block table of the factor: the state-dependent blocks (three column tasks), the measurement's bias Jacobians,
-    // the residual
-    double *blk = sBlk + f * BLK_D;
+    // the residual -- through LDS into the lanes' registers
+    BlkTab T;
+    V3 dcol;                                                 // the lane's column of its diagonal block of H2
     {
-        const FactorMeas m = factor_meas_of(sU1 + f * IN_D, A.grav);
-        FactorShared S;
-        V3 e5[5];
-        factor_shared_core<MODEL>(m, S, e5);
-        if (q < 3) state_blocks_column<MODEL>(S, m, q, blk);
-        else if (q == 3) {
-            stb(blk + B_JB, ldcm(m.J_beta)); stb(blk + B_JA, ldcm(m.J_alpha));
-            stb(blk + B_HB, ldcm(m.H_beta)); stb(blk + B_HA, ldcm(m.H_alpha));
-        } else if (q == 4) {
+        double *blk = sLam + f * TAB_D;
+        {
+            const FactorMeas m = factor_meas_of(sU1 + f * IN_D, A.grav);
+            FactorShared S;
+            V3 e5[5];
+            factor_shared_core<MODEL>(m, S, e5);
+            if (q < 3) state_blocks_column<MODEL>(S, m, q, blk);
+            else if (q == 3) {
+                stb(blk + B_JB, ldcm(m.J_beta)); stb(blk + B_JA, ldcm(m.J_alpha));
+                stb(blk + B_HB, ldcm(m.H_beta)); stb(blk + B_HA, ldcm(m.H_alpha));
+            } else if (q == 4) {
 #pragma unroll
-            for (int a = 0; a < 5; a++) { blk[B_ERR + 3 * a] = e5[a].x; blk[B_ERR + 3 * a + 1] = e5[a].y; blk[B_ERR + 3 * a + 2] = e5[a].z; }
-            blk[B_DT] = m.dt[0];
+                for (int a = 0; a < 5; a++) { blk[B_ERR + 3 * a] = e5[a].x; blk[B_ERR + 3 * a + 1] = e5[a].y; blk[B_ERR + 3 * a + 2] = e5[a].z; }
+                blk[B_DT] = m.dt[0];
+            }
         }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < TAB_R; r++) T.r[r] = blk[r * 16 + q];      // entries past BLK_D: never used
+        dcol = h2_diag_col(blk, (q < 15) ? q / 3 : 0, (q < 15) ? q % 3 : 0);
     }
-    wave_lds_fence();
     // the input records are dead: the R matrices of the wavefront (900 doubles, coalesced) take their place
     {
         double rr[RT];
@@ -462,21 +534,43 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
     // ---- row phase: row q of Lam and of Z, y_q
     double *lam = sLam + f * MAT_D, *zx = sU1 + f * MAT_D;
     {
-        double l[15], z[15], y, own[15];
+        double l[15], z[15], own[15];
 #pragma unroll
         for (int k = 0; k < 15; k++) own[k] = sU1[f * 225 + qr * 15 + k];
         lambda_row_dpp<0>(own, l);
-        z_row(l, blk, z, y);
-        wave_lds_fence();     // every lane has read R before the area becomes zx
+        tab_h1t(l, T, z);
+        double y = tmul<B_ERR>(T, l[0]);
+        tab_edot<1>(y, l, T);
+        wave_lds_fence();     // every lane has read R (and its table entries) before the areas become zx / lam
 #pragma unroll
         for (int c = 0; c < 15; c++) { lam[qr * ROWP + c] = l[c]; zx[qr * ROWP + c] = z[c]; }
         zx[qr * ROWP + 15] = y;
     }
     wave_lds_fence();
 
-    // ---- column phase: everything the lane stores, into registers (the exchange arrays and the block table die here)
+    // ---- column phase: everything the lane stores, into registers (hsn::lane_columns; the exchange arrays die here)
     double g[15], u[15], t[15], fq;
-    lane_columns(q, lam, zx, blk, g, u, t, fq);
+    {
+        const int j = (q < 15) ? q / 3 : 0;
+        const double sgn = (q == 15) ? -1.0 : 1.0;
+        {
+            double zc[15];
+#pragma unroll
+            for (int k = 0; k < 15; k++) zc[k] = sgn * zx[k * ROWP + q];       // column q of Z; for q = 15: -y
+            tab_h1t(zc, T, g);
+            double acc = tmul<B_ERR>(T, zc[0]);
+            tab_edot<1>(acc, zc, T);
+            fq = -acc;
+        }
+        {
+            double w[15];
+            rows_comb(lam, j, dcol, w);
+#pragma unroll
+            for (int c = 0; c < 15; c++) w[c] = (q == 15) ? -zx[c * ROWP + 15] : w[c];      // lane 15: w = -y
+            tab_h2t(w, T, t);
+        }
+        rows_comb(zx, j, dcol, u);
+    }
     wave_lds_fence();
 
     // ---- out through the stage: the four factors' packed triangles are one contiguous 15.9 KB run of the output

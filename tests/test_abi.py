@@ -95,3 +95,33 @@ def test_default_library_reads_no_environment_switches():
         assert "getenv" not in open(os.path.join(build.CSRC, unit + ".hip")).read()
     rows = open(build.REPORT).read()
     assert "cpi_mean_dma_kernel" not in rows and "cpi_mean_blk_kernel" not in rows and "probe" not in rows
+
+
+def test_dpp_sources_are_not_fresh_valu_results():
+    """The double-precision DPP multiply-adds (cpi_factor_kernels.hpp: dpp_fmac) are inline assembly, which hipcc's hazard
+    recogniser does not inspect: "VALU write of a VGPR, then a DPP read of it: two wait states" is checked here on the
+    disassembly of the shipped library (tests/tools/dpp_hazards.py), after the checker has shown it sees a planted case."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import dpp_hazards
+    planted = """
+0000000000001000 <k>:
+	v_fma_f64 v[4:5], v[0:1], v[2:3], v[4:5]
+	s_nop 0
+	v_fmac_f64_dpp v[8:9], v[4:5], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf
+	v_fma_f64 v[4:5], v[0:1], v[2:3], v[4:5]
+	s_nop 1
+	v_fmac_f64_dpp v[8:9], v[4:5], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf
+	ds_read_b64 v[4:5], v0
+	v_fmac_f64_dpp v[8:9], v[4:5], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf
+	v_mov_b32_e32 v5, 0
+	v_add_f64 v[10:11], v[0:1], v[2:3]
+	v_mov_b64_dpp v[8:9], v[4:5] row_newbcast:1 row_mask:0xf bank_mask:0xf
+"""
+    n, bad = dpp_hazards.scan(planted)
+    assert n == 4 and len(bad) == 2 and "s_nop 1" not in bad[0][2] and "v_mov_b32_e32 v5" in bad[1][1]
+    from cpi_amd import _lib
+    _lib.load()
+    n, bad = dpp_hazards.check(os.path.join(ROOT, "cpi_amd", "libcpi_amd.so"))
+    assert n > 500, "the Hessian sweep's DPP multiply-adds are gone?"
+    assert not bad, bad[:5]

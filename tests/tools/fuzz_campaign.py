@@ -112,6 +112,57 @@ def main():
         if not ok:
             fails += 1
             print("FAIL factor case", case, F, model, flush=True)
+    # Hessian blocks of random sweeps against the numpy definition on the whitened sweep (round 3: 3x3 block algebra)
+    for case in range(max(4, cases // 20)):
+        F = int(rng.integers(1, 2000))
+        model = int(rng.integers(1, 3))
+        kn, lin, q = synth.make_windows(F, 15, seed=seed * 2000 + case, device=eng.device, edge_cases=False)
+        meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac", "cov"))
+        R = eng.sqrt_information(meas["P"])
+        xi, xj = synth.make_states(meas["alpha"], meas["beta"], meas["q"], meas["DT"], lin, model, device=eng.device, seed=seed * 17 + case)
+        states = torch.cat([xi, xj], 0).contiguous()
+        ii = torch.arange(F, dtype=torch.int32, device=eng.device)
+        qq = q if model == 2 else None
+        white = eng.factor_eval(model, meas, lin, qq, states, ii, ii + F, sqrt_info=R)
+        hess = eng.factor_hessian(model, meas, lin, qq, states, R, ii, ii + F)
+        torch.cuda.synchronize()
+        A1 = white["H1"].cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1); A2 = white["H2"].cpu().numpy().reshape(F, 15, 15).transpose(0, 2, 1)
+        Ab = np.concatenate([A1, A2, -white["err"].cpu().numpy()[:, :, None]], axis=2)
+        M = np.einsum("fki,fkj->fij", Ab, Ab)
+        want_h = np.stack([M[:, i, d] for d in range(31) for i in range(d + 1)], axis=1)
+        if not (np.abs(hess.cpu().numpy() - want_h) / np.abs(want_h).max(axis=1, keepdims=True)).max() < 1e-12:
+            fails += 1
+            print("FAIL hessian case", case, F, model, flush=True)
+    # the zero-copy stream entry: random streams (irregular sampling, repeated stamps) cut at random update times -- against
+    # the oracle's deque-loop restatement and BIT FOR BIT against the host-assembled ragged layout, random lane splits / outputs
+    from cpi_amd import stream as st
+    for case in range(max(6, cases // 10)):
+        K = int(rng.integers(2, 4000))
+        U = int(rng.integers(1, 300))
+        model = int(rng.integers(1, 4))
+        avg = int(rng.integers(0, 2)) if model < 3 else 0
+        t = 100.0 + np.cumsum(rng.choice([0.0, 0.0025, 0.005, 0.005, 0.005, 0.01, 0.025], K))
+        sm = np.concatenate([t[:, None], rng.normal(size=(K, 3)), rng.normal(size=(K, 3)) * 3 + np.array([0, 0, 9.8])], axis=1)
+        ut = np.sort(rng.choice(np.concatenate([t, t + 0.0013, [t[0] - 1.0, t[-1] + 0.3]]), U))
+        knots, first, count = st.assemble_windows(sm, ut)
+        N = int(count.max())
+        _, lin, q = synth.make_windows(U, 2, seed=seed * 3000 + case)
+        lanes = int(rng.choice(lanes_all))
+        want = wants[int(rng.integers(0, len(wants)))]
+        prm = eng.make_params(model, avg, 1, lanes_per_window=lanes)
+        qq = dev(q.numpy(), eng) if model != 3 else None
+        try:
+            out = eng.preintegrate_stream(dev(sm, eng), dev(ut, eng), dev(lin.numpy(), eng), qq, prm, want=want, N=max(N, 1))
+            csr = eng.preintegrate(dev(knots, eng), dev(lin.numpy(), eng), qq, prm, want=want, first=dev(first, eng), count=dev(count, eng), N=max(N, 1))
+            torch.cuda.synchronize()
+            for k in csr:
+                assert torch.equal(out[k], csr[k]), "stream entry differs from the ragged layout in " + k
+            if model < 3:
+                ref = op.oracle().stream(op.make_params(model, avg, 1), sm, ut, lin.numpy(), q.numpy())
+                check_pre({k: v.cpu().numpy() for k, v in out.items()}, ref, what=want, v2=(model == 2), label="stream case %d" % case)
+        except AssertionError as ex:
+            fails += 1
+            print("FAIL stream case", case, K, U, model, lanes, want, ex, flush=True)
     print("campaign seed %d: %d preintegration cases, %d failures" % (seed, cases, fails), flush=True)
     return 1 if fails else 0
 
