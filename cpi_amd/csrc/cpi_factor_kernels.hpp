@@ -118,6 +118,22 @@ __device__ __forceinline__ FactorMeas factor_meas_of(const double *in, const dou
 // the FPW factors' H1 blocks are one contiguous FPW x 1 800-byte span of the output (measured on MI355X: that
 // pattern stores at 4.8 TB/s, per-column 120/240-byte pieces at 2.5 TB/s -- which rules out one lane per factor).
 // LPF = 16 has the most wavefronts (small sweeps fill the chip); LPF = 8 / 4 do 2x / 4x less redundant arithmetic.
+// row I of R h for the whitening of cpi_factor_kernel (16 lanes per factor): the terms k = I .. 14 in that order, R[I][k] =
+// register Rc[I] of lane k.  (dpp_fmac: defined with the square-root-information kernel below.)
+template <int K> __device__ __forceinline__ void dpp_fmac(double &acc, double b, double x);
+template <int I, int K>
+__device__ __forceinline__ void whiten_row_dpp(const double (&Rc)[15], const double (&h)[15], double &acc) {
+    if constexpr (K < 15) { dpp_fmac<K>(acc, Rc[I], h[K]); whiten_row_dpp<I, K + 1>(Rc, h, acc); }
+}
+template <int I>
+__device__ __forceinline__ void whiten_col_dpp(const double (&Rc)[15], double (&h)[15]) {
+    if constexpr (I < 15) {
+        double acc = 0.0;
+        whiten_row_dpp<I, I>(Rc, h, acc);
+        h[I] = acc;                           // rows are finished top-down, so h[k], k > I, is still unwhitened
+        whiten_col_dpp<I + 1>(Rc, h);
+    }
+}
 #ifndef CPI_FACTOR_WPS
 #define CPI_FACTOR_WPS 1
 #endif
@@ -160,13 +176,23 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
         }
     }
     // ---- optional whitening (GTSAM Gaussian::WhitenSystem): y = R x with R upper triangular, column-major
-    auto whiten_col = [&](double *h) {   // in place: out[i] = sum_{k >= i} R[i][k] h[k]
+    // Sixteen lanes per factor = one DPP row: lane k keeps column k of R (Rc[i] = R[i][k]) and every R[i][k] h[k] is ONE
+    // v_fmac_f64_dpp with lane k's register as the broadcast operand -- 240 LDS broadcasts per lane less (H1 and H2).
+    double Rc[(WHITEN && LPF == 16) ? 15 : 1];
+    if constexpr (WHITEN && LPF == 16) {
 #pragma unroll
-        for (int i = 0; i < 15; i++) {
-            double acc = 0.0;
+        for (int i = 0; i < 15; i++) Rc[i] = Rf[min(q, 14) * 15 + i];
+    }
+    auto whiten_col = [&](double (&h)[15]) {   // in place: out[i] = sum_{k >= i} R[i][k] h[k]
+        if constexpr (WHITEN && LPF == 16) whiten_col_dpp<0>(Rc, h);
+        else {
 #pragma unroll
-            for (int k = i; k < 15; k++) acc = fma(Rf[k * 15 + i], h[k], acc);
-            h[i] = acc;                   // rows are finished top-down, so h[k], k > i, is still unwhitened
+            for (int i = 0; i < 15; i++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = i; k < 15; k++) acc = fma(Rf[k * 15 + i], h[k], acc);
+                h[i] = acc;                   // rows are finished top-down, so h[k], k > i, is still unwhitened
+            }
         }
     };
     if (whiten) {   // R err needs the whole residual
@@ -343,13 +369,17 @@ __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], 
         // lanes j < k: trailing update of column j (all rows < k) with B[j][k] = A[k][j] / b_kk (symmetry: a
         // static register of lane j); finished lanes multiply by zero
         const double bjk = (j < K) ? a[K] * inv : 0.0;
-        const double uk = u[K];
+        // B[i][k] = A[i][k] / b_kk sits in lane k: both updates take it as the broadcast operand of a DPP multiply-add, the
+        // lane's own factors folded with 1 / b_kk first (two instructions per row where a broadcast, a multiply and two
+        // multiply-adds stood).  Rows descend so that the pivot of the next step (a[K-1]) is the OLDEST write of this loop,
+        // and the s_nop covers K = 1 -- inline assembly is invisible to the compiler's DPP hazard check in both directions.
+        const double ca = -inv * bjk, cu = inv * u[K];
 #pragma unroll
-        for (int i = 0; i < K; i++) {
-            const double c = row_share<K>(a[i]) * inv;     // B[i][k], i < k
-            a[i] = fma(-c, bjk, a[i]);
-            acc[i] = fma(c, uk, acc[i]);
+        for (int i = K - 1; i >= 0; i--) {
+            dpp_fmac<K>(acc[i], a[i], cu);
+            dpp_fmac<K>(a[i], a[i], ca);
         }
+        asm volatile("s_nop 1");
         __builtin_amdgcn_sched_barrier(0);   // keep the steps in order: hoisted broadcasts would cost ~200 registers
         chol_inv_step<K - 1>(a, u, acc, j);
     }
@@ -423,7 +453,13 @@ __device__ __forceinline__ void lambda_row_dpp(const double (&own)[15], double (
 // of lane i & 15, so a product with a table entry is ONE double-precision DPP instruction (dpp_mul / dpp_fmac) -- no LDS
 // read, no register for the entry, and the three-blocks-at-a-time loads that set the register budget of the first version
 // are gone.  The table passes through LDS once (five lanes produce it, sixteen pick up their seven entries).
+// Entries 0 .. 53 are the state-dependent blocks (hsn::B_B .. B_RK, row-major, written by state_blocks_column); 54 .. 90
+// are the measurement's bias Jacobians and dt EXACTLY as the input record holds them (fin::O_JB .. O_DT: column-major
+// blocks) -- the lanes pick those up from the record itself; 91 .. 105 is the residual.
 constexpr int TAB_R = 7, TAB_D = 16 * TAB_R;
+constexpr int TB_JB = 54, TB_JA = 63, TB_HB = 72, TB_HA = 81, TB_DT = 90, TB_ERR = 91, TB_END = 106;
+static_assert(fin::O_JA - fin::O_JB == 9 && fin::O_HB - fin::O_JB == 18 && fin::O_HA - fin::O_JB == 27 && fin::O_DT - fin::O_JB == 36,
+              "the record keeps J_beta, J_alpha, H_beta, H_alpha, dt in one run");
 struct BlkTab { double r[TAB_R]; };
 template <int I> __device__ __forceinline__ double tmul(const BlkTab &T, double x) { return dpp_mul<(I & 15)>(T.r[I >> 4], x); }
 template <int I> __device__ __forceinline__ void tfmac(double &acc, const BlkTab &T, double x) { dpp_fmac<(I & 15)>(acc, T.r[I >> 4], x); }
@@ -437,6 +473,12 @@ __device__ __forceinline__ V3 tab_mulT(const BlkTab &T, V3 v) {
     return o;
 }
 template <int OFF>
+__device__ __forceinline__ void tab_mulT_cm_acc(V3 &o, const BlkTab &T, V3 v) {      // the same for a COLUMN-major block
+    tfmac<OFF + 0>(o.x, T, v.x); tfmac<OFF + 1>(o.x, T, v.y); tfmac<OFF + 2>(o.x, T, v.z);
+    tfmac<OFF + 3>(o.y, T, v.x); tfmac<OFF + 4>(o.y, T, v.y); tfmac<OFF + 5>(o.y, T, v.z);
+    tfmac<OFF + 6>(o.z, T, v.x); tfmac<OFF + 7>(o.z, T, v.y); tfmac<OFF + 8>(o.z, T, v.z);
+}
+template <int OFF>
 __device__ __forceinline__ void tab_mulT_acc(V3 &o, const BlkTab &T, V3 v) {
     tfmac<OFF + 0>(o.x, T, v.x); tfmac<OFF + 3>(o.x, T, v.y); tfmac<OFF + 6>(o.x, T, v.z);
     tfmac<OFF + 1>(o.y, T, v.x); tfmac<OFF + 4>(o.y, T, v.y); tfmac<OFF + 7>(o.y, T, v.z);
@@ -448,19 +490,19 @@ __device__ __forceinline__ void tab_h1t(const double (&v)[15], const BlkTab &T, 
     const V3 vt = ldv(v), vg = ldv(v + 3), vv = ldv(v + 6), va = ldv(v + 9), vp = ldv(v + 12);
     V3 a = tab_mulT<B_B>(T, vt); tab_mulT_acc<B_E>(a, T, vv); tab_mulT_acc<B_F>(a, T, vp);
     put3(g + 0, a);
-    V3 b = tab_mulT<B_JB>(T, vv); tab_mulT_acc<B_JA>(b, T, vp);
+    V3 b = mk(0.0, 0.0, 0.0); tab_mulT_cm_acc<TB_JB>(b, T, vv); tab_mulT_cm_acc<TB_JA>(b, T, vp);
     V3 c = -vg; tab_mulT_acc<B_C>(c, T, vt);
     put3(g + 3, c - b);
     V3 s = vv;                                                        // dt vp + vv
-    tfmac<B_DT>(s.x, T, vp.x); tfmac<B_DT>(s.y, T, vp.y); tfmac<B_DT>(s.z, T, vp.z);
+    tfmac<TB_DT>(s.x, T, vp.x); tfmac<TB_DT>(s.y, T, vp.y); tfmac<TB_DT>(s.z, T, vp.z);
     put3(g + 6, -tab_mulT<B_RK>(T, s));
     put3(g + 12, -tab_mulT<B_RK>(T, vp));
-    V3 h = va; tab_mulT_acc<B_HB>(h, T, vv); tab_mulT_acc<B_HA>(h, T, vp);
+    V3 h = va; tab_mulT_cm_acc<TB_HB>(h, T, vv); tab_mulT_cm_acc<TB_HA>(h, T, vp);
     put3(g + 9, -h);
 }
 template <int C>
 __device__ __forceinline__ void tab_edot(double &acc, const double (&v)[15], const BlkTab &T) {   // + e . v
-    if constexpr (C < 15) { tfmac<hsn::B_ERR + C>(acc, T, v[C]); tab_edot<C + 1>(acc, v, T); }
+    if constexpr (C < 15) { tfmac<TB_ERR + C>(acc, T, v[C]); tab_edot<C + 1>(acc, v, T); }
 }
 // hsn::h2t_vec
 __device__ __forceinline__ void tab_h2t(const double (&w)[15], const BlkTab &T, double (&t)[15]) {
@@ -477,7 +519,7 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
     constexpr int FPW = 4, IN_D = fin::IN_D;
     // [input records -> R -> zx] | [block tables -> lam]; at the end everything is dead and becomes the output stage
     constexpr int U1 = FPW * MAT_D;
-    static_assert(FPW * IN_D <= U1 && FPW * 225 <= U1 && FPW * TAB_D <= U1 && BLK_D <= TAB_D, "the areas are re-used");
+    static_assert(FPW * IN_D <= U1 && FPW * 225 <= U1 && FPW * TAB_D <= U1 && TB_END <= TAB_D, "the areas are re-used");
     __shared__ __attribute__((aligned(16))) double sAll[2 * U1];
     __shared__ double sDummy[2];
     static_assert(FPW * HESS_PACKED + 64 <= 2 * U1, "stage area");
@@ -506,18 +548,19 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
             V3 e5[5];
             factor_shared_core<MODEL>(m, S, e5);
             if (q < 3) state_blocks_column<MODEL>(S, m, q, blk);
-            else if (q == 3) {
-                stb(blk + B_JB, ldcm(m.J_beta)); stb(blk + B_JA, ldcm(m.J_alpha));
-                stb(blk + B_HB, ldcm(m.H_beta)); stb(blk + B_HA, ldcm(m.H_alpha));
-            } else if (q == 4) {
+            else if (q == 4) {
 #pragma unroll
-                for (int a = 0; a < 5; a++) { blk[B_ERR + 3 * a] = e5[a].x; blk[B_ERR + 3 * a + 1] = e5[a].y; blk[B_ERR + 3 * a + 2] = e5[a].z; }
-                blk[B_DT] = m.dt[0];
+                for (int a = 0; a < 5; a++) { blk[TB_ERR + 3 * a] = e5[a].x; blk[TB_ERR + 3 * a + 1] = e5[a].y; blk[TB_ERR + 3 * a + 2] = e5[a].z; }
             }
         }
         wave_lds_fence();
+        const double *rec = sU1 + f * IN_D + (fin::O_JB - TB_JB);
 #pragma unroll
-        for (int r = 0; r < TAB_R; r++) T.r[r] = blk[r * 16 + q];      // entries past BLK_D: never used
+        for (int r = 0; r < TAB_R; r++) {                              // entries past TB_END: never used
+            const int i = r * 16 + q;
+            const bool from_record = (r * 16 + 15 >= TB_JB) && (r * 16 < TB_ERR) && i >= TB_JB && i < TB_ERR;
+            T.r[r] = *(from_record ? rec + i : blk + i);
+        }
         dcol = h2_diag_col(blk, (q < 15) ? q / 3 : 0, (q < 15) ? q % 3 : 0);
     }
     // the input records are dead: the R matrices of the wavefront (900 doubles, coalesced) take their place
@@ -539,7 +582,7 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
         for (int k = 0; k < 15; k++) own[k] = sU1[f * 225 + qr * 15 + k];
         lambda_row_dpp<0>(own, l);
         tab_h1t(l, T, z);
-        double y = tmul<B_ERR>(T, l[0]);
+        double y = tmul<TB_ERR>(T, l[0]);
         tab_edot<1>(y, l, T);
         wave_lds_fence();     // every lane has read R (and its table entries) before the areas become zx / lam
 #pragma unroll
@@ -558,7 +601,7 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
 #pragma unroll
             for (int k = 0; k < 15; k++) zc[k] = sgn * zx[k * ROWP + q];       // column q of Z; for q = 15: -y
             tab_h1t(zc, T, g);
-            double acc = tmul<B_ERR>(T, zc[0]);
+            double acc = tmul<TB_ERR>(T, zc[0]);
             tab_edot<1>(acc, zc, T);
             fq = -acc;
         }
