@@ -430,14 +430,16 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
 // Z into the exchange arrays, then packed columns q and 15 + q; lane 15: column 30 by the same code applied to -y.  The
 // packed triangle is written WITHOUT predicates: a lane stores all 15 entries of its runs, what lies beyond its diagonal
 // falls into a later column's space and is overwritten by its owner, who stores later (hsn / tests/hostsim pin the order).
-// 18.8 KB of LDS and <= 256 registers per wavefront: two wavefronts per SIMD.  History: round 2 formed 31 whitened columns
-// and 496 length-15 dot products (4 362 instructions per wavefront of 4 factors, 1 wavefront per SIMD: 3.4 ms per 1 M
-// factors); a first block version with 5 lanes per factor and 12 factors per wavefront was correct and cut the arithmetic
-// 2.3x but sat at one wavefront per SIMD with 154 doubles of results per lane (2.17 ms).
+// Every product with an entry of R or of the block table is a v_fmac_f64_dpp with a row broadcast as its operand (BlkTab
+// below): no LDS read and no register per entry.  17.3 KB of LDS and <= 256 registers per wavefront: two wavefronts per
+// SIMD.  History: round 2 formed 31 whitened columns and 496 length-15 dot products (4 362 instructions per wavefront of 4
+// factors, 1 wavefront per SIMD: 3.4 ms per 1 M factors); a first block version with 5 lanes per factor and 12 factors per
+// wavefront was correct and cut the arithmetic 2.3x but sat at one wavefront per SIMD with 154 doubles of results per lane
+// (2.17 ms); this mapping with the block table in LDS and two-instruction broadcasts: 1.78 ms; as shipped: 1.50 ms.
 constexpr int HESS_PACKED = 496;
 // Row q of Lam = R^T R with lane q of a 16-lane DPP row holding column q of R (own[k] = R[k][q], zeros below the diagonal):
-// Lam[q][c] = sum_{k <= c} R[k][q] R[k][c], and R[k][c] is register own[k] of lane c -- a DPP row_share broadcast (two
-// v_mov_b32_dpp) instead of 120 LDS reads per lane: the LDS pipe of a CU, shared by its eight wavefronts, is what bounds
+// Lam[q][c] = sum_{k <= c} R[k][q] R[k][c], and R[k][c] is register own[k] of lane c -- the broadcast operand of a DPP
+// multiply-add instead of 120 LDS reads per lane: the LDS pipe of a CU, shared by its eight wavefronts, is what bounds
 // this kernel.  Same terms in the same order as hsn::lambda_row (the host twin).
 template <int C>
 __device__ __forceinline__ void lambda_row_dpp(const double (&own)[15], double (&l)[15]) {
