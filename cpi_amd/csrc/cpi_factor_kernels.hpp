@@ -519,23 +519,34 @@ template <int MODEL>
 __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
     using namespace hsn;
     constexpr int FPW = 4, IN_D = fin::IN_D;
-    // [input records -> R -> zx] | [block tables -> lam]; at the end everything is dead and becomes the output stage
+    // [input records | R] -> [zx | lam] with the block tables at the far end (dead before lam reaches them); at the end
+    // everything is dead and becomes the output stage
     constexpr int U1 = FPW * MAT_D;
-    static_assert(FPW * IN_D <= U1 && FPW * 225 <= U1 && FPW * TAB_D <= U1 && TB_END <= TAB_D, "the areas are re-used");
+    static_assert(FPW * IN_D <= U1 && FPW * 225 <= U1 && TB_END <= TAB_D, "the areas are re-used");
     __shared__ __attribute__((aligned(16))) double sAll[2 * U1];
     __shared__ double sDummy[2];
     static_assert(FPW * HESS_PACKED + 64 <= 2 * U1, "stage area");
     double *sU1 = sAll, *sLam = sAll + U1;
+    double *sR = sAll + FPW * IN_D, *sTab = sAll + 2 * U1 - FPW * TAB_D;
+    static_assert(FPW * IN_D + FPW * 225 <= 2 * U1 - FPW * TAB_D, "R sits between the records and the block tables");
     const int lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     const int q = lane & 15, f = min(lane >> 4, nf - 1);     // missing factors shadow the last one (same values, same slots)
     const int qr = min(q, 14);                               // lane 15 shadows row 14 in the row phase
 
-    // ---- the input records (one round trip).  R follows after the block tables: the neighbour wavefront covers the second
-    // round trip
+    // ---- the input records
     constexpr int RT = (FPW * 225 + 63) / 64;
-    factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sU1, sDummy);
+    {
+        // the R matrices of the wavefront (900 doubles, coalesced) travel with the input records: ONE memory round trip
+        double rr[RT];
+#pragma unroll
+        for (int t = 0; t < RT; t++) rr[t] = A.sqrt_info[f0 * 225 + min(lane + 64 * t, nf * 225 - 1)];
+        factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sU1, sDummy);
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+            if (lane + 64 * t < FPW * 225) sR[lane + 64 * t] = rr[t];
+    }
     __syncthreads();
 
     // ---- block table of the factor: the state-dependent blocks (three column tasks), the measurement's bias Jacobians,
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
     BlkTab T;
     V3 dcol;                                                 // the lane's column of its diagonal block of H2
     {
-        double *blk = sLam + f * TAB_D;
+        double *blk = sTab + f * TAB_D;
         {
             const FactorMeas m = factor_meas_of(sU1 + f * IN_D, A.grav);
             FactorShared S;
@@ -565,23 +576,13 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
         }
         dcol = h2_diag_col(blk, (q < 15) ? q / 3 : 0, (q < 15) ? q % 3 : 0);
     }
-    // the input records are dead: the R matrices of the wavefront (900 doubles, coalesced) take their place
-    {
-        double rr[RT];
-#pragma unroll
-        for (int t = 0; t < RT; t++) rr[t] = A.sqrt_info[f0 * 225 + min(lane + 64 * t, nf * 225 - 1)];
-#pragma unroll
-        for (int t = 0; t < RT; t++)
-            if (lane + 64 * t < FPW * 225) sU1[lane + 64 * t] = rr[t];
-    }
-    wave_lds_fence();
 
     // ---- row phase: row q of Lam and of Z, y_q
     double *lam = sLam + f * MAT_D, *zx = sU1 + f * MAT_D;
     {
         double l[15], z[15], own[15];
 #pragma unroll
-        for (int k = 0; k < 15; k++) own[k] = sU1[f * 225 + qr * 15 + k];
+        for (int k = 0; k < 15; k++) own[k] = sR[f * 225 + qr * 15 + k];
         lambda_row_dpp<0>(own, l);
         tab_h1t(l, T, z);
         double y = tmul<TB_ERR>(T, l[0]);
