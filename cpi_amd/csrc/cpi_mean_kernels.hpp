@@ -20,7 +20,8 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
     // L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us, 15 k with L = 4: 16.0 -> 15.3 us, 10 k with L = 6:
     // 12.5 -> 11.8 us once the padded second step of an odd last chunk is skipped), 1 when a wave is latency-bound
     // with few intervals per lane (L >= 12: 5 k windows 9.55 vs 9.65 us, 2.5 k 7.7 vs 8.0 us); 3 / 4 knots per chunk cost the second
-    // wavefront per SIMD
+    // wavefront per SIMD (L = 1, 1 M x 50 windows: 659 / 665 us against 651 us, model 2 700 / 1 919 against 640 us -- the longer
+    // pieces do not buy back what the re-touched 128-byte lines cost)
     constexpr int C = (L <= 8 && !JAC) ? 2 : 1;
     constexpr int SEGD = 7 * C;       // doubles per lane per chunk
     constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
