@@ -50,7 +50,8 @@ def load():
     lib.cpi_abi_version.restype = C.c_int
     if lib.cpi_abi_version() != ABI_VERSION:
         raise ImportError("cpi_amd: %s has ABI version %d, this binding expects %d (stale build?)" % (LIB_PATH, lib.cpi_abi_version(), ABI_VERSION))
-    missing = [n for n in ("cpi_preintegrate_stream", "cpi_assemble_tiles", "cpi_tile_windows", "cpi_outputs_bind_slab", "cpi_preintegrate_tiled_batch_host")
+    missing = [n for n in ("cpi_preintegrate_stream", "cpi_assemble_tiles", "cpi_tile_windows", "cpi_outputs_bind_slab", "cpi_preintegrate_tiled_batch_host",
+                          "cpi_preintegrate_stream_host")
                if not hasattr(lib, n)]
     if missing:
         raise ImportError("cpi_amd: %s lacks %s (a build from before round 3: run python -m cpi_amd.build --force)" % (LIB_PATH, ", ".join(missing)))
@@ -83,6 +84,7 @@ def load():
     lib.cpi_stream_counts.restype = C.c_void_p
     lib.cpi_preintegrate_stream.argtypes = [vp, C.POINTER(CpiParams), i64, dp, i64, dp, i32, dp, dp, vp, C.POINTER(CpiOutputs)]
     lib.cpi_preintegrate_stream.restype = C.c_int
+    lib.cpi_preintegrate_stream_host.argtypes = [vp, C.POINTER(CpiParams), i64, dp, i64, dp, i32, dp, dp, C.POINTER(CpiOutputs), vp]
     lib.cpi_tile_windows.argtypes = [vp, i64, i32, dp, vp, vp, dp]
     lib.cpi_assemble_tiles.argtypes = [vp, i64, dp, i64, dp, i32, dp, vp]
     lib.cpi_preintegrate_tiled_batch_host.argtypes = [vp, C.POINTER(CpiParams), i64, i32, dp, vp, dp, dp, C.POINTER(CpiOutputs)]
@@ -108,7 +110,7 @@ def load():
               lib.cpi_predict_batch, lib.cpi_preintegrate_batch_host, lib.cpi_factor_eval_batch_host, lib.cpi_factor_hessian_batch,
               lib.cpi_preintegrate_tiled_batch, lib.cpi_tile_knots, lib.cpi_group_create, lib.cpi_group_gather, lib.cpi_group_synchronize, lib.cpi_group_size, lib.cpi_ctx_set_stream,
               lib.cpi_tile_windows, lib.cpi_assemble_tiles, lib.cpi_preintegrate_tiled_batch_host, lib.cpi_outputs_bind_slab,
-              lib.cpi_group_last_gather_messages, lib.cpi_test_group_create_shared):
+              lib.cpi_group_last_gather_messages, lib.cpi_test_group_create_shared, lib.cpi_preintegrate_stream_host):
         f.restype = C.c_int
     _lib = lib
     return lib

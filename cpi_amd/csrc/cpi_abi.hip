@@ -1074,6 +1074,43 @@ extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, 
     return CPI_OK;
 }
 
+// The stream entry from HOST memory: what a GraphSolver-shaped caller holds (its IMU deque as one array, the update times of the
+// states it creates, one linearisation point per window) -> the measurements of every window, in host memory.  One-off
+// staging (the stream is uploaded once, whole); the windows are cut on the device.
+extern "C" int cpi_preintegrate_stream_host(cpi_ctx *ctx, const cpi_params *prm, int64_t K, const double *stream, int64_t U,
+                                            const double *update_times, int32_t N, const double *lin, const double *q_k_lin,
+                                            const cpi_outputs *out, int32_t *count) {
+    if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
+    if (K < 0 || U < 0 || N < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream_host: negative size");
+    if (U == 0) return CPI_OK;
+    if (K == 0) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream_host: the stream is empty");
+    if (!prm || !out || !stream || !update_times || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream_host: NULL argument");
+    if (prm->model == CPI_MODEL_V2 && !q_k_lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream_host: model 2 needs q_k_lin");
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    DevBuf ds, du, dl, dq, dw, dout[12];
+    CPI_UP(ds, stream, (size_t)K * 7 * sizeof(double));
+    CPI_UP(du, update_times, (size_t)U * sizeof(double));
+    CPI_UP(dl, lin, (size_t)U * 6 * sizeof(double));
+    CPI_UP(dq, q_k_lin, (size_t)U * 4 * sizeof(double));
+    CPI_HIP(ctx, hipMalloc(&dw.p, cpi_stream_workspace_bytes(U)));
+    cpi_outputs d = *out, h = *out;
+    for (int k = 0; k < 12; k++)
+        if (*out_field(&h, k)) {
+            CPI_HIP(ctx, hipMalloc(&dout[k].p, (size_t)U * OUT_N[k] * sizeof(double)));
+            *out_field(&d, k) = (double *)dout[k].p;
+        }
+    const int rc = cpi_preintegrate_stream(ctx, prm, K, (const double *)ds.p, U, (const double *)du.p, N, (const double *)dl.p,
+                                           (const double *)dq.p, dw.p, &d);
+    if (rc != CPI_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    for (int k = 0; k < 12; k++)
+        if (*out_field(&h, k))
+            CPI_HIP(ctx, hipMemcpyAsync(*out_field(&h, k), dout[k].p, (size_t)U * OUT_N[k] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (count) CPI_HIP(ctx, hipMemcpyAsync(count, cpi_stream_counts(dw.p, U), (size_t)U * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CPI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CPI_OK;
+}
+
 extern "C" int cpi_factor_eval_batch_host(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
                                           const cpi_outputs *meas, const double *lin, const double *q_k_lin,
                                           const double *states, int64_t S, const int32_t *idx_i,

@@ -11,6 +11,7 @@
 // launch -- the intended use).  Matrices are plain column-major arrays (Eigen::Map them if needed).
 // Header-only; link with -lcpi_amd.  No CPU fallback: errors throw std::runtime_error.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstdlib>
@@ -394,6 +395,63 @@ inline TiledWindowSet assemble_windows_tiled(const std::vector<double> &stream, 
     return ts;
 }
 
+// ---- the caller's loop for MANY windows at once --------------------------------------------------------------------
+// What GraphSolver keeps between two states is a deque of IMU readings (GraphSolver.h: imu_times / imu_linaccs /
+// imu_angvel, filled by addmeasurement_imu); createimufactor_cpi_v1 / _v2 (GraphSolver_IMU.cpp:34-134) walk it up to the
+// update time, feed a CpiV1 / CpiV2 and read its members.  ImuStream is that deque as one array, and preintegrate() is that
+// loop for EVERY update time in one call: the stream goes to the device once, the kernels cut the windows themselves
+// (cpi_preintegrate_stream_host), one CpiResult per update time comes back -- window u covers (update[u-1], update[u]]
+// (the first one starts at the stream's first reading), its tail interval holds the front reading until the update time.
+class ImuStream {
+public:
+    void push(double t, const Vec3 &w, const Vec3 &a) {           // GraphSolver::addmeasurement_imu
+        knots_.push_back(t);
+        for (int i = 0; i < 3; i++) knots_.push_back(w[i]);
+        for (int i = 0; i < 3; i++) knots_.push_back(a[i]);
+    }
+    void assign(const std::vector<double> &knots) { knots_ = knots; }   // e.g. parse_imu_text's records
+    size_t size() const { return knots_.size() / 7; }
+    const std::vector<double> &knots() const { return knots_; }
+    // prm: cpi_params as CpiBase::params() builds them (model, sigmas, gravity, flags).  lin [U][6] = b_w_lin, b_a_lin per window;
+    // q_k_lin [U][4] (model 2; may be empty otherwise).  counts (optional) receives every window's interval count.
+    // A window longer than max_intervals (default: as long as the stream) is an error, not a truncation.
+    std::vector<CpiResult> preintegrate(const Context &ctx, const cpi_params &prm, const std::vector<double> &update_times,
+                                        const std::vector<double> &lin, const std::vector<double> &q_k_lin = std::vector<double>(),
+                                        std::vector<int32_t> *counts = nullptr, int32_t max_intervals = 0) const {
+        const int64_t U = (int64_t)update_times.size(), K = (int64_t)size();
+        if ((int64_t)lin.size() != U * 6) throw std::runtime_error("ImuStream::preintegrate: lin must hold 6 doubles per update time");
+        if (!q_k_lin.empty() && (int64_t)q_k_lin.size() != U * 4) throw std::runtime_error("ImuStream::preintegrate: q_k_lin must hold 4 doubles per update time");
+        std::vector<CpiResult> res((size_t)U);
+        if (U == 0) return res;
+        const int32_t N = max_intervals > 0 ? max_intervals : (int32_t)std::min<int64_t>(std::max<int64_t>(K, 1), 65535);
+        std::vector<double> DT(U), al(U * 3), be(U * 3), q(U * 4), Jq(U * 9), Ja(U * 9), Jb(U * 9), Ha(U * 9), Hb(U * 9), Oa(U * 9),
+            Ob(U * 9), P(U * 225);
+        cpi_outputs o{ DT.data(), al.data(), be.data(), q.data(), Jq.data(), Ja.data(), Jb.data(), Ha.data(), Hb.data(),
+                       prm.model == CPI_MODEL_V2 ? Oa.data() : nullptr, prm.model == CPI_MODEL_V2 ? Ob.data() : nullptr, P.data() };
+        std::vector<int32_t> cnt((size_t)U);
+        ctx.check(cpi_preintegrate_stream_host(ctx.get(), &prm, K, knots_.data(), U, update_times.data(), N, lin.data(),
+                                               q_k_lin.empty() ? nullptr : q_k_lin.data(), &o, cnt.data()));
+        for (int64_t u = 0; u < U; u++)
+            if (cnt[u] > N) throw std::runtime_error("ImuStream::preintegrate: window " + std::to_string(u) + " holds " + std::to_string(cnt[u]) +
+                                                     " intervals, more than max_intervals = " + std::to_string(N));
+        for (int64_t w = 0; w < U; w++) {
+            CpiResult &r = res[w];
+            r.DT = DT[w];
+            for (int i = 0; i < 3; i++) { r.alpha_tau[i] = al[w * 3 + i]; r.beta_tau[i] = be[w * 3 + i]; }
+            for (int i = 0; i < 4; i++) r.q_k2tau[i] = q[w * 4 + i];
+            for (int i = 0; i < 9; i++) {
+                r.J_q[i] = Jq[w * 9 + i]; r.J_a[i] = Ja[w * 9 + i]; r.J_b[i] = Jb[w * 9 + i]; r.H_a[i] = Ha[w * 9 + i];
+                r.H_b[i] = Hb[w * 9 + i]; r.O_a[i] = Oa[w * 9 + i]; r.O_b[i] = Ob[w * 9 + i];
+            }
+            for (int i = 0; i < 225; i++) r.P_meas[i] = P[w * 225 + i];
+        }
+        if (counts) *counts = cnt;
+        return res;
+    }
+private:
+    std::vector<double> knots_;
+};
+
 // evaluateError-shaped evaluator (ImuFactorCPIv1.h:139 / ImuFactorCPIv2.h:151).  state = 16 doubles
 // [q(4) bg(3) v(3) ba(3) p(3)]; error[15]; H1/H2 column-major 15x15, may be nullptr.
 class ImuFactorCPI {
@@ -401,6 +459,11 @@ public:
     // built straight from a finished preintegrator, with the field->ctor mapping of GraphSolver_IMU.cpp:74-75,129-130
     explicit ImuFactorCPI(const CpiBase &cpi) : model_(cpi.factor_model()), m_(cpi), grav_(cpi.grav), qk_(cpi.q_k_lin) {
         for (int i = 0; i < 3; i++) { lin_[i] = cpi.b_w_lin[i]; lin_[3 + i] = cpi.b_a_lin[i]; }
+    }
+    // from a window of ImuStream::preintegrate: the measurement, the model (1 / 2) and the linearisation point it was made with
+    ImuFactorCPI(int model, const CpiResult &meas, const Vec3 &grav, const Vec3 &b_w_lin, const Vec3 &b_a_lin, const Vec4 &q_k_lin = Vec4{{0, 0, 0, 1}})
+        : model_(model == CPI_MODEL_FORSTER ? CPI_MODEL_V1 : model), m_(meas), grav_(grav), qk_(q_k_lin) {
+        for (int i = 0; i < 3; i++) { lin_[i] = b_w_lin[i]; lin_[3 + i] = b_a_lin[i]; }
     }
     void evaluateError(const Context &ctx, const double *state_i, const double *state_j, double *error, double *H1 = nullptr,
                        double *H2 = nullptr) {

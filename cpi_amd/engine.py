@@ -227,6 +227,30 @@ class Engine:
         """Device workspace of preintegrate_stream for U windows (28 bytes per window; re-usable across calls)."""
         return torch.empty((self.lib.cpi_stream_workspace_bytes(U) // 8 + 1,), dtype=torch.float64, device=self.device)
 
+    def preintegrate_stream_host(self, stream, update_times, lin, q_k_lin=None, params=None, want=("mean", "jac", "cov"), N=None,
+                                 pinned=False, return_counts=False):
+        """preintegrate_stream for a caller that holds everything in HOST memory (cpi_preintegrate_stream_host): the IMU
+        stream [K,7], the update times [U], one linearisation point per window -- CPU float64 tensors in, CPU tensors out;
+        synchronous.  A window longer than N intervals raises (N defaults to the stream's length: nothing can be)."""
+        params = params or self.make_params()
+        K, U = stream.shape[0], update_times.shape[0]
+        N = int(N) if N is not None else min(max(K, 1), 65535)
+        for t in (stream, update_times, lin, q_k_lin):
+            assert t is None or (not t.is_cuda and t.is_contiguous() and t.dtype == torch.float64), "inputs must be contiguous CPU float64 tensors"
+        out = {}
+        for name, n in OUT_FIELDS:
+            grp = "mean" if name in MEAN_FIELDS else ("cov" if name == "P" else "jac")
+            if grp in want and (params.model == 2 or name not in ("O_a", "O_b")):
+                out[name] = torch.empty((U,) if n == 1 else (U, n), dtype=torch.float64, pin_memory=pinned)
+        cnt = torch.empty((U,), dtype=torch.int32)
+        o = self._outputs_struct(out)
+        self._sync_stream()
+        self._check(self.lib.cpi_preintegrate_stream_host(self.ctx, C.byref(params), K, _ptr(stream), U, _ptr(update_times), N,
+                                                          _ptr(lin), _ptr(q_k_lin), C.byref(o), _ptr(cnt)))
+        if U and int(cnt.max()) > N:
+            raise ValueError("preintegrate_stream_host: a window has %d intervals, N = %d" % (int(cnt.max()), N))
+        return (out, cnt) if return_counts else out
+
     def preintegrate_tiled_host(self, tiles, W, lin, q_k_lin=None, params=None, count=None, pinned=True, out=None):
         """Mean outputs from tiles held in HOST memory (cpi_preintegrate_tiled_batch_host: chunked upload / kernel /
         download pipeline).  CPU float64 tensors; returns CPU tensors; synchronous."""

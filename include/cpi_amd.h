@@ -36,7 +36,8 @@ extern "C" {
                                additions within 2 (new symbols only): tiled layout entries, cpi_host_alloc / _free;
                                round 3: cpi_preintegrate_stream (+ _workspace_bytes, _counts), cpi_tile_windows,
                                cpi_assemble_tiles, cpi_preintegrate_tiled_batch_host,
-                               cpi_outputs_slab_doubles / _bind_slab, cpi_group_last_gather_messages */
+                               cpi_outputs_slab_doubles / _bind_slab, cpi_group_last_gather_messages,
+                               cpi_preintegrate_stream_host */
 
 enum { CPI_OK = 0, CPI_ERR_INVALID = 1, CPI_ERR_HIP = 2, CPI_ERR_NO_DEVICE = 3, CPI_ERR_RCCL = 4 };
 enum {
@@ -304,6 +305,14 @@ int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, 
 int cpi_preintegrate_tiled_batch_host(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *tiles,
                                       const int32_t *count, const double *lin, const double *q_k_lin, const cpi_outputs *out);
 /* page-locked host memory for the entries above (hipHostMalloc / hipHostFree); NULL when the allocation fails */
+/* cpi_preintegrate_stream with HOST pointers -- what a caller shaped like GraphSolver::createimufactor_cpi_v1/v2
+ * (GraphSolver_IMU.cpp:34-134) holds: its IMU deque as one array stream[K][7], the update times of the states it creates,
+ * one linearisation point per window; the measurements of every window come back in host memory.  count (may be NULL)
+ * receives the TRUE interval count of every window (> N: that window was truncated to N intervals).  The stream is uploaded
+ * once, whole; the windows are cut on the device.  PCIe-inclusive, never the benchmarked path. */
+int cpi_preintegrate_stream_host(cpi_ctx *ctx, const cpi_params *prm, int64_t K, const double *stream, int64_t U,
+                                 const double *update_times, int32_t N, const double *lin, const double *q_k_lin,
+                                 const cpi_outputs *out, int32_t *count);
 void *cpi_host_alloc(size_t bytes);
 void cpi_host_free(void *p);
 int cpi_factor_eval_batch_host(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,

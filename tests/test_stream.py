@@ -274,3 +274,82 @@ def test_gpu_stream_windows_vs_deque_oracle(mode):
     torch.cuda.synchronize()
     ref = op.oracle().stream(op.make_params(*mode), kn, ut, lin, q)
     check_pre({k: v.cpu().numpy() for k, v in out.items()}, ref, v2=(mode[0] == 2), label="stream %s" % (mode,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", [1, 2, 3])
+def test_gpu_stream_host_entry_equals_the_device_entry(model):
+    """cpi_preintegrate_stream_host: the same call for a caller that holds the stream, the update times and the
+    linearisation points in HOST memory -- bit for bit the device entry's results, the true counts, and a window that
+    does not fit its bound is an error."""
+    import torch
+    import cpi_amd
+    eng = cpi_amd.Engine()
+    kn = st.parse_imu_text(open(DATA).read())
+    ut = _updates(kn)
+    ut = np.sort(np.concatenate([ut, [kn[0, 0] - 1.0, ut[7], kn[-1, 0] + 0.5]]))
+    _, _, count = st.assemble_windows(kn, ut)
+    U = len(ut)
+    rng = np.random.default_rng(1)
+    lin = np.concatenate([0.01 * rng.standard_normal((U, 3)), 0.05 * rng.standard_normal((U, 3))], axis=1)
+    q = rng.standard_normal((U, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); q[q[:, 3] < 0] *= -1
+    H = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    prm = eng.make_params(model)
+    qq = None if model == 3 else H(q)
+    host, cnt = eng.preintegrate_stream_host(H(kn), H(ut), H(lin), qq, prm, return_counts=True)
+    dev = eng.preintegrate_stream(H(kn).to(eng.device), H(ut).to(eng.device), H(lin).to(eng.device),
+                                  None if qq is None else qq.to(eng.device), prm)
+    torch.cuda.synchronize()
+    assert np.array_equal(cnt.numpy(), count)
+    for k, v in host.items():
+        assert torch.equal(v, dev[k].cpu()), (model, k)
+    only_means = eng.preintegrate_stream_host(H(kn), H(ut), H(lin), qq, prm, want=("mean",), N=int(count.max()), pinned=True)
+    # (a mean-only request runs the composing mean kernel, a full one carries the means in the covariance kernel: same to rounding)
+    assert sorted(only_means) == ["DT", "alpha", "beta", "q"] and (only_means["alpha"] - host["alpha"]).abs().max().item() < 1e-12
+    with pytest.raises(ValueError):
+        eng.preintegrate_stream_host(H(kn), H(ut), H(lin), qq, prm, N=int(count.max()) - 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", [1, 2])
+def test_gpu_cpp_imu_stream_facade(model):
+    """cpi_host::ImuStream -- the caller's loop of GraphSolver_IMU.cpp:34-134 for every update time in one call, from C++
+    through the C-ABI: the reference's IMU text excerpt -> parse_imu_text -> ImuStream::preintegrate -> one CpiResult per
+    window, against the oracle's restatement of the reference's deque loop; then window 1 wrapped in an ImuFactorCPI and
+    evaluated, against the oracle's evaluateError."""
+    from cpi_amd import _lib
+    _lib.load()
+    kn = st.parse_imu_text(open(DATA).read())
+    ut = _updates(kn)
+    _, _, count = st.assemble_windows(kn, ut)
+    U = len(ut)
+    rng = np.random.default_rng(5)
+    lin = np.concatenate([0.01 * rng.standard_normal((U, 3)), 0.05 * rng.standard_normal((U, 3))], axis=1)
+    q = rng.standard_normal((U, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); q[q[:, 3] < 0] *= -1
+    tmp = tempfile.mkdtemp()
+    exe, libdir = os.path.join(tmp, "test_imu_stream"), os.path.join(ROOT, "cpi_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_imu_stream.cpp"), "-o", exe,
+                           "-L" + libdir, "-lcpi_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    np.savetxt(os.path.join(tmp, "ut.txt"), ut, fmt="%.17g")
+    np.savetxt(os.path.join(tmp, "lin.txt"), np.concatenate([lin, q], axis=1), fmt="%.17g")
+    p = subprocess.run([exe, DATA, os.path.join(tmp, "ut.txt"), os.path.join(tmp, "lin.txt"), str(model)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().split("\n")
+    rows = np.array([[float(x) for x in ln.split()] for ln in lines[:U]])
+    names = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9), ("H_a", 9), ("H_b", 9),
+             ("O_a", 9), ("O_b", 9), ("P", 225)]
+    out, o = {}, 0
+    for name, n in names:
+        out[name] = rows[:, o] if n == 1 else rows[:, o:o + n]
+        o += n
+    oprm = op.make_params(model, 0, 1)
+    ref = op.oracle().stream(oprm, kn, ut, lin, q)
+    check_pre(out, ref, v2=(model == 2), label="c++ ImuStream m%d" % model)
+    assert lines[U].split()[0] == "COUNT" and np.array_equal(np.array(lines[U].split()[1:], dtype=np.int32), count)
+    assert lines[U + 1] == "BOUND 1"
+    err = np.array([float(x) for x in lines[U + 2].split()[1:]])
+    rec = op.factor_records({k: v[1:2] for k, v in ref.items()}, lin[1:2], q[1:2] if model == 2 else None)
+    x = np.array([[0, 0, 0, 1, *lin[1, 0:3], 0.1, -0.2, 0.05, *lin[1, 3:6], 1, 2, 3]], dtype=np.float64)
+    e_ref, _, _ = op.oracle().factor(model, rec, x, x)
+    assert np.abs(err - e_ref[0]).max() <= 1e-9 * max(1.0, np.abs(e_ref).max())

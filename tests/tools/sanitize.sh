@@ -7,7 +7,7 @@
 #   tests/tools/sanitize.sh gpu    (GPU box)        the C-ABI's host translation unit (cpi_abi.hip: contexts, device sets, the
 #                                                   slab gather, the three-stream host pipeline) rebuilt with ASan + UBSan and
 #                                                   linked with the ordinary kernel objects into libcpi_amd_asan.so; the C++
-#                                                   hosts (tests/cpp/test_facade / test_group incl. the 5-rank shared mode /
+#                                                   hosts (tests/cpp/test_facade / test_imu_stream / test_group incl. the 5-rank shared mode /
 #                                                   test_threads) compiled with the same runtime against it; ThreadSanitizer on
 #                                                   test_threads
 # Writes gpurun_out/sanitize_<part>.txt; exit code 0 = no sanitizer report.
@@ -53,7 +53,7 @@ else
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC $SAN -fno-gpu-sanitize -DCPI_BUILD_ID=\"$BID\" -c -o build/san/cpi_abi_asan.o cpi_amd/csrc/cpi_abi.hip || exit 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $SAN -o build/san/libcpi_amd.so build/san/cpi_abi_asan.o cpi_amd/csrc/_obj/cpi_mean.o cpi_amd/csrc/_obj/cpi_cov.o cpi_amd/csrc/_obj/cpi_factor.o -ldl || exit 2
   LNK="-Lbuild/san -lcpi_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$R/build/san -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,$RT"
-  for t in test_facade test_group test_threads; do
+  for t in test_facade test_group test_threads test_imu_stream; do
     $CXX -std=c++17 -O1 $SAN -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/cpp/$t.cpp -o build/san/${t}_asan $LNK || exit 2
   done
   export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:protect_shadow_gap=0 UBSAN_OPTIONS=print_stacktrace=1
@@ -73,6 +73,17 @@ PY
   run "test_group 1 device" build/san/test_group_asan build/san/w48.bin 1 1
   run "test_group 5 ranks on one device (slab gather, RCCL stand-in)" env CPI_AMD_RCCL_LIB=$FAKE build/san/test_group_asan build/san/w48.bin 2 5 shared
   run "test_threads 4 host threads (ASan+UBSan)" build/san/test_threads_asan build/san/thr.bin 4
+  python - <<'PY'
+import numpy as np
+kn = np.loadtxt('tests/golden/imu_gazebo200_excerpt.dat')
+t0 = 1e-3 * kn[0, 7]
+ut = t0 + 0.0523 + 0.1 * np.arange(20)
+np.savetxt('build/san/ut20.txt', ut, fmt='%.17g')
+r = np.random.default_rng(2)
+q = r.standard_normal((20, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); q[q[:, 3] < 0] *= -1
+np.savetxt('build/san/lin20.txt', np.concatenate([0.01 * r.standard_normal((20, 6)), q], axis=1), fmt='%.17g')
+PY
+  for m in 1 2 3; do run "test_imu_stream model $m (ASan+UBSan: ImuStream facade, cpi_preintegrate_stream_host)" build/san/test_imu_stream_asan tests/golden/imu_gazebo200_excerpt.dat build/san/ut20.txt build/san/lin20.txt $m; done
   # ThreadSanitizer: the facade + test are instrumented, the HIP runtime is not (its internal threads are invisible to TSan)
   $CXX -std=c++17 -O1 -fsanitize=thread -g -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/cpp/test_threads.cpp -o build/san/test_threads_tsan \
       -Lcpi_amd -lcpi_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$R/cpi_amd -Wl,-rpath,/opt/rocm/lib 2>> $OUT || say "TSan build failed"
