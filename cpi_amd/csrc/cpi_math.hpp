@@ -1165,7 +1165,11 @@ CPI_HD void factor_eval_col(const FactorMeas &f, int c, double &err_c, double h1
 // ONE LANE PER ROW / COLUMN: lane q < 15 of a factor owns row q of Lam and of Z, then packed columns q and 15 + q of the
 // result; lane 15 owns column 30 (g, f), which is the SAME arithmetic applied to -y = -Lam e instead of a column of Z.  The
 // exchange (rows -> columns) goes through the arrays lam / zx (LDS on the device, host memory in tests/hostsim): 15 rows
-// pitched 16 doubles, column 15 of zx holds y.  The functions below are a lane's arithmetic; block table `blk` per factor:
+// pitched 18 doubles, column 15 of zx holds y.  The functions below are a lane's arithmetic on a block table `blk` in memory.
+// The device kernel shares state_blocks_column, h2_diag_col, rows_comb and pk with the host emulation; its products with table
+// entries are DPP broadcast operands (cpi_factor_kernels.hpp: tab_h1t / tab_h2t, the table spread over the factor's lanes),
+// of which z_row / h1t_vec / h2t_vec / lane_columns here are the plain-memory twins that tests/hostsim checks against the
+// dense definition (same terms; sums of block products accumulate in one chain there, pairwise here).
 namespace hsn {
 static const int B_B = 0, B_C = 9, B_E = 18, B_F = 27, B_A = 36, B_RK = 45, B_JB = 54, B_JA = 63, B_HB = 72, B_HA = 81,
                  B_ERR = 90, B_DT = 105, BLK_D = 108;       // 3x3 blocks ROW-major; residual e[15]; dt; 2 of padding
@@ -1279,8 +1283,10 @@ CPI_HD void rows_comb(const double *mat, int j, V3 d, double out[15]) {
     for (int c0 = 0; c0 < 15; c0 += 5) {      // five columns at a time: 15 doubles of rows in flight, not 45
 #pragma unroll
         for (int c = c0; c < c0 + 5; c++) out[c] = fma(d.z, r2[c], fma(d.y, r1[c], d.x * r0[c]));
+#ifndef CPI_ROWS_NOPIN
         CPI_PIN3(out[c0], out[c0 + 1], out[c0 + 2]);
         CPI_PIN1(out[c0 + 3]); CPI_PIN1(out[c0 + 4]);
+#endif
     }
 }
 // t[3 i + m] = (D_i^T w_i)[m]: from w = (D_j^T Lam_j.)[n, :] the column of G22; from w = -y the g2 part of column 30
