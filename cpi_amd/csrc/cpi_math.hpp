@@ -1283,10 +1283,8 @@ CPI_HD void rows_comb(const double *mat, int j, V3 d, double out[15]) {
     for (int c0 = 0; c0 < 15; c0 += 5) {      // five columns at a time: 15 doubles of rows in flight, not 45
 #pragma unroll
         for (int c = c0; c < c0 + 5; c++) out[c] = fma(d.z, r2[c], fma(d.y, r1[c], d.x * r0[c]));
-#ifndef CPI_ROWS_NOPIN
-        CPI_PIN3(out[c0], out[c0 + 1], out[c0 + 2]);
+        CPI_PIN3(out[c0], out[c0 + 1], out[c0 + 2]);      // (without the pins: the same registers, the same 1.39 ms)
         CPI_PIN1(out[c0 + 3]); CPI_PIN1(out[c0 + 4]);
-#endif
     }
 }
 // t[3 i + m] = (D_i^T w_i)[m]: from w = (D_j^T Lam_j.)[n, :] the column of G22; from w = -y the g2 part of column 30
