@@ -125,3 +125,18 @@ def test_dpp_sources_are_not_fresh_valu_results():
     n, bad = dpp_hazards.check(os.path.join(ROOT, "cpi_amd", "libcpi_amd.so"))
     assert n > 500, "the Hessian sweep's DPP multiply-adds are gone?"
     assert not bad, bad[:5]
+
+
+def test_cpp_hosts_compile_against_the_facade_without_a_gpu():
+    """Every C++ host under tests/cpp/ must compile (syntax + semantics, no link, no GPU) against cpi_host.hpp and
+    include/cpi_amd.h: a change of the facade or of the C-ABI that breaks a caller shows up in the CPU suite, not only on
+    the GPU box.  (test_group / test_threads include the HIP runtime API for device buffers.)"""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "cpp")
+    for f in sorted(os.listdir(d)):
+        if not f.endswith(".cpp"):
+            continue
+        cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror=return-type", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+               os.path.join(d, f)]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0, "%s:\n%s" % (f, p.stdout[-2000:])
