@@ -1,0 +1,48 @@
+"""CPU: bench.py's output contract without a GPU -- emit() turns a headline + the full extra rows into ONE last stdout line
+of < 6 KB that the driver can parse (round 3's 33 KB line came back as `parsed: null`) and writes the full rows to
+bench_extra.json."""
+import json
+
+import bench
+
+
+def _row(name, W, with_cpu=True):
+    r = {"workload": name, "units_per_step": W, "samples": 50, "value": 1.234567891234e8, "unit": "windows/s", "launch_ms": 1.23456789,
+         "launch_mode": "graph", "roofline": bench.roofline_of(name, W, 50, 1.2e-3, {}, "no profiles/r04_pmc.json")}
+    if with_cpu:
+        r["cpu_baseline"] = {"value": 4.0e4, "unit": "windows/s", "cores": 16, "kind": "reference", "single_core_value": 2.6e3, "sample": "x" * 300}
+    return r
+
+
+def test_emit_keeps_the_last_line_under_6k_and_writes_the_rows(tmp_path, monkeypatch, capsys):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    res = {"metric": "preintegration windows/sec (50-sample windows)", "value": 7.1e8, "unit": "windows/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+           "ms_per_step": 0.014, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "v1_mean: 10000 windows x 50 samples per GPU per step, CPI model 1, mean-only (BASELINE.json configs[1])",
+                      "pool_batches": 12, "clock_preramp_ms": 60.0, "library_build": "0123456789abcdef", "launch_mode": "g" * 80, "parallelism": "1 GPU"},
+           "roofline": bench.roofline_of("v1_mean", 10000, 50, 12.4e-6, {}, "no pmc"), "goal_40pct_hbm": False, "goal_note": "n" * 250,
+           "cpu_baseline": dict(_row("v1_mean", 10000)["cpu_baseline"], sample="s" * 200,
+                                sparse_port={"value": 3.2e6, "unit": "windows/s", "cores": 16, "kind": "port", "single_core_value": 2.1e5, "what": "w" * 60, "sample": "p" * 90})}
+    extra = [_row(name, W) for name, W, _ in bench.EXTRA_ROWS]
+    extra[4]["roofline"]["fp64"] = {"TFLOPs": 31.6, "peak": 78.6, "frac": 0.40, "source": "counters", "useful_frac": 0.34}
+    extra.append({"workload": "v1_mean_3ctx", "units_per_step": 10000, "value": 1.2e9, "unit": "windows/s", "contexts": 3, "us_per_batch": 8.4,
+                  "hbm_GBs": 3500.0, "hbm_frac": 0.437, "note": "n" * 120})
+    extra.append({"workload": "broken", "units_per_step": 5, "error": "RuntimeError('x')"})
+    bench.emit(res, extra)
+    out = capsys.readouterr().out
+    line = out.strip().splitlines()[-1]
+    assert len(line) < 6000, len(line)
+    r = json.loads(line)
+    assert r["value"] == 7.1e8 and r["roofline"]["frac"] > 0 and r["cpu_baseline"]["cores"] == 16
+    assert r["configs2"]["value"] > 0 and r["configs2"]["fp64"]["useful_frac"] == 0.34 and r["configs2"]["cpu_baseline"]["kind"] == "reference"
+    assert len(r["extra_rows"]) == len(extra) and r["extra_rows"]["broken@5"] == "error"
+    assert r["routes_1M_x_50"]["dense_kernel_preassembled"] > 0
+    doc = json.load(open(tmp_path / "bench_extra.json"))
+    assert len(doc["rows"]) == len(extra) and doc["headline"]["value"] == 7.1e8 and "extra_rows" not in doc["headline"]
+
+
+def test_emit_without_extra_rows_is_the_plain_headline(tmp_path, monkeypatch, capsys):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit({"metric": "m", "value": 1.0}, None)
+    assert json.loads(capsys.readouterr().out.strip()) == {"metric": "m", "value": 1.0}
+    assert not (tmp_path / "bench_extra.json").exists()
