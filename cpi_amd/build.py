@@ -4,6 +4,8 @@
     python -m cpi_amd.build --force --report     # rebuild everything and print the per-kernel resource table
     python -m cpi_amd.build --experiments        # additionally libcpi_amd_exp.so (-DCPI_EXPERIMENTS: the measurement-only
                                                  # kernels and environment switches of tools/exp/; load it with CPI_AMD_LIB)
+    python -m cpi_amd.build --test-hooks         # additionally libcpi_amd_test.so (-DCPI_TEST_HOOKS: the two entries of
+                                                 # include/cpi_amd_test.h; the PRODUCT library exports nothing but include/cpi_amd.h)
 
 The library is four translation units (cpi_amd/csrc/cpi_args.hpp) compiled IN PARALLEL into cpi_amd/csrc/_obj/*.o and
 linked into one shared object; an object is rebuilt only when the sources it includes (or the flags) change, so touching
@@ -23,20 +25,28 @@ INC = os.path.join(os.path.dirname(HERE), "include")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcpi_amd.so")
 LIB_EXP = os.path.join(HERE, "libcpi_amd_exp.so")
+LIB_TEST = os.path.join(HERE, "libcpi_amd_test.so")
 REPORT = os.path.join(CSRC, "resource_usage.txt")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage"]
-COMMON = ["cpi_args.hpp", "../../include/cpi_amd.h"]
+COMMON = ["cpi_args.hpp", "../../include/cpi_amd.h", "exports.map"]   # exports.map: the link step's version script
 DEVICE = COMMON + ["cpi_math.hpp", "cpi_device_util.hpp"]
 # translation unit -> the files it includes (what its object depends on)
 UNITS = {
     "cpi_mean": DEVICE + ["cpi_mean.hip", "cpi_mean_kernels.hpp"],
     "cpi_cov": DEVICE + ["cpi_cov.hip", "cpi_cov_kernels.hpp"],
     "cpi_factor": DEVICE + ["cpi_factor.hip", "cpi_factor_kernels.hpp"],
-    "cpi_abi": COMMON + ["cpi_abi.hip", "../../include/cpi_amd_test.h"],
+    "cpi_abi": COMMON + ["cpi_abi.hip", "../../include/cpi_amd_test.h"],   # the test header: -DCPI_TEST_HOOKS builds only
 }
 EXP_EXTRA = {"cpi_mean": ["cpi_mean_experimental.hpp"]}   # additional includes under -DCPI_EXPERIMENTS
 EXP_UNITS = ("cpi_mean", "cpi_abi")                        # the units that differ in an experiments build
+# library variants: path, define, the units compiled with the define (the other objects are shared with the default build),
+# object-name suffix.  "exp" = measurement kernels / environment switches, "test" = the hooks of include/cpi_amd_test.h.
+VARIANTS = {
+    "": (LIB, None, (), ""),
+    "exp": (LIB_EXP, "-DCPI_EXPERIMENTS", EXP_UNITS, "_exp"),
+    "test": (LIB_TEST, "-DCPI_TEST_HOOKS", ("cpi_factor", "cpi_abi"), "_test"),
+}
 
 
 def _path(rel):
@@ -52,15 +62,18 @@ def _sources(experiments=False):
     return sorted(s)
 
 
-def source_id(experiments=False):
+def source_id(experiments=False, variant=None):
     """sha256[:16] over the sources the library is built from -- compiled into it (cpi_build_id()), so that measurement
     records (profiles/*_pmc.json) can be tied to the exact library that is loaded."""
+    variant = ("exp" if experiments else "") if variant is None else variant
     h = hashlib.sha256()
-    for d in _sources(experiments):
+    for d in _sources(variant == "exp"):
         with open(_path(d), "rb") as f:
             h.update(d.encode() + b"\0" + f.read())
-    if experiments:
+    if variant == "exp":
         h.update(b"CPI_EXPERIMENTS")
+    elif variant:
+        h.update(VARIANTS[variant][1].encode())
     return h.hexdigest()[:16]
 
 
@@ -72,12 +85,14 @@ def _unit_key(unit, defines, experiments):
     return h.hexdigest()[:16]
 
 
-def _compile(unit, experiments, force):
-    exp = experiments and unit in EXP_UNITS
-    defines = (["-DCPI_EXPERIMENTS"] if exp else [])
+def _compile(unit, variant, force):
+    _, define, vunits, suffix = VARIANTS[variant]
+    own = bool(variant) and unit in vunits          # this unit differs from the default build's object
+    exp = own and variant == "exp"
+    defines = ([define] if own else [])
     if unit == "cpi_abi":
-        defines.append('-DCPI_BUILD_ID="%s"' % source_id(experiments))
-    obj = os.path.join(OBJ, unit + ("_exp" if exp else "") + ".o")
+        defines.append('-DCPI_BUILD_ID="%s"' % source_id(variant=variant))
+    obj = os.path.join(OBJ, unit + (suffix if own else "") + ".o")
     stamp, log = obj + ".key", obj + ".log"
     key = _unit_key(unit, defines, exp)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
@@ -110,38 +125,74 @@ def _resource_rows(text):
 
 
 def _link(lib, objs):
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
+    """Linked under a temporary name and moved into place: a process that loads the library while another one rebuilds it
+    sees the old file or the new one, never a half-written one."""
+    tmp = "%s.tmp.%d" % (lib, os.getpid())
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+           "-o", tmp] + objs + ["-ldl"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if p.returncode != 0:
         sys.stderr.write(p.stdout)
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("link failed: %s" % lib)
+    os.replace(tmp, lib)
 
 
-def stale(lib=LIB, experiments=False):
+class _BuildLock:
+    """One builder at a time per tree (several ranks / pytest subprocesses may import the package at once and would
+    otherwise write the same _obj/*.o and .so concurrently).  Advisory flock on a file under _obj/."""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(OBJ, exist_ok=True)
+        self.f = open(os.path.join(OBJ, ".lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
+def stale(lib=LIB, experiments=False, variant=None):
     """Content-based (a sidecar file holds the source id the library was built from): file times do not survive a copy of
     the tree to another machine, and a rebuild there would burn GPU-box minutes for nothing."""
     try:
         with open(lib + ".id") as f:
-            return (not os.path.exists(lib)) or f.read().strip() != source_id(experiments)
+            return (not os.path.exists(lib)) or f.read().strip() != source_id(experiments, variant)
     except OSError:
         return True
 
 
-def build(force=False, report=False, experiments=False):
-    """Returns the path of the library built (the default library; with experiments=True BOTH are built and the default's
-    path is returned)."""
-    os.makedirs(OBJ, exist_ok=True)
-    todo = []
-    if force or stale(LIB, False):
-        todo.append((LIB, False))
-    if experiments and (force or stale(LIB_EXP, True)):
-        todo.append((LIB_EXP, True))
-    for lib, exp in todo:
+def build(force=False, report=False, experiments=False, test_hooks=False):
+    """Returns the path of the default library (with experiments / test_hooks the additional variants are built too:
+    libcpi_amd_exp.so, libcpi_amd_test.so)."""
+    with _BuildLock():
+        return _build_locked(force, report, experiments, test_hooks)
+
+
+def build_test_hooks():
+    """libcpi_amd_test.so, built when stale; returns its path (tests/: CPI_AMD_LIB for subprocesses, tests/hooks_py.py in-process)."""
+    build(test_hooks=True)
+    return LIB_TEST
+
+
+def _build_locked(force, report, experiments, test_hooks):
+    todo = []   # staleness is judged INSIDE the lock: whoever waited for another builder finds the library fresh
+    for variant, wanted in (("", True), ("exp", experiments), ("test", test_hooks)):
+        if wanted and (force or stale(VARIANTS[variant][0], variant=variant)):
+            todo.append(variant)
+    for variant in todo:
+        lib, _, vunits, _ = VARIANTS[variant]
+        exp = variant
         with ThreadPoolExecutor(len(UNITS)) as ex:
-            res = list(ex.map(lambda u: _compile(u, exp, force and (not exp or u in EXP_UNITS)), UNITS))
+            res = list(ex.map(lambda u: _compile(u, variant, force and (not variant or u in vunits)), UNITS))
         _link(lib, [o for o, _ in res])
         with open(lib + ".id", "w") as f:
-            f.write(source_id(exp))
+            f.write(source_id(variant=variant))
         if not exp:
             rows = [r for _, text in res for r in _resource_rows(text)]
             with open(REPORT, "w") as f:
@@ -155,7 +206,8 @@ def build(force=False, report=False, experiments=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, report="--report" in sys.argv, experiments="--experiments" in sys.argv)
+    build(force="--force" in sys.argv, report="--report" in sys.argv, experiments="--experiments" in sys.argv,
+          test_hooks="--test-hooks" in sys.argv)
     print(LIB)
     if "--report" in sys.argv:
         print(open(REPORT).read())

@@ -27,7 +27,9 @@
 #include <vector>
 
 #include "../../include/cpi_amd.h"
-#include "../../include/cpi_amd_test.h"
+#ifdef CPI_TEST_HOOKS
+#include "../../include/cpi_amd_test.h"   // the two test hooks exist in libcpi_amd_test.so only (python -m cpi_amd.build --test-hooks)
+#endif
 #include "cpi_args.hpp"
 
 using namespace cpi;
@@ -340,6 +342,15 @@ extern "C" int cpi_preintegrate_stream(cpi_ctx *ctx, const cpi_params *prm, int6
     if (!stream || !update_times || !workspace) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: NULL argument");
     if (((uintptr_t)workspace & 15) != 0) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: the workspace must be 16-byte aligned");
     if (!grid_ok(U)) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: U exceeds 2^31 - 1 windows per call");
+    // everything preintegrate_impl would refuse is refused HERE, before the cut kernel is enqueued: an invalid call must not
+    // leave a launch behind that writes the caller's workspace
+    if (!prm || !out || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: prm/out/lin is NULL");
+    if (prm->model != CPI_MODEL_V1 && prm->model != CPI_MODEL_V2 && prm->model != CPI_MODEL_FORSTER)
+        return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: model must be 1, 2 or 3 (CPI_MODEL_FORSTER)");
+    if (prm->model == CPI_MODEL_V2 && !q_k_lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: model 2 needs q_k_lin");
+    if (N > 65535) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream: N (intervals per window) must be <= 65535");
+    if (prm->lanes_per_window != 0 && !launch::mean_lanes_supported(prm->lanes_per_window))
+        return fail(ctx, CPI_ERR_INVALID, "lanes_per_window must be 0 or one of 1,2,3,4,5,6,8,12,16,32,64");
     char *ws = static_cast<char *>(workspace);
     long long *first = reinterpret_cast<long long *>(ws);
     double *tstart = reinterpret_cast<double *>(ws + align16((size_t)U * 8));
@@ -744,13 +755,16 @@ static int group_create(int n, const int *devices, bool shared_device_for_tests,
     return CPI_OK;
 }
 extern "C" int cpi_group_create(int n, const int *devices, cpi_group **out) { return group_create(n, devices, false, out); }
+#ifdef CPI_TEST_HOOKS
 // include/cpi_amd_test.h: n ranks that all live on ONE device -- the n > 1 code paths of the device set on a 1-GPU box.
 // Real RCCL refuses duplicate devices in ncclCommInitAll; the test-suite binds tests/fake_rccl through CPI_AMD_RCCL_LIB.
+// Not in the product library: the entry switches the duplicate-device guard of cpi_group_create off.
 extern "C" int cpi_test_group_create_shared(int n, int device, cpi_group **out) {
     if (n <= 0 || n > kMaxGroup) return gfail(nullptr, CPI_ERR_INVALID, "cpi_test_group_create_shared: n out of range");
     std::vector<int> devs(n, device);
     return group_create(n, devs.data(), true, out);
 }
+#endif
 extern "C" int cpi_group_synchronize(cpi_group *g) {
     if (!g) return gfail(nullptr, CPI_ERR_INVALID, "group is NULL");
     for (int r = 0; r < g->n; r++) {
@@ -881,6 +895,7 @@ extern "C" int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_out
 }
 
 // -------------------------------------------------------------------------------- test hook (include/cpi_amd_test.h)
+#ifdef CPI_TEST_HOOKS
 extern "C" int cpi_test_quat_ops(cpi_ctx *ctx, int32_t op, int64_t n, const double *in, double *out) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (op < 0 || op > 5 || n < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_test_quat_ops: unknown op / negative size");
@@ -892,6 +907,7 @@ extern "C" int cpi_test_quat_ops(cpi_ctx *ctx, int32_t op, int64_t n, const doub
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
+#endif
 
 // ============================================================================================
 // host-pointer variants

@@ -113,7 +113,9 @@ void factor_packed(int model, int lpf, const FactorArgs &a, double *packed, hipS
 void factor_hessian(int model, const FactorArgs &a, double *hess, hipStream_t st);
 void sqrt_info(long long F, const double *P, double *R, hipStream_t st);
 void predict(int model, const PredictArgs &a, hipStream_t st);
-void test_quat_ops(int op, long long n, const double *in, double *out, hipStream_t st);
+#ifdef CPI_TEST_HOOKS
+void test_quat_ops(int op, long long n, const double *in, double *out, hipStream_t st);   // libcpi_amd_test.so only
+#endif
 void unpack_slabs(int n, const long long *lo, const long long *cnt, const long long *wb, const double *staging, long long stride,
                   const cpi_outputs &root_out, hipStream_t st);
 #ifdef CPI_EXPERIMENTS

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void cpi_unpack_slabs_kernel(UnpackArgs U) {
     }
 }
 
+#ifdef CPI_TEST_HOOKS   // include/cpi_amd_test.h: libcpi_amd_test.so only
 __global__ __launch_bounds__(64) void cpi_test_quat_ops_kernel(int op, long long n, const double *in, double *out) {
     const long long k = (long long)blockIdx.x * 64 + threadIdx.x;
     if (k >= n) return;
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(64) void cpi_test_quat_ops_kernel(int op, long long
         default: put_q(out + 4 * k, quat_inv(ldq4(in + 4 * k))); break;
     }
 }
+#endif
 }  // namespace
 
 namespace cpi {
@@ -106,9 +108,11 @@ void predict(int model, const PredictArgs &a, hipStream_t st) {
     else hipLaunchKernelGGL((cpi_predict_kernel<2>), dim3((unsigned)nb), dim3(256), 0, st, a);
 }
 
+#ifdef CPI_TEST_HOOKS
 void test_quat_ops(int op, long long n, const double *in, double *out, hipStream_t st) {
     hipLaunchKernelGGL(cpi_test_quat_ops_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, op, n, in, out);
 }
+#endif
 
 void unpack_slabs(int n, const long long *lo, const long long *cnt, const long long *wb, const double *staging, long long stride,
                   const cpi_outputs &root_out, hipStream_t st) {

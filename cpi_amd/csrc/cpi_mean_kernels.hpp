@@ -52,10 +52,17 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
         tailseg = tail && (s1 == n) && (len > 0);
     }
     const int len_f = len - (tailseg ? 1 : 0);                          // knots after the segment's first that exist in memory
+    // First knot of the segment IN MEMORY.  Knot s0 always exists (a window owns count + 1 knots) -- except the virtual tail
+    // knot, which only an EMPTY trailing segment (s0 == n, lanes beyond ceil(n / per)) can start on: nothing of such a segment is
+    // ever consumed, but its first knot is still fetched (pk below, and the staging path re-reads a never-valid element's base
+    // knot), and when the window ends on the stream's last reading (update time past the last stamp) knot k0 + n lies 56 bytes
+    // behind the caller's buffer -- unmapped memory, or NaN bits that reach the state through 0 * NaN on the dt = 0 steps with
+    // imu_avg.  Such a segment is based on the last real knot instead.
+    const int sb = (cut && tail && s0 == n && n > 0) ? s0 - 1 : s0;
 
     // (Deriving the descriptors of a dense layout arithmetically instead of through LDS was measured: +0.35 us per
     // 13 us launch -- the 64-bit integer arithmetic costs more than the shuffle reduction and the LDS round trip.)
-    segdesc[lane] = ((unsigned long long)((k0 + s0) * 7) << 16) | (unsigned long long)(unsigned)len_f;
+    segdesc[lane] = ((unsigned long long)((k0 + sb) * 7) << 16) | (unsigned long long)(unsigned)len_f;
 
     const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
     V3 gk = mk(0, 0, 0);
@@ -63,9 +70,7 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
 
     double pk[7];
     {
-        // knot s0 always exists (a window owns count + 1 knots) -- except a virtual tail knot, which only an empty trailing
-        // segment can start on (its pk is never consumed)
-        const double *kb = A.knots + (k0 + ((tail && s0 == n && n > 0) ? s0 - 1 : s0)) * 7;
+        const double *kb = A.knots + (k0 + sb) * 7;
 #pragma unroll
         for (int i = 0; i < 7; i++) pk[i] = kb[i];
         if (cut && s0 == 0) pk[0] = t_start;

@@ -27,6 +27,14 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class _nullctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 class Engine:
     """One C-ABI context.  stream=None: the engine FOLLOWS torch's current stream of its device -- every call is issued
     on torch.cuda.current_stream() as it is at that call (so inputs produced and outputs allocated under
@@ -213,14 +221,19 @@ class Engine:
         self._sync_stream()
         self._check(self.lib.cpi_preintegrate_stream(self.ctx, C.byref(params), K, _ptr(stream), U, _ptr(update_times), int(N), _ptr(lin),
                                                      _ptr(q_k_lin), _ptr(ws), C.byref(o)))
-        cptr = self.lib.cpi_stream_counts(_ptr(ws), U)
-        counts = torch.empty((U,), dtype=torch.int32, device=self.device)
-        if U:
-            off = (cptr - ws.data_ptr()) // 4
-            counts = ws.view(torch.int32)[off:off + U]
+        # The workspace (28 bytes per window) must outlive the kernels that read it.  Allocated here it came from torch's
+        # caching allocator on the stream the kernels were just issued on (follow mode), so dropping the reference is safe: the
+        # block can only be handed to later, stream-ordered allocations of that stream.  An engine pinned to an explicit stream
+        # says so to the allocator.  Nothing but output fields is stored in the returned dict.
+        if workspace is None and not self._follow and self.stream is not None:
+            ws.record_stream(self.stream)
+        counts = torch.empty((0,), dtype=torch.int32, device=self.device)
+        if U and (return_counts or check_counts):
+            off = (self.lib.cpi_stream_counts(_ptr(ws), U) - ws.data_ptr()) // 4
+            with torch.cuda.stream(self.stream) if (not self._follow and self.stream is not None) else _nullctx():
+                counts = ws.view(torch.int32)[off:off + U].clone()   # a copy: a re-used workspace is overwritten by the next call
             if check_counts and int(counts.max().item()) > N:
                 raise ValueError("preintegrate_stream: a window has %d intervals, more than N = %d" % (int(counts.max().item()), N))
-        out["_workspace"] = ws      # keeps the 28 bytes per window alive while the kernels run
         return (out, counts) if return_counts else out
 
     def stream_workspace(self, U):

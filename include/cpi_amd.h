@@ -132,7 +132,9 @@ int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32
  *                 with the front reading held, after which the front stamp is overwritten by the update time; window 0 starts
  *                 at the stream's first reading
  *   N             upper bound of the intervals of a window (whole + tail); a longer window is truncated to N intervals --
- *                 check cpi_stream_counts, which holds the TRUE counts after the call
+ *                 check cpi_stream_counts, which holds the TRUE counts after the call.  Give a TIGHT bound: the kernels'
+ *                 loops run to the longest window of a wavefront, but the automatic lane split of the mean kernel
+ *                 (cpi_params.lanes_per_window = 0) is chosen from N, not from the counts
  *   lin, q_k_lin  per window, as in cpi_preintegrate_batch
  *   workspace     cpi_stream_workspace_bytes(U) bytes of device memory, 16-byte aligned (28 bytes per window: where the
  *                 reference's deque stands at each update, found by binary search because the stamps are sorted)

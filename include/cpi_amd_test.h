@@ -1,5 +1,8 @@
 /*
- * cpi_amd_test.h -- test hooks of libcpi_amd.so (NOT part of the drop-in boundary; used by tests/ only).
+ * cpi_amd_test.h -- test hooks (NOT part of the drop-in boundary; used by tests/ only).  They exist ONLY in
+ * cpi_amd/libcpi_amd_test.so -- the product sources compiled with -DCPI_TEST_HOOKS (python -m cpi_amd.build --test-hooks;
+ * tests select it with CPI_AMD_LIB or tests/hooks_py.py).  The product library libcpi_amd.so exports exactly the
+ * prototypes of cpi_amd.h (tests/test_abi.py).
  *
  * The device-side SO(3) / JPL-quaternion helpers of cpi_amd/csrc/cpi_math.hpp replace the reference's
  * cpi_compare/src/utils/quat_ops.h (rot_2_quat :45-86, skew_x :92-98, quat_2_Rot :104-109, quat_multiply :115-128,

@@ -12,7 +12,9 @@
 #include <cstring>
 
 #include "../../cpi_amd/csrc/cpi_host.hpp"
+#ifdef CPI_TEST_HOOKS   // the "shared" mode (n ranks on ONE device) needs libcpi_amd_test.so; without it this host links the product library
 #include "../../include/cpi_amd_test.h"
+#endif
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
@@ -35,7 +37,11 @@ int main(int argc, char **argv) {
 
     const bool shared = argc > 4 && std::strcmp(argv[4], "shared") == 0;
     cpi_group *raw = nullptr;
+#ifdef CPI_TEST_HOOKS
     if (shared && cpi_test_group_create_shared(n, 0, &raw) != CPI_OK) { std::fprintf(stderr, "%s\n", cpi_group_last_error(nullptr)); return 4; }
+#else
+    if (shared) { std::fprintf(stderr, "the shared-device mode is a test hook: compile with -DCPI_TEST_HOOKS against libcpi_amd_test.so\n"); return 4; }
+#endif
     cpi_host::DeviceGroup grp = shared ? cpi_host::DeviceGroup(raw) : cpi_host::DeviceGroup(n);
     cpi_params prm{};
     prm.sigma_w = 0.005; prm.sigma_wb = 4e-6; prm.sigma_a = 0.01; prm.sigma_ab = 2e-4;

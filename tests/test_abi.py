@@ -9,24 +9,42 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    syms = set()
-    for f in sorted(os.listdir(os.path.join(ROOT, "include"))):     # every header of include/: the boundary and the test hooks
-        if f.endswith(".h"):
-            src = open(os.path.join(ROOT, "include", f)).read()
-            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-            syms |= set(re.findall(r"\b(cpi_[a-z_]+)\s*\(", src))
-    return sorted(syms)
+def _declared_symbols(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(cpi_[a-z_]+)\s*\(", src))
 
 
-def test_library_builds_and_exports_every_declared_symbol():
-    from cpi_amd import _lib
+def _exported(lib_path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
+def test_library_builds_and_exports_exactly_the_public_header():
+    """The dynamic symbols of the PRODUCT library are the prototypes of include/cpi_amd.h -- all of them and nothing else: no
+    test hook (round 3 shipped cpi_test_quat_ops and cpi_test_group_create_shared, the latter switches the duplicate-device
+    guard off), no cpi::launch function, no std:: instantiation (cpi_amd/csrc/exports.map)."""
+    from cpi_amd import _lib, build
     lib = _lib.load()
-    syms = _declared_symbols()
-    assert len(syms) >= 20 and "cpi_group_gather" in syms and "cpi_test_quat_ops" in syms
-    for s in syms:
+    public = _declared_symbols("cpi_amd.h")
+    assert len(public) >= 20 and "cpi_group_gather" in public and not [s for s in public if s.startswith("cpi_test_")]
+    for s in sorted(public):
         assert hasattr(lib, s), "libcpi_amd.so does not export %s" % s
+    exported = _exported(build.LIB)
+    assert exported == public, (sorted(exported - public), sorted(public - exported))
     assert lib.cpi_abi_version() == 2
+
+
+def test_hooks_library_adds_exactly_the_test_header():
+    """libcpi_amd_test.so = the same sources with -DCPI_TEST_HOOKS: the public ABI plus the two entries of include/cpi_amd_test.h."""
+    from cpi_amd import build
+    from tests import hooks_py
+    path = hooks_py.lib_path()
+    assert path == build.LIB_TEST and os.path.exists(path)
+    hooks = _declared_symbols("cpi_amd_test.h")
+    assert hooks == {"cpi_test_quat_ops", "cpi_test_group_create_shared"}
+    assert _exported(path) == _declared_symbols("cpi_amd.h") | hooks
 
 
 def test_struct_layouts_match_header():

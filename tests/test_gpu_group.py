@@ -21,8 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_n_rank_device_sets_on_one_device_reproduce_the_unsharded_call_bitwise():
-    from tests import fake_rccl_py
-    env = dict(os.environ, CPI_AMD_RCCL_LIB=fake_rccl_py.lib_path())
+    from tests import fake_rccl_py, hooks_py
+    env = dict(os.environ, CPI_AMD_RCCL_LIB=fake_rccl_py.lib_path(), CPI_AMD_LIB=hooks_py.lib_path())   # the library WITH the hooks
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "group_check.py")], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0 and "group_check ok" in p.stdout, p.stdout[-3000:]
@@ -39,7 +39,8 @@ def test_unloadable_rccl_is_an_error_code_not_a_crash():
             "assert 'dlopen(/nonexistent/librccl.so.1)' in msg and len(msg) > 40, msg\n"
             "rc = lib.cpi_test_group_create_shared(2, 0, C.byref(g))\n"       # and again: the failed state is not sticky garbage
             "assert rc == _lib.CPI_ERR_RCCL\nprint('rccl-load ok:', msg)\n") % ROOT
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CPI_AMD_RCCL_LIB="/nonexistent/librccl.so.1"),
+    from tests import hooks_py
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CPI_AMD_RCCL_LIB="/nonexistent/librccl.so.1", CPI_AMD_LIB=hooks_py.lib_path()),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0 and "rccl-load ok" in p.stdout, p.stdout[-2000:]
 
@@ -152,11 +153,15 @@ def test_cpp_host_sharding_a_batch_over_the_device_set(golden_dir):
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     from cpi_amd import _lib
     _lib.load()
-    exe = os.path.join(tempfile.mkdtemp(), "test_group")
+    tmp = tempfile.mkdtemp()
+    exe, exe_hooks = os.path.join(tmp, "test_group"), os.path.join(tmp, "test_group_hooks")
     libdir = os.path.join(ROOT, "cpi_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                           os.path.join(ROOT, "tests", "cpp", "test_group.cpp"), "-o", exe, "-L" + libdir, "-lcpi_amd",
-                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    from tests import hooks_py
+    hooks_py.lib_path()
+    base = ["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "test_group.cpp")]
+    tail = ["-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(base + ["-o", exe, "-L" + libdir, "-lcpi_amd"] + tail)                                   # the product library
+    subprocess.check_call(base + ["-DCPI_TEST_HOOKS", "-o", exe_hooks, "-L" + libdir, "-l:libcpi_amd_test.so"] + tail)   # + "shared" mode
     d = dict(np.load(os.path.join(golden_dir, "pre_w48.npz")))
     kn, lin, q = d["knots"], d["lin"], d["q_k_lin"]
     W, n1, _ = kn.shape
@@ -177,7 +182,7 @@ def test_cpp_host_sharding_a_batch_over_the_device_set(golden_dir):
         # the same binary with 5 ranks sharing the device over the RCCL stand-in: 48 windows -> blocks of 10, 10, 10, 10, 8,
         # one slab message per peer, identical output text (same kernels on the same windows)
         from tests import fake_rccl_py
-        p5 = subprocess.run([exe, path, str(model), "5", "shared"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+        p5 = subprocess.run([exe_hooks, path, str(model), "5", "shared"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
                             env=dict(os.environ, CPI_AMD_RCCL_LIB=fake_rccl_py.lib_path()))
         assert p5.returncode == 0, p5.stderr
         assert "group of 5 rank(s) on one device" in p5.stderr and "1 message(s) per peer" in p5.stderr, p5.stderr
@@ -237,3 +242,10 @@ def test_bench_gpus_2_end_to_end_rehearsal_on_one_gpu():
         assert c["gather_schedule"] == ("pipelined" if extra else "final") and c["kernel_ms"] > 0 and c["gather_ms"] > 0
         assert c["wall_ms"] >= c["kernel_ms"] * 0.99 and abs(d["ms_per_step"] * 5 - c["wall_ms"]) < 1e-6 * c["wall_ms"]
         assert ("graph" in c["launch_mode"]) == (not extra)
+        # round 4: the line says what the process group saw (here: gloo, two ranks on ONE device -- which is why it is a
+        # rehearsal), separates the kernels from the collective tail, and rank 0 has recomputed every rank's last-step batch
+        # and compared the gathered blocks bitwise
+        assert c["rccl"]["backend"] == "gloo" and c["rccl"]["world_size"] == 2 and c["rccl"]["distinct_devices"] == 1
+        assert c["value_kernel_only"] >= d["value"]
+        assert c["gather_verified"] is True and "bitwise" in c["gather_verified_how"]
+        assert len(line) < 6000

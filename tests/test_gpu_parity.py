@@ -310,6 +310,52 @@ def test_config2_size_composition_property(eng):
         assert torch.equal(again[k], ref[k])
 
 
+@pytest.mark.parametrize("model", [1, 2])
+def test_config2_size_launch_geometries_vs_reference_sample(eng, orc, model):
+    """BASELINE configs[1] AT ITS OWN LAUNCH GEOMETRY (10 000 windows x 50 samples, mean-only; model 2 = bench row v2_mean):
+    128 strided windows of the 10 000-window launch against the compiled reference (CpiV1.h:67-154 / CpiV2.h:88-205) at the
+    regression gates, for every way the bench and the facades launch it -- (i) the auto lane split the headline runs (L = 6 at
+    this size), (ii) one lane and 64 lanes per window, (iii) the tiled SPLIT kernel (157 tiles x 4 wavefronts) fed by the
+    device assembler cpi_assemble_tiles, (iv) the zero-copy stream entry with a partial tail interval in every window.
+    Until round 4 this size was checked through properties only (goldens hold 48 windows, seeded runs 1 500)."""
+    from cpi_amd import stream as st
+    W, N = 10000, 50
+    mode = (model, 0, 1)
+    pick = np.arange(0, W, 79)[:128]                       # every 79th window: all tiles / wavefronts, every lane-group position
+    assert pick.size == 128 and pick[-1] < W
+    # ---- dense layout: (i) auto, (ii) L = 1 and 64 (+ the neighbours of the auto choice)
+    kn, lin, q = synth.make_windows(W, N, seed=53 + model, device=eng.device)
+    ref, from_ref = _cpu(orc, mode, kn[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
+    ref = {k: ref[k] for k in ("DT", "alpha", "beta", "q")}
+    for lanes in (0, 1, 5, 6, 8, 64):
+        out = eng.preintegrate(kn, lin, q, eng.make_params(model, lanes_per_window=lanes), want=("mean",))
+        torch.cuda.synchronize()
+        check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, ref, what=("mean",), regression=from_ref,
+                  label="configs[1] size, model %d, dense, lanes %d" % (model, lanes))
+    # ---- ONE stream of 500 001 readings + 10 000 update times: (iii) assembler + tiled SPLIT kernel, (iv) stream entry
+    for phase in (0.0, 0.4):                               # on the IMU grid (N whole intervals) / a partial tail per window
+        stream, upd, slin, sq = synth.make_stream(W, N, seed=59 + model, device=eng.device, phase=phase)
+        knots, first, count = st.assemble_windows(stream.cpu().numpy(), upd.cpu().numpy())       # host assembler = the deque loop
+        Nw = int(count.max())
+        assert Nw == (N if phase == 0.0 else N + 1)
+        dense = np.stack([knots[first[u] + np.minimum(np.arange(Nw + 1), count[u])] for u in pick])   # short windows: dt = 0 padding
+        sref, from_ref2 = _cpu(orc, mode, dense, slin[pick].cpu().numpy(), sq[pick].cpu().numpy())
+        sref = {k: sref[k] for k in ("DT", "alpha", "beta", "q")}
+        tiles, cnt = eng.assemble_tiles(stream, upd, Nw)
+        torch.cuda.synchronize()
+        assert np.array_equal(cnt.cpu().numpy(), count)
+        for S in (0, 1, 4):                                # 0 = auto: 157 tiles < 640 -> four wavefronts per tile (SPLIT)
+            out = eng.preintegrate_tiled(tiles, W, slin, sq, eng.make_params(model, lanes_per_window=S), count=cnt)
+            torch.cuda.synchronize()
+            check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, sref, what=("mean",), regression=from_ref2,
+                      label="configs[1] size, model %d, tiled S=%d, phase %.1f" % (model, S, phase))
+        for lanes in (0, 1, 6):
+            out = eng.preintegrate_stream(stream, upd, slin, sq, eng.make_params(model, lanes_per_window=lanes), want=("mean",), N=Nw)
+            torch.cuda.synchronize()
+            check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, sref, what=("mean",), regression=from_ref2,
+                      label="configs[1] size, model %d, stream entry lanes %d, phase %.1f" % (model, lanes, phase))
+
+
 def test_config3_size_structure_properties(eng, orc):
     """BASELINE configs[2] (100k x 50, model 2, covariance + bias Jacobians): structural invariants of
     the reference (P symmetric PSD, theta/b_a and b_w/b_a blocks exactly zero, b_w and b_a blocks

@@ -1,6 +1,6 @@
 """Device-side quaternion / SO(3) helpers (cpi_math.hpp, the shipped instruction sequences: v_rsq_f64 + Newton, Horner
-sin / cos) against the REFERENCE'S OWN quat_ops.h functions, through the test hook cpi_test_quat_ops of libcpi_amd.so
-(include/cpi_amd_test.h).  Expected values: tests/golden/quat_ops.npz, produced by the compiled reference
+sin / cos) against the REFERENCE'S OWN quat_ops.h functions, through the test hook cpi_test_quat_ops of libcpi_amd_test.so
+(include/cpi_amd_test.h; the product sources built with -DCPI_TEST_HOOKS).  Expected values: tests/golden/quat_ops.npz, produced by the compiled reference
 (oracle/gen_quat_ops.py).  With these primitives pinned, what remains unpinned of evaluateError / predict is the block
 assembly -- covered by the finite-difference test of the DEVICE residual under JPLNavState::retract below."""
 import ctypes as C
@@ -24,23 +24,36 @@ def eng():
     return cpi_amd.Engine(device=0)
 
 
-def run_device(eng, name, x):
+@pytest.fixture(scope="module")
+def hooks():
+    """libcpi_amd_test.so (the product sources + the hooks of include/cpi_amd_test.h) with a context of its own on the
+    default stream: the product library does not export cpi_test_quat_ops."""
+    from tests import hooks_py
+    h = hooks_py.lib()
+    ctx = C.c_void_p()
+    assert h.cpi_ctx_create(0, None, C.byref(ctx)) == 0, h.cpi_last_error(None)
+    yield h, ctx
+    h.cpi_ctx_destroy(ctx)
+
+
+def run_device(hooks, name, x):
+    h, ctx = hooks
     opcode, nin, nout = OPS[name]
-    xin = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64).reshape(-1, nin)).to(eng.device)
-    out = torch.full((xin.shape[0], nout), float("nan"), dtype=torch.float64, device=eng.device)
-    fn = eng.lib.cpi_test_quat_ops
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
-    eng._check(fn(eng.ctx, opcode, xin.shape[0], xin.data_ptr(), out.data_ptr()))
-    eng.synchronize()
+    dev = torch.device("cuda", 0)
+    xin = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64).reshape(-1, nin)).to(dev)
+    out = torch.full((xin.shape[0], nout), float("nan"), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    rc = h.cpi_test_quat_ops(ctx, opcode, xin.shape[0], xin.data_ptr(), out.data_ptr())
+    assert rc == 0, h.cpi_last_error(ctx)
+    assert h.cpi_ctx_synchronize(ctx) == 0
     return out.cpu().numpy()
 
 
 @pytest.mark.parametrize("name", sorted(OPS))
-def test_device_helpers_equal_the_compiled_reference(eng, golden_dir, name):
+def test_device_helpers_equal_the_compiled_reference(hooks, golden_dir, name):
     g = np.load(os.path.join(golden_dir, "quat_ops.npz"))
     x, want = g[name + "__in"], g[name + "__out"]
-    got = run_device(eng, name, x)
+    got = run_device(hooks, name, x)
     scale = np.maximum(1.0, np.abs(want).max())
     err = np.abs(got - want).max() / scale
     print("device %s: max err %.3e over %d cases" % (name, err, x.shape[0]))
@@ -48,7 +61,7 @@ def test_device_helpers_equal_the_compiled_reference(eng, golden_dir, name):
     assert err <= TOL_DEVICE, (name, err)
 
 
-def test_device_helpers_vs_live_reference_large_sample(eng):
+def test_device_helpers_vs_live_reference_large_sample(hooks):
     """When the compiled reference travelled to this box: 20 000 fresh random cases per helper."""
     from oracle import oracle_py as op
     ref = op.reference()
@@ -73,7 +86,7 @@ def test_device_helpers_vs_live_reference_large_sample(eng):
              "rot_2_quat": call_ref("quat_2_Rot", q)}
     for name, x in cases.items():
         want = call_ref(name, x)
-        got = run_device(eng, name, x)
+        got = run_device(hooks, name, x)
         err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
         assert err <= TOL_DEVICE, (name, err)
 

@@ -77,10 +77,11 @@ def test_sqrt_information_well_conditioned_and_not_positive_definite(eng):
     assert np.isnan(Rg[6]).any()
 
 
-@pytest.mark.parametrize("F", [1, 5, 12, 13, 700])
+@pytest.mark.parametrize("F", [1, 2, 3, 5, 6, 7, 12, 13, 700, 703])
 def test_hessian_blocks_ragged_grid_and_unwritten_neighbours(eng, F):
-    """Twelve factors per wavefront, the last wavefront ragged: every factor complete, nothing written past F (the output
-    buffer is allocated larger and pre-filled), chained states, both models; equal to the F = whole-batch run bit for bit."""
+    """Four factors per wavefront (16 lanes = one DPP row each), the last wavefront ragged -- F % 4 = 1, 2, 3 and 0, i.e. every
+    partial-wavefront shape of the shadow-lane / DPP path: every factor complete, nothing written past F (the output buffer
+    is allocated larger and pre-filled), chained states, both models; equal to the F = whole-batch run bit for bit."""
     kn, lin, q = synth.make_windows(F, 20, seed=300 + F, device=eng.device, edge_cases=False)
     for model in (1, 2):
         meas = eng.preintegrate(kn, lin, q, eng.make_params(model))
@@ -100,7 +101,7 @@ def test_hessian_blocks_ragged_grid_and_unwritten_neighbours(eng, F):
         want = np.stack([ref[:, i, d] for d in range(31) for i in range(d + 1)], axis=1)
         got = big[:F].cpu().numpy()
         assert (np.abs(got - want) / np.abs(want).max(axis=1, keepdims=True)).max() < 1e-12, (model, F)
-        if F > 12:      # a factor's result does not depend on where it sits in the wavefront
+        if F > 7:       # a factor's result does not depend on where it sits in the wavefront (7: another slot of the DPP row group)
             sl = slice(7, F)
             part = eng.factor_hessian(model, {k: v[sl].contiguous() for k, v in meas.items()}, lin[sl].contiguous(),
                                       None if qq is None else qq[sl].contiguous(), states[7:].contiguous(), R[sl].contiguous())

@@ -229,6 +229,46 @@ def test_gpu_stream_entry_reads_the_stream_in_place(mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model", [1, 2])
+def test_gpu_stream_entry_never_reads_behind_the_last_reading(model):
+    """with several lanes per window an EMPTY trailing lane segment of a tail window started on the virtual tail
+    knot -- whose address, for a window that ends on the stream's LAST reading (update time past the last stamp), lies 56 bytes
+    behind the caller's buffer; with imu_avg the loaded w1 / a1 reached the state through 0 * NaN.  Here the stream is the
+    front of a larger allocation whose remainder is NaN: every lane split (n % L != 0 included), imu_avg on and off, mean-only
+    and everything-out must be finite and bit-identical to the host-assembled ragged layout (which holds no such knot)."""
+    import torch
+    import cpi_amd
+    from cpi_amd import synth
+    eng = cpi_amd.Engine()
+    stream, upd, lin, q = synth.make_stream(37, 13, seed=11, phase=0.45)       # every window: 13 whole intervals + a tail
+    K = stream.shape[0]
+    upd = upd.clone(); upd[-1] = stream[-1, 0] + 0.003                          # the last window ends PAST the last stamp: fu == K - 1
+    knots, first, count = st.assemble_windows(stream.numpy(), upd.numpy())
+    assert int(first[-1]) + int(count[-1]) == K and int(count[-1]) >= 2         # its virtual tail knot would be knot K
+    N = int(count.max())
+    big = torch.full((K + 8, 7), float("nan"), dtype=torch.float64, device=eng.device)
+    big[:K] = stream.to(eng.device)
+    ds = big[:K]                                                                # contiguous view: NaN knots right behind the stream
+    T = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(eng.device)
+    du, dl, dq, ck, cf, cc = T(upd), T(lin), T(q), T(knots), T(first), T(count)
+    for avg in (True, False):
+        for lanes in (0, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64):
+            prm = eng.make_params(model, avg, True, lanes_per_window=lanes)
+            for want in (("mean",), ("mean", "jac"), ("mean", "jac", "cov")):
+                for Nb in (N, N + 9, min(K, 65535)):                            # a loose bound picks larger auto lane splits
+                    out = eng.preintegrate_stream(ds, du, dl, dq, prm, want=want, N=Nb, check_counts=False)
+                    csr = eng.preintegrate(ck, dl, dq, prm, want=want, first=cf, count=cc, N=Nb)
+                    torch.cuda.synchronize()
+                    for k in csr:
+                        assert bool(torch.isfinite(out[k]).all()), (avg, lanes, want, Nb, k)
+                        assert torch.equal(out[k], csr[k]), (avg, lanes, want, Nb, k)
+    ref = op.oracle().stream(op.make_params(model, 1, 1), stream.numpy(), upd.numpy(), lin.numpy(), q.numpy())
+    out = eng.preintegrate_stream(ds, du, dl, dq, eng.make_params(model, True, True), N=N)
+    torch.cuda.synchronize()
+    check_pre({k: v.cpu().numpy() for k, v in out.items() if not k.startswith("_")}, ref, v2=(model == 2), label="stream tail at the end of the buffer m%d" % model)
+
+
+@pytest.mark.gpu
 def test_gpu_stream_entry_forster_and_many_windows():
     """The same entry for the Forster comparator, and on a synthetic stream cut into thousands of windows (every window ends
     in a partial tail interval; wavefronts of the covariance kernels mix windows of different lengths): bit for bit equal to

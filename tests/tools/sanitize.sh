@@ -48,13 +48,13 @@ else
   CXX=/opt/rocm/lib/llvm/bin/clang++
   SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -shared-libsan"
   RT=$(dirname $($CXX -print-file-name=libclang_rt.asan-x86_64.so))
-  python -m cpi_amd.build > /dev/null || exit 2
+  python -m cpi_amd.build --test-hooks > /dev/null || exit 2   # the hosts below use the shared-device hook: objects with -DCPI_TEST_HOOKS
   BID=$(python -c "from cpi_amd import build; print(build.source_id())")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC $SAN -fno-gpu-sanitize -DCPI_BUILD_ID=\"$BID\" -c -o build/san/cpi_abi_asan.o cpi_amd/csrc/cpi_abi.hip || exit 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $SAN -o build/san/libcpi_amd.so build/san/cpi_abi_asan.o cpi_amd/csrc/_obj/cpi_mean.o cpi_amd/csrc/_obj/cpi_cov.o cpi_amd/csrc/_obj/cpi_factor.o -ldl || exit 2
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC $SAN -fno-gpu-sanitize -DCPI_TEST_HOOKS -DCPI_BUILD_ID=\"$BID\" -c -o build/san/cpi_abi_asan.o cpi_amd/csrc/cpi_abi.hip || exit 2
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $SAN -o build/san/libcpi_amd.so build/san/cpi_abi_asan.o cpi_amd/csrc/_obj/cpi_mean.o cpi_amd/csrc/_obj/cpi_cov.o cpi_amd/csrc/_obj/cpi_factor_test.o -ldl || exit 2
   LNK="-Lbuild/san -lcpi_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$R/build/san -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,$RT"
   for t in test_facade test_group test_threads test_imu_stream; do
-    $CXX -std=c++17 -O1 $SAN -pthread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/cpp/$t.cpp -o build/san/${t}_asan $LNK || exit 2
+    $CXX -std=c++17 -O1 $SAN -pthread -D__HIP_PLATFORM_AMD__ -DCPI_TEST_HOOKS -I/opt/rocm/include tests/cpp/$t.cpp -o build/san/${t}_asan $LNK || exit 2
   done
   export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:protect_shadow_gap=0 UBSAN_OPTIONS=print_stacktrace=1
   python - <<'PY'
