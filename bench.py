@@ -501,10 +501,10 @@ def cpu_baseline(wl, min_seconds=8.0):
     ws = min(Wc, (1500 if wl.model == 1 else 600) * 50 // max(50, wl.N))
     t1 = time.perf_counter(); lib.run(prm, kn[:ws], lin[:ws], q[:ws], nthreads=1); t1 = time.perf_counter() - t1
     what = {1: "CpiV1::feed_IMU", 2: "CpiV2::feed_IMU (stj = 1)", 3: "the Forster restatement"}[wl.model]
-    note = "" if "cov" in wl.want else "; the reference has no mean-only mode: this CPU figure also integrates Jacobians + covariance"
+    note = "" if "cov" in wl.want else "; no mean-only mode in the reference: CPU figure incl. Jacobians + covariance"
     res = {"value": done / el, "unit": "windows/s", "cores": cores, "kind": kind, "single_core_value": ws / t1,
-           "sample": "%d passes x %d of the row's %d-sample windows via %s, %d threads (cgroup quota; %d logical CPUs)%s"
-                     % (done // Wc, Wc, wl.N, what, cores, os.cpu_count() or 1, note)}
+           "sample": ("%d passes x %d of the row's %d-sample windows via %s, %d threads (cgroup quota; %d CPUs)%s"
+                      % (done // Wc, Wc, wl.N, what, cores, os.cpu_count() or 1, note))[:200]}
     if port:
         res["sparse_port"] = port
     return res
@@ -710,6 +710,7 @@ def main():
     wl = Workload(eng, a.workload, W, N, seed=base_seed(rank), lanes=a.lanes, min_out_sets=2 if (do_gather and schedule == "pipelined") else 1)
     PRERAMP_MS = 60.0
     preramp(wl, PRERAMP_MS)
+    wl.i = 0     # the pre-ramp runs for a TIME, i.e. a rank-dependent number of steps: every rank walks the batch pool from the same index
     tm = time_steps(wl, a.steps, a.warmup, dist_on, a.gather, schedule, graph=not a.eager)
     wall, kern_ms, gather_ms = tm["wall"], tm["kernel_ms"], tm["gather_ms"]
     wall_ng = None

@@ -153,6 +153,7 @@ static int mean_blk() { static int v = [] { const char *e = getenv("CPI_AMD_MEAN
 static int blk_mode() { static int v = env_int("CPI_AMD_BLK_MODE", 0); return v; }
 static int probe_lds() { static int v = env_int("CPI_AMD_PROBE_LDS", 0); return v; }
 static bool no_overlap() { static int v = env_int("CPI_AMD_NO_OVERLAP", 0); return v != 0; }
+static bool no_fused_cut() { static int v = env_int("CPI_AMD_NO_FUSED_CUT", 0); return v != 0; }   // A/B: the workspace route for mean-only streams
 static int factor_lanes() { static int v = env_int("CPI_AMD_FACTOR_LANES", 0); return (v == 16 || v == 8 || v == 4) ? v : 0; }
 static int packed_lpf() { static int v = env_int("CPI_AMD_PACKED_LPF", 0); return (v == 2 || v == 3 || v == 4 || v == 6 || v == 8) ? v : 0; }
 }  // namespace expsw
@@ -207,16 +208,26 @@ static PreArgs shift_windows(const PreArgs &a, long long w0) {
 }
 #endif
 
+// cpi_preintegrate_stream: knots = ONE stream of K readings cut at update[W]; the workspace arrays are filled by
+// cpi_cut_windows_kernel when a kernel that reads them runs (covariance / Forster / analytic-Jacobian kernels), and stay
+// untouched -- except count -- when the mean kernel cuts its own windows (mean-only requests)
+struct StreamCut {
+    long long K;
+    const double *update;
+    long long *first;
+    int *count;
+    double *tstart, *tend;
+};
 static int preintegrate_impl(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *knots, const int64_t *first,
-                             const int32_t *count, const double *tstart, const double *tend, const double *lin,
+                             const int32_t *count, const StreamCut *sc, const double *lin,
                              const double *q_k_lin, const cpi_outputs *out);
 extern "C" int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N,
                                       const double *knots, const int64_t *first, const int32_t *count,
                                       const double *lin, const double *q_k_lin, const cpi_outputs *out) {
-    return preintegrate_impl(ctx, prm, W, N, knots, first, count, nullptr, nullptr, lin, q_k_lin, out);
+    return preintegrate_impl(ctx, prm, W, N, knots, first, count, nullptr, lin, q_k_lin, out);
 }
 static int preintegrate_impl(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32_t N, const double *knots, const int64_t *first,
-                             const int32_t *count, const double *tstart, const double *tend, const double *lin,
+                             const int32_t *count, const StreamCut *sc, const double *lin,
                              const double *q_k_lin, const cpi_outputs *out) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (!prm || !out) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_batch: prm/out is NULL");
@@ -235,35 +246,49 @@ static int preintegrate_impl(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int
     const bool want_mean = out->DT || out->alpha || out->beta || out->q;
     const bool want_jac = out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b;
     const bool want_cov = out->P != nullptr;
-    if (!want_mean && !want_jac && !want_cov) return CPI_OK;
-
-    DeviceGuard guard_;
-    CPI_HIP(ctx, guard_.enter(ctx->device));
-    PreArgs a;
-    memset(&a, 0, sizeof a);
-    a.W = W; a.N = N; a.knots = knots; a.first = (const long long *)first; a.count = count;
-    a.lin = lin; a.qk = q_k_lin; a.tstart = tstart; a.tend = tend;
-    for (int i = 0; i < 3; i++) a.grav[i] = prm->grav[i];
-    a.q4[0] = prm->sigma_w * prm->sigma_w; a.q4[1] = prm->sigma_wb * prm->sigma_wb;
-    a.q4[2] = prm->sigma_a * prm->sigma_a; a.q4[3] = prm->sigma_ab * prm->sigma_ab;
-    a.out = *out;
-    if (prm->model == CPI_MODEL_FORSTER) {   // one kernel owns everything; imu_avg, q_k_lin, grav play no part
-        launch::forster(a, ctx->stream);
-        CPI_HIP(ctx, hipGetLastError());
-        return CPI_OK;
-    }
+    const bool forster = prm->model == CPI_MODEL_FORSTER;
     const bool avg = prm->imu_avg != 0;
     const bool v2 = prm->model == CPI_MODEL_V2;
     const bool stj = v2 && prm->state_transition_jacobians != 0;
-
     // Which kernel owns what:
     //   covariance kernel : P, and (model 2 + state_transition_jacobians) the Jacobians read out of
     //                       Discrete_J_b; it also carries the means, so it writes them when it runs.
     //   mean kernel       : means when no covariance kernel runs; the ANALYTIC Jacobians (model 1 always,
     //                       model 2 when state_transition_jacobians == 0).
-    const bool run_cov = want_cov || (stj && want_jac);
-    const bool mean_jac = want_jac && !stj;
-    const bool run_mean = mean_jac || (want_mean && !run_cov);
+    const bool anything = want_mean || want_jac || want_cov;
+    const bool run_cov = !forster && (want_cov || (stj && want_jac));
+    const bool mean_jac = !forster && want_jac && !stj;
+    const bool run_mean = !forster && (mean_jac || (want_mean && !run_cov));
+    // A stream: the mean-only kernel cuts its own windows (fused; it still leaves the TRUE counts in the workspace); every
+    // other kernel reads the cut that cpi_cut_windows_kernel leaves there.  Nothing asked for: the counts are still owed.
+    bool fused_cut = sc && anything && run_mean && !mean_jac && !run_cov && sc->K >= 4;
+#ifdef CPI_EXPERIMENTS
+    if (expsw::no_fused_cut()) fused_cut = false;
+#endif
+
+    DeviceGuard guard_;
+    CPI_HIP(ctx, guard_.enter(ctx->device));
+    if (sc && !fused_cut) {
+        launch::cut_windows(sc->K, knots, (long long)W, sc->update, (int)N, sc->first, sc->count, sc->tstart, sc->tend, ctx->stream);
+        CPI_HIP(ctx, hipGetLastError());
+        first = reinterpret_cast<const int64_t *>(sc->first); count = sc->count;
+    }
+    if (!anything) return CPI_OK;
+    PreArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = W; a.N = N; a.knots = knots; a.first = (const long long *)first; a.count = count;
+    a.lin = lin; a.qk = q_k_lin;
+    if (sc) { a.K = sc->K; if (!fused_cut) { a.tstart = sc->tstart; a.tend = sc->tend; } }
+    for (int i = 0; i < 3; i++) a.grav[i] = prm->grav[i];
+    a.q4[0] = prm->sigma_w * prm->sigma_w; a.q4[1] = prm->sigma_wb * prm->sigma_wb;
+    a.q4[2] = prm->sigma_a * prm->sigma_a; a.q4[3] = prm->sigma_ab * prm->sigma_ab;
+    a.out = *out;
+    if (forster) {   // one kernel owns everything; imu_avg, q_k_lin, grav play no part
+        launch::forster(a, ctx->stream);
+        CPI_HIP(ctx, hipGetLastError());
+        return CPI_OK;
+    }
+
     // Model 1 with Jacobians AND covariance is two independent kernels over the same knots (disjoint outputs).  The
     // covariance kernel waits on the LDS pipe about as much as it issues VALU work and uses no more than two wavefronts per
     // SIMD; the Jacobian kernel is pure FP64 VALU with no LDS: issued on a side stream (fork / join by events, so everything
@@ -296,6 +321,7 @@ static int preintegrate_impl(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int
         PreArgs m = a;
         m.write_means = (want_mean && !run_cov) ? 1 : 0;
         m.write_jac = mean_jac ? 1 : 0;
+        if (fused_cut) { m.update = sc->update; m.count_out = sc->count; m.first = nullptr; m.count = nullptr; }
         const int LL = pick_lanes(prm, W, N, mean_jac);
         long long done = 0;
 #ifdef CPI_EXPERIMENTS
@@ -352,17 +378,13 @@ extern "C" int cpi_preintegrate_stream(cpi_ctx *ctx, const cpi_params *prm, int6
     if (prm->lanes_per_window != 0 && !launch::mean_lanes_supported(prm->lanes_per_window))
         return fail(ctx, CPI_ERR_INVALID, "lanes_per_window must be 0 or one of 1,2,3,4,5,6,8,12,16,32,64");
     char *ws = static_cast<char *>(workspace);
-    long long *first = reinterpret_cast<long long *>(ws);
-    double *tstart = reinterpret_cast<double *>(ws + align16((size_t)U * 8));
-    double *tend = reinterpret_cast<double *>(ws + 2 * align16((size_t)U * 8));
-    int *count = reinterpret_cast<int *>(ws + 3 * align16((size_t)U * 8));
-    {
-        DeviceGuard guard_;
-        CPI_HIP(ctx, guard_.enter(ctx->device));
-        launch::cut_windows((long long)K, stream, (long long)U, update_times, (int)N, first, count, tstart, tend, ctx->stream);
-        CPI_HIP(ctx, hipGetLastError());
-    }
-    return preintegrate_impl(ctx, prm, U, N, stream, reinterpret_cast<const int64_t *>(first), count, tstart, tend, lin, q_k_lin, out);
+    StreamCut sc;
+    sc.K = (long long)K; sc.update = update_times;
+    sc.first = reinterpret_cast<long long *>(ws);
+    sc.tstart = reinterpret_cast<double *>(ws + align16((size_t)U * 8));
+    sc.tend = reinterpret_cast<double *>(ws + 2 * align16((size_t)U * 8));
+    sc.count = reinterpret_cast<int *>(ws + 3 * align16((size_t)U * 8));
+    return preintegrate_impl(ctx, prm, U, N, stream, nullptr, nullptr, &sc, lin, q_k_lin, out);
 }
 
 // ============================================================================================

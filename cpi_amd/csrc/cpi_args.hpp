@@ -31,6 +31,14 @@ struct PreArgs {
     // [stamp of the last real knot, tend[w]] with that knot's reading held.  Both NULL: plain knots.
     const double *tstart;
     const double *tend;
+    // FUSED cut (mean-only requests of cpi_preintegrate_stream; cpi_mean_kernel<..., CUT = 2>): knots = the stream of K
+    // readings, update[W] = the update times; every wavefront finds where the reference's deque stands for its own windows
+    // (the arithmetic of cpi_cut_windows_kernel, in registers) and writes the TRUE interval count to count_out[W] --
+    // first / count / tstart / tend stay NULL and no cut kernel runs.  K > 0 also tells a CUT = 1 launch where the stream
+    // ends (fast addressing: a wavefront whose furthest read stays inside the stream needs no per-element pointers).
+    const double *update;
+    long long K;
+    int *count_out;
     double grav[3];
     double q4[4];      // sigma^2 of the four diagonal blocks of Q_c (CpiBase.h:54-57)
     int write_means;   // kernel writes DT/alpha/beta/q

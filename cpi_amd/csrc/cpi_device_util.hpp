@@ -168,6 +168,22 @@ __device__ __forceinline__ int wave_max(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS, no vector registers in between.  The LDS image of one
+// instruction is fixed by the hardware -- "wave-uniform base (M0) + 16 x lane" --, the global address is "scalar base +
+// 32-bit lane offset"; gfx950 takes 8-byte aligned sources (56-byte knots).  hipcc does not preserve M0 around a statement, so
+// it is set and restored here.  Ordering is the wave's own counted s_waitcnt vmcnt (the compiler's counter model does not see
+// these loads: wait explicitly with wait_vmcnt); a region is re-armed only after lgkmcnt(0) has retired the reads of its
+// previous contents.
+__device__ __forceinline__ void glds16(unsigned voff, const void *sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); }
+__device__ __forceinline__ long long readfirstlane64(long long v) {
+    return ((long long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+}
+
 // (PreArgs: cpi_args.hpp)
 
 

@@ -28,12 +28,16 @@ bool mean_lanes_supported(int L) {
 
 template <int MODEL, bool JAC, bool AVG>
 static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
-    const bool cut = a.tstart != nullptr;
+    // 0: plain knots; 1: windows cut by cpi_cut_windows_kernel (workspace route); 2: the wavefront cuts its own windows
+    // (mean-only requests of cpi_preintegrate_stream; no analytic-Jacobian instantiations -- the caller never asks)
+    const int cut = a.update != nullptr ? 2 : (a.tstart != nullptr ? 1 : 0);
 #define CPI_LAUNCH_L(LL)                                                                         \
     case LL: {                                                                                   \
         const long long nb = (a.W + (64 / LL) - 1) / (64 / LL);                                  \
-        if (cut) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL, true>), dim3((unsigned)nb), dim3(64), 0, st, a); \
-        else hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL, false>), dim3((unsigned)nb), dim3(64), 0, st, a); \
+        if (cut == 2) {                                                                          \
+            if constexpr (!JAC) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL, 2>), dim3((unsigned)nb), dim3(64), 0, st, a); \
+        } else if (cut == 1) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL, 1>), dim3((unsigned)nb), dim3(64), 0, st, a); \
+        else hipLaunchKernelGGL((cpi_mean_kernel<MODEL, JAC, AVG, LL, 0>), dim3((unsigned)nb), dim3(64), 0, st, a); \
     } break;
     if constexpr (MODEL == 2 && JAC) { switch (L) { CPI_LAUNCH_L(1) default: break; } } else
     switch (L) {

@@ -39,13 +39,7 @@ struct DmaGeom {
     static_assert((KC * 56) % 16 == 0, "a stage is a whole number of 16-byte pieces (KC even)");
     static_assert(!ALIGNED || (WPI % 2 == 0), "alignment phase of an instruction's first window must not depend on j");
 };
-__device__ __forceinline__ void glds16(unsigned voff, const void *sbase, unsigned lds_dst) {
-    unsigned keep;
-    // M0 carries the LDS destination; hipcc does not preserve it around a statement, so it is set and restored here
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); }
+// (glds16 / wait_vmcnt: cpi_device_util.hpp)
 template <int MODEL, bool AVG, int KC, int S, bool ALIGNED>
 __global__ __launch_bounds__(64, 1) void cpi_mean_dma_kernel(PreArgs A) {
     typedef DmaGeom<KC, ALIGNED> G;

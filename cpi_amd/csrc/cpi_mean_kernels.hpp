@@ -4,16 +4,73 @@
 
 namespace {
 
+// Number of knots with stamp <= T (stamps non-decreasing).  An IMU stream is sampled almost uniformly, so the answer lies
+// within a few knots of the linear interpolation between the stream's ends: gallop from that guess until T is bracketed,
+// then bisect the bracket -- typically 3-5 probes inside one or two cache lines, where a plain bisection of a 50 M-knot
+// stream takes 26 probes of which the last ten are private to the window (measured: 2.4 KB of extra HBM traffic per window).
+__device__ __forceinline__ long long knots_not_after(const double *stream, long long K, double T) {
+    const double t0 = stream[0], t1 = stream[(K - 1) * 7];
+    if (!(T >= t0)) return 0;
+    if (T >= t1) return K;
+    long long g = (long long)((T - t0) / (t1 - t0) * (double)(K - 1));
+    g = min(max(g, 0ll), K - 1);
+    long long lo, hi;                       // invariant: stream[lo - 1] <= T (or lo == 0), stream[hi] > T (or hi == K)
+    if (stream[g * 7] <= T) {
+        lo = g + 1; hi = K;
+        for (long long step = 1; lo < K; step <<= 1) {
+            const long long p = min(g + step, K - 1);
+            if (stream[p * 7] <= T) { lo = p + 1; if (p == K - 1) break; } else { hi = p; break; }
+        }
+    } else {
+        hi = g; lo = 0;
+        for (long long step = 1; hi > 0; step <<= 1) {
+            const long long p = max(g - step, 0ll);
+            if (stream[p * 7] <= T) { lo = p + 1; break; } else { hi = p; if (p == 0) break; }
+        }
+    }
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (stream[mid * 7] <= T) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// The same count with ONE memory round trip in the common case: the four stamps around the interpolation guess are requested
+// together (one or two cache lines) and resolved with compares; only a guess that does not bracket T (a stream with gaps)
+// falls back to the gallop above.  The answer is unique for non-decreasing stamps, so both routes return the same number.
+// Used by the fused cut in the prologue of cpi_mean_kernel<..., CUT = 2>, where every dependent round trip is exposed
+// latency of a whole wavefront.  t0 / t1: stamps of the first / last reading.
+__device__ __forceinline__ long long knots_not_after_near(const double *stream, long long K, double t0, double t1, double T,
+                                                          double &last_stamp) {
+    // last_stamp: the stamp of knot (result - 1) when result > 0 -- one of the probes in the common case, so the caller's
+    // "stamp of the front reading" costs no further round trip
+    last_stamp = t0;
+    if (!(T >= t0)) return 0;
+    if (T >= t1) { last_stamp = t1; return K; }
+    long long g = (long long)((T - t0) / (t1 - t0) * (double)(K - 1));
+    g = min(max(g, 1ll), K - 3);          // probes g - 1 .. g + 2 (K >= 4 is checked by the caller)
+    const double pa = stream[(g - 1) * 7], pb = stream[g * 7], pc = stream[(g + 1) * 7], pd = stream[(g + 2) * 7];
+    if (pa <= T && T < pd) {              // #{t <= T} = (g - 1) + 1 + [pb <= T] + [pc <= T]
+        last_stamp = (pc <= T) ? pc : ((pb <= T) ? pb : pa);
+        return g + (pb <= T ? 1 : 0) + (pc <= T ? 1 : 0);
+    }
+    const long long r = knots_not_after(stream, K, T);
+    last_stamp = stream[max(r - 1, 0ll) * 7];
+    return r;
+}
+
 // ============================================================================================
 // mean (+ analytic Jacobian) kernel
 // ============================================================================================
 #ifndef CPI_MEAN_WPS
 #define CPI_MEAN_WPS 1
 #endif
-// CUT: the windows are cut out of one stream in flight (cpi_preintegrate_stream; PreArgs::tstart / tend) -- a template
-// parameter, so that the plain-knot instantiations carry none of it (the 10 k-window headline launch is issue-bound:
-// a few extra live registers and selects per interval cost it 3-4 %).
-template <int MODEL, bool JAC, bool AVG, int L, bool CUT>
+// CUT: the windows are cut out of one stream in flight (cpi_preintegrate_stream) -- a template parameter, so that the
+// plain-knot instantiations carry none of it (the 10 k-window headline launch is issue-bound: a few extra live registers
+// and selects per interval cost it 3-4 %).  1: the cut was made by cpi_cut_windows_kernel (PreArgs::first / count / tstart /
+// tend: the workspace route, shared with the covariance kernels); 2: FUSED -- the wavefront cuts its own windows in its
+// prologue from PreArgs::update (mean-only requests: no cut kernel, no 56 bytes of workspace traffic per window, and the
+// search probes land on the lines the window reads anyway).
+template <int MODEL, bool JAC, bool AVG, int L, int CUT>
 __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) && L == 1 ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
     constexpr int WPB = 64 / L;       // windows per wavefront
     // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has several intervals (L <= 8; 20 k x 50 with
@@ -34,23 +91,46 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
     const bool valid = (w < A.W) && (grp < WPB);   // L not a power of two leaves 64 - WPB*L idle lanes
     if (grp >= WPB) w = (long long)blockIdx.x * WPB;   // idle lanes shadow the block's first window (stays near the block)
     if (w >= A.W) w = A.W - 1;
-    const int n = A.count ? min(max(A.count[w], 0), A.N) : A.N;   // a count outside [0, N] must not corrupt the packed descriptors
-    const long long k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
+    constexpr bool cut = CUT != 0;
+    int n;
+    long long k0;
+    // Windows cut out of a stream in flight: the window's first knot takes the stamp t_start, and a partial tail interval
+    // has NO knot in memory -- it is the last real knot's reading held until t_end.  The lane that owns the tail fetches one
+    // knot less and builds that knot from its predecessor when it gets there.
+    double t_start = 0.0, t_end = 0.0;
+    bool tail = false;
+    if constexpr (CUT == 2) {
+        // the arithmetic of cpi_cut_windows_kernel (GraphSolver_IMU.cpp:50-69 as a closed form), per lane, in registers
+        const double ts0 = A.knots[0], ts1 = A.knots[(A.K - 1) * 7];
+        const double T = A.update[w], Tp = A.update[w > 0 ? w - 1 : 0];
+        double stT, stP;
+        const long long cT = knots_not_after_near(A.knots, A.K, ts0, ts1, T, stT);
+        const long long cP = knots_not_after_near(A.knots, A.K, ts0, ts1, Tp, stP);
+        const long long fp = (w > 0) ? max(cP - 1, 0ll) : 0ll;
+        t_start = (w > 0) ? fmax(Tp, ts0) : ts0;
+        const long long fu = max(max(cT - 1, 0ll), fp);
+        const int m = (int)min(fu - fp, (long long)0x3fffffff);
+        const double front_t = (m > 0) ? stT : t_start;                  // m > 0: fu = cT - 1 > 0, whose stamp the search returned
+        const bool tl = (T - front_t) > 0;
+        const int cnt = m + (tl ? 1 : 0);
+        if (valid && l == 0) A.count_out[w] = cnt;                       // the TRUE count (cpi_stream_counts)
+        k0 = fp;
+        n = min(cnt, A.N);
+        t_end = T;
+        tail = tl && cnt <= A.N;                                         // a truncated window has lost its tail
+    } else {
+        n = A.count ? min(max(A.count[w], 0), A.N) : A.N;   // a count outside [0, N] must not corrupt the packed descriptors
+        k0 = A.first ? A.first[w] : w * (long long)(A.N + 1);
+        if constexpr (CUT == 1) {
+            t_start = A.tstart[w]; t_end = A.tend[w];
+            tail = (t_end == t_end) && (A.count[w] <= A.N);              // NaN = no tail; a truncated window has lost it
+        }
+    }
     const int per = (n + L - 1) / L;
     const int s0 = min(n, l * per), s1 = min(n, s0 + per);
     const int len = s1 - s0;
     const int maxlen = __builtin_amdgcn_readfirstlane(wave_max(len));   // wave-uniform: loop control stays scalar
-    // Windows cut out of a stream in flight (PreArgs::tstart / tend): the window's first knot takes the stamp tstart, and a
-    // partial tail interval has NO knot in memory -- it is the last real knot's reading held until tend.  The lane that owns
-    // the tail fetches one knot less and builds that knot from its predecessor when it gets there.
-    constexpr bool cut = CUT;
-    double t_start = 0.0, t_end = 0.0;
-    bool tail = false, tailseg = false;
-    if constexpr (cut) {
-        t_start = A.tstart[w]; t_end = A.tend[w];
-        tail = (t_end == t_end) && (A.count[w] <= A.N);                  // NaN = no tail; a truncated window has lost it
-        tailseg = tail && (s1 == n) && (len > 0);
-    }
+    const bool tailseg = cut && tail && (s1 == n) && (len > 0);
     const int len_f = len - (tailseg ? 1 : 0);                          // knots after the segment's first that exist in memory
     // First knot of the segment IN MEMORY.  Knot s0 always exists (a window owns count + 1 knots) -- except the virtual tail
     // knot, which only an EMPTY trailing segment (s0 == n, lanes beyond ceil(n / per)) can start on: nothing of such a segment is
@@ -130,7 +210,22 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
     unsigned voff[SEGD];   // byte offset of the element from the block's first knot (dense layouts)
     int smax[SEGD];
     int tofs[SEGD];
-    const double *blk0 = A.knots + (long long)blockIdx.x * WPB * (long long)(A.N + 1) * 7;   // wave-uniform
+    const double *blk0 = A.knots + (long long)blockIdx.x * WPB * (long long)(A.N + 1) * 7;   // wave-uniform (dense layout)
+    bool fast_stream = false;
+    if constexpr (cut) {
+        // The stream entry's twin of the dense layout's fast path below: "wave-uniform base + chunk stride in SGPRs + constant
+        // 32-bit lane offsets" is valid for a stream whenever (a) every lane-segment of the wavefront has the same length --
+        // then no lane ever CONSUMES a knot behind its own segment (the padded step of an odd last chunk is skipped, a tail
+        // knot is replaced by a select), so reading on is harmless whatever those knots hold --, (b) the segments lie within
+        // 2^30 bytes above the first one and (c) the furthest read stays inside the stream (PreArgs::K).  A uniform update
+        // grid satisfies all three for every wavefront but the last; ragged wavefronts keep the per-element pointers.
+        const long long b = k0 + sb;
+        const long long b0 = readfirstlane64(b);
+        const int nch = (maxlen + C - 1) / C;
+        const bool ok = (A.K > 0) && (len == maxlen) && (b >= b0) && (b - b0 < (1ll << 24)) && (b + (long long)nch * C <= A.K - 1);
+        fast_stream = __all(ok);
+        if (fast_stream) blk0 = A.knots + b0 * 7;
+    }
     {
         // (Issuing all SEGD descriptor reads before using the first -- one LDS round trip instead of SEGD dependent ones,
         // which hipcc keeps in program order with an s_waitcnt after each -- was measured: 12.55 vs 12.33 us per launch
@@ -156,7 +251,8 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
     // (Not with per-window counts: the knots behind a short window's last interval belong to the caller's dense array and
     // may never have been written -- a NaN there would reach the state through 0 * NaN on the inactive steps.  The
     // per-element path below stops at the segment's end and re-reads its last, valid knot instead.)
-    const bool safe_overread = (A.first == nullptr) && (A.count == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W);
+    const bool safe_overread = cut ? fast_stream
+                                   : ((A.first == nullptr) && (A.count == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W));
     auto issue = [&](int it) {
         if (safe_overread) {
             // scalar base (advanced by SALU) + constant 32-bit lane offsets: no vector arithmetic per element
@@ -184,7 +280,12 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
     // Per-wavefront time stamps explain why: with 1000 wavefronts in flight a chunk is 3.6 MB and takes 0.89 us
     // (0.74 us with 625 wavefronts, 1.2 us with 2000) -- the loop streams at ~4 TB/s and is paced by the memory
     // system, not by the latency of one wavefront's accesses.
-    const int nchunks = (maxlen + C - 1) / C;
+    // Stream windows on a uniform update grid: EVERY lane-segment of the wavefront ends in its window's tail interval and all
+    // are equally long -- the tail step is then peeled off behind the loop and the loop carries no per-step selects (14
+    // v_cndmask per interval of ~300 VALU; measured on the 1 M x 51 stream: 724 -> see DESIGN.md 3.1b).  Wave-uniform.
+    const bool utail = cut && __all(tailseg && len == maxlen);
+    const int nsteps = utail ? maxlen - 1 : maxlen;
+    const int nchunks = (nsteps + C - 1) / C;
     if (nchunks > 0) issue(0);
     for (int it = 0; it < nchunks; ++it) {
         commit();
@@ -193,16 +294,18 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
 #pragma unroll   // C <= 2: the two steps of a chunk share one basic block (no knot copy between them)
         for (int c = 0; c < C; ++c) {
             const int s = it * C + c;
-            if (C > 1 && s >= maxlen) break;   // wave-uniform: no lane has this interval (odd longest segment)
+            if (C > 1 && s >= nsteps) break;   // wave-uniform: no lane has this interval (odd longest segment)
             const double *nk = &tile[lane * PITCH + c * 7];
             double q[7];
 #pragma unroll
             for (int i = 0; i < 7; i++) q[i] = nk[i];
             if constexpr (cut) {      // the tail knot: the predecessor's reading under the update time
-                const bool here = tailseg && s == len - 1;
-                q[0] = here ? t_end : q[0];
+                if (!utail) {
+                    const bool here = tailseg && s == len - 1;
+                    q[0] = here ? t_end : q[0];
 #pragma unroll
-                for (int i = 1; i < 7; i++) q[i] = here ? pk[i] : q[i];
+                    for (int i = 1; i < 7; i++) q[i] = here ? pk[i] : q[i];
+                }
             }
             if constexpr (GSEG)
                 mean_step_v2seg<AVG>(st, ga, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
@@ -214,6 +317,16 @@ __global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) 
             for (int i = 0; i < 7; i++) pk[i] = q[i];
         }
         __syncthreads();
+    }
+    if constexpr (cut) {
+        if (utail) {   // the peeled tail interval [stamp of the last real knot, t_end], that knot's reading held
+            if constexpr (GSEG)
+                mean_step_v2seg<AVG>(st, ga, pk[0], t_end, mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                     mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]), bw, ba, true);
+            else
+                mean_step<MODEL, JAC, AVG>(st, pk[0], t_end, mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                           mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]), bw, ba, gk, true);
+        }
     }
 
     }   // !DIRECT
@@ -455,36 +568,6 @@ __global__ __launch_bounds__(256) void cpi_tile_knots_kernel(long long W, int N,
 //     front(T)  = max(#{knots with t <= T} - 1, 0)          (the deque's front index after the window ending at T)
 //     stamp(T)  = max(T, t_0)                               (the front stamp after that window)
 // One wavefront per tile, one lane per window; a row of the tile is seven coalesced 512-byte stores.
-// Number of knots with stamp <= T (stamps non-decreasing).  An IMU stream is sampled almost uniformly, so the answer lies
-// within a few knots of the linear interpolation between the stream's ends: gallop from that guess until T is bracketed,
-// then bisect the bracket -- typically 3-5 probes inside one or two cache lines, where a plain bisection of a 50 M-knot
-// stream takes 26 probes of which the last ten are private to the window (measured: 2.4 KB of extra HBM traffic per window).
-__device__ __forceinline__ long long knots_not_after(const double *stream, long long K, double T) {
-    const double t0 = stream[0], t1 = stream[(K - 1) * 7];
-    if (!(T >= t0)) return 0;
-    if (T >= t1) return K;
-    long long g = (long long)((T - t0) / (t1 - t0) * (double)(K - 1));
-    g = min(max(g, 0ll), K - 1);
-    long long lo, hi;                       // invariant: stream[lo - 1] <= T (or lo == 0), stream[hi] > T (or hi == K)
-    if (stream[g * 7] <= T) {
-        lo = g + 1; hi = K;
-        for (long long step = 1; lo < K; step <<= 1) {
-            const long long p = min(g + step, K - 1);
-            if (stream[p * 7] <= T) { lo = p + 1; if (p == K - 1) break; } else { hi = p; break; }
-        }
-    } else {
-        hi = g; lo = 0;
-        for (long long step = 1; hi > 0; step <<= 1) {
-            const long long p = max(g - step, 0ll);
-            if (stream[p * 7] <= T) { lo = p + 1; break; } else { hi = p; if (p == 0) break; }
-        }
-    }
-    while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
-        if (stream[mid * 7] <= T) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
 // The same cut WITHOUT moving a knot (cpi_preintegrate_stream): per window the front reading's index, the interval count
 // (whole + tail), the start stamp and the update time of a tail interval (NaN: none) -- 28 bytes per window; the
 // preintegration kernels then read the stream in place (PreArgs::tstart / tend).
@@ -492,48 +575,110 @@ __global__ __launch_bounds__(256) void cpi_cut_windows_kernel(long long K, const
                                                               long long *first, int *count, double *tstart, double *tend) {
     const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
     if (u >= U) return;
-    const double t0 = stream[0], T = update[u];
+    const double t0 = stream[0], t1 = stream[(K - 1) * 7], T = update[u];
+    const bool near_ok = K >= 4;          // one round trip per search in the common case (knots_not_after_near)
     long long fp = 0;
-    double start_t = t0;
+    double start_t = t0, stT = t0, stP;
+    const long long cT = near_ok ? knots_not_after_near(stream, K, t0, t1, T, stT) : knots_not_after(stream, K, T);
     if (u > 0) {
         const double Tp = update[u - 1];
-        fp = max(knots_not_after(stream, K, Tp) - 1, 0ll);
+        fp = max((near_ok ? knots_not_after_near(stream, K, t0, t1, Tp, stP) : knots_not_after(stream, K, Tp)) - 1, 0ll);
         start_t = fmax(Tp, t0);
     }
-    const long long fu = max(max(knots_not_after(stream, K, T) - 1, 0ll), fp);
+    const long long fu = max(max(cT - 1, 0ll), fp);
     const int m = (int)min(fu - fp, (long long)0x3fffffff);
-    const double front_t = (m > 0) ? stream[fu * 7] : start_t;
+    const double front_t = (m > 0) ? (near_ok ? stT : stream[fu * 7]) : start_t;
     const bool tail = (T - front_t) > 0;
     first[u] = fp; count[u] = m + (tail ? 1 : 0); tstart[u] = start_t;
     tend[u] = tail ? T : __builtin_nan("");
 }
+// Rows leave as coalesced 512-byte stores (lane = window).  The READ side decides the speed of this kernel -- it is a copy:
+//   * round 3 let lane i load its own window's knots (8 B per lane and instruction, 64 different 128-byte lines per
+//     instruction): 1.46-1.48 ms per 1 M x 50 = 3.9 TB/s of read + write;
+//   * now the RB = 8 rows of a trip travel as LDS-DMA (glds16): one instruction fetches the 448 contiguous bytes of TWO
+//     windows (28 lanes x 16 B each), 32 instructions fill a 33-KB image of the trip's 64 x 8 knots -- no staging registers,
+//     8 lines per instruction instead of 64 --, and lane i then reads ITS window's values out of the image (pitch 1040 B per
+//     instruction image: 2-way bank conflicts, the minimum of this placement) for the row stores.
+// The DMA route needs the wavefront's windows within 2^24 knots above the first one and K >= RB (wave-uniform test); any
+// other wavefront takes the per-lane loads of round 3.
 __global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) {
+    constexpr int RB = 8;                       // rows per trip
+    constexpr int PPW = RB * 56 / 16;           // 16-byte pieces of a window's trip: 28
+    constexpr int WPI = 64 / PPW;               // windows per DMA instruction: 2
+    constexpr int NI = 64 / WPI;                // DMA instructions per trip: 32
+    constexpr int IMG = 1040;                   // bytes between instruction images (1024 + 16: see above)
+    static_assert(WPI == 2 && NI == 32, "lane maps below assume two windows per instruction");
+    __shared__ __attribute__((aligned(1024))) char img[NI * IMG];
+    __shared__ int srel[64];
     const int lane = threadIdx.x;
     const long long u = (long long)blockIdx.x * 64 + lane;
     const bool valid = u < A.U;
     const long long uc = valid ? u : A.U - 1;
-    const double t0 = A.stream[0];
+    const double t0 = A.stream[0], tl_ = A.stream[(A.K - 1) * 7];
     const double T = A.update[uc];
     long long fp = 0;
     double start_t = t0;
+    double stT, stP;
+    const bool near_ok = A.K >= 4;
+    const long long cT = near_ok ? knots_not_after_near(A.stream, A.K, t0, tl_, T, stT) : knots_not_after(A.stream, A.K, T);
     if (uc > 0) {
         const double Tp = A.update[uc - 1];
-        fp = max(knots_not_after(A.stream, A.K, Tp) - 1, 0ll);
+        const long long cP = near_ok ? knots_not_after_near(A.stream, A.K, t0, tl_, Tp, stP) : knots_not_after(A.stream, A.K, Tp);
+        fp = max(cP - 1, 0ll);
         start_t = fmax(Tp, t0);
     }
-    const long long fu = max(max(knots_not_after(A.stream, A.K, T) - 1, 0ll), fp);
+    const long long fu = max(max(cT - 1, 0ll), fp);
     const int m = (int)min(fu - fp, (long long)0x3fffffff);          // whole intervals
-    const double front_t = (m > 0) ? A.stream[fu * 7] : start_t;
+    const double front_t = (m > 0) ? (near_ok ? stT : A.stream[fu * 7]) : start_t;   // m > 0: fu = cT - 1, whose stamp the search returned
     const bool tail = (T - front_t) > 0;
     const int cnt = m + (tail ? 1 : 0);
     if (valid) A.count[u] = cnt;                                      // the TRUE count: a caller can check max(count) <= N
     const int rows = min(cnt, A.N);                                   // rows 0 .. rows exist in the tile
     const int rmax = __builtin_amdgcn_readfirstlane(wave_max(rows));
     double *tb = A.tiles + (long long)blockIdx.x * A.ts + lane;
-    // RB rows per trip: a lane then consumes RB x 56 contiguous bytes of the stream while its 128-byte lines are in flight /
-    // fresh in the L1.  Row by row, the lines of the 64 windows of every resident wavefront (8 MB per XCD) fell out of the
-    // L1 AND the L2 between two touches and the stream was fetched twice: 1.66 ms per 1 M x 50 windows.
-    constexpr int RB = 8;
+
+    const long long base = min(readfirstlane64(fp), A.K - RB);        // wave-uniform; the DMA offsets are relative to it
+    const bool dma = __all((A.K >= RB) && (fp >= readfirstlane64(fp)) && (fp + (long long)m - base < (1ll << 24)));
+    if (dma) {
+        const char *sbase = reinterpret_cast<const char *>(A.stream + base * 7);
+        const int dw = min(lane / PPW, WPI - 1);                      // lanes 56..63 re-fetch a piece of the second window
+        const int dp = (lane < PPW * WPI) ? lane - dw * PPW : 0;
+        const unsigned img_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)img);
+        const char *mine = img + (lane / WPI) * IMG + (lane % WPI) * (PPW * 16);   // this lane's window in the image
+        for (int r0 = 0; r0 <= rmax; r0 += RB) {
+            // the trip's RB knots of window i start at knot fp + min(r0, m) (rows past m repeat knot m: the tail row is knot
+            // m's reading under the update time), pulled back so that the piece stays inside the stream
+            const long long st = min(fp + (long long)min(r0, m), A.K - RB);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the previous trip's image reads have retired
+            srel[lane] = (int)(st - base);
+            wave_lds_fence();
+            unsigned so[NI];                                          // all offsets first: one LDS round trip, then 32 DMA issues
+#pragma unroll
+            for (int j = 0; j < NI; ++j) so[j] = (unsigned)srel[j * WPI + dw];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) glds16(so[j] * 56u + (unsigned)dp * 16u, sbase, img_base + j * IMG);
+            wait_vmcnt<0>();
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < RB; i++) {
+                const int r = r0 + i;
+                const int jj = (int)(fp + (long long)min(r, m) - st);             // 0 .. RB - 1 for every row that is stored
+                const double *src = reinterpret_cast<const double *>(mine + min(max(jj, 0), RB - 1) * 56);
+                double v[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) v[k] = src[k];
+                if (r == 0) v[0] = start_t;
+                if (tail && r == m + 1) v[0] = T;
+                if (r <= rows) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) tb[(long long)r * A.ss + k * 64] = v[k];
+                }
+            }
+        }
+        return;
+    }
+    // per-lane loads (round 3): RB rows per trip, a lane consumes RB x 56 contiguous bytes of the stream while its 128-byte
+    // lines are in flight / fresh in the L1
     for (int r0 = 0; r0 <= rmax; r0 += RB) {
         double v[RB][7];
 #pragma unroll

@@ -229,7 +229,7 @@ def test_bench_gpus_2_end_to_end_rehearsal_on_one_gpu():
     for extra in ([], ["--workload", "v2_full", "--windows", "20000", "--scaling", "strong"]):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extra",
                             "--no-cpu"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
-        assert p.returncode == 0, p.stderr[-2000:]
+        assert p.returncode == 0, "\n".join(ln for ln in p.stderr.splitlines() if "Traceback" in ln or "Error" in ln or "bench.py" in ln or "assert" in ln)[-3000:]
         line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")][-1]
         d = json.loads(line)
         assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 5

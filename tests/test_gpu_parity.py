@@ -321,7 +321,7 @@ def test_config2_size_launch_geometries_vs_reference_sample(eng, orc, model):
     from cpi_amd import stream as st
     W, N = 10000, 50
     mode = (model, 0, 1)
-    pick = np.arange(0, W, 79)[:128]                       # every 79th window: all tiles / wavefronts, every lane-group position
+    pick = np.arange(0, W, 77)[:128]                       # every 77th window: all tiles / wavefronts, every lane-group position
     assert pick.size == 128 and pick[-1] < W
     # ---- dense layout: (i) auto, (ii) L = 1 and 64 (+ the neighbours of the auto choice)
     kn, lin, q = synth.make_windows(W, N, seed=53 + model, device=eng.device)

@@ -244,7 +244,10 @@ def test_gpu_stream_entry_never_reads_behind_the_last_reading(model):
     K = stream.shape[0]
     upd = upd.clone(); upd[-1] = stream[-1, 0] + 0.003                          # the last window ends PAST the last stamp: fu == K - 1
     knots, first, count = st.assemble_windows(stream.numpy(), upd.numpy())
-    assert int(first[-1]) + int(count[-1]) == K and int(count[-1]) >= 2         # its virtual tail knot would be knot K
+    # the last window: its front reading + whole intervals reach the stream's LAST reading, then a tail -- the virtual tail
+    # knot would be knot K, one past the buffer
+    front = int(np.searchsorted(stream[:, 0].numpy(), float(upd[-2]), side="right")) - 1
+    assert front + int(count[-1]) == K and int(count[-1]) >= 2 and float(upd[-1]) > float(stream[-1, 0])
     N = int(count.max())
     big = torch.full((K + 8, 7), float("nan"), dtype=torch.float64, device=eng.device)
     big[:K] = stream.to(eng.device)

@@ -31,6 +31,8 @@ def main():
         gbs = bench.bytes_per_unit(name, N) * W / (best * 1e-6) / 1e9
         print("%-18s %-10s W=%-8d L=%-3d launch_us=%10.2f  units/s=%.4g  GB/s=%.1f  frac=%.3f" % (
             tag, name, W, lanes, best, W / (best * 1e-6), gbs, gbs / 8000.0), flush=True)
+        if wl.assembly:
+            print("%-18s   assembly (cpi_assemble_tiles) %.4f ms per batch = %.0f GB/s of read + write" % (tag, wl.assembly["ms_per_batch"], wl.assembly["GBs"]), flush=True)
         del wl
         torch.cuda.empty_cache()
 
