@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernels are VALU / LDS-bound
 MALL_BYTES = 256 << 20
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 
 # name -> kind, model, default units per step, samples, algorithmic HBM bytes per unit at 50 samples (SURVEY.md 8(d):
 # read + write, f64, compulsory traffic only), dominant kernel.  kinds: "pre" preintegration (dense layout), "tiled" the
@@ -84,9 +84,11 @@ WORKLOADS = {
     "v1_mean_tiled": dict(kind="tiled", model=1, want=("mean",), W=1000000, N=50, bytes=2856 + 88, kernel="cpi_mean_tiled_kernel<1,false,true,SPLIT>"),
     "v2_mean_tiled": dict(kind="tiled", model=2, want=("mean",), W=1000000, N=50, bytes=2888 + 88, kernel="cpi_mean_tiled_kernel<2,false,true,SPLIT>"),
     # the zero-copy stream entry (cpi_preintegrate_stream): ONE resident IMU stream of W x N + 1 readings + W update times, the
-    # kernels cut the windows in place.  A window reads N new readings (the boundary reading is shared), its update time,
-    # lin, and its 28-byte workspace record twice (written by the cut kernel, read by the preintegration kernel)
-    "v1_mean_stream": dict(kind="stream", model=1, want=("mean",), W=1000000, N=50, bytes=2800 + 8 + 48 + 56 + 88, kernel="cpi_mean_kernel<1,false,false,L> (+ cpi_cut_windows_kernel)"),
+    # kernels cut the windows in place.  A window reads N new readings (the boundary reading is shared), its update time and
+    # lin.  Mean-only (round 4): the mean kernel cuts its own windows -- no cut kernel, no workspace record; it writes the
+    # window's true interval count (4 B).  The *_full rows keep the workspace route: a 28-byte record per window written by the
+    # cut kernel and read by the preintegration kernel(s)
+    "v1_mean_stream": dict(kind="stream", model=1, want=("mean",), W=1000000, N=50, bytes=2800 + 8 + 48 + 4 + 88, kernel="cpi_mean_kernel<1,false,false,1,CUT=2,BIG> (fused cut)"),
     "v1_full_stream": dict(kind="stream", model=1, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2800 + 8 + 48 + 56 + 2320, kernel="cpi_cov_kernel<1,false> (+ cut, Jacobian kernels)",
                            useful_lanes=(15, 16)),
     "v2_full_stream": dict(kind="stream", model=2, want=("mean", "jac", "cov"), W=100000, N=50, bytes=2800 + 8 + 80 + 56 + 2392, kernel="cpi_cov_kernel<2,false> (+ cut kernel)",
@@ -551,7 +553,7 @@ def sparse_port_rate(wl, kn, lin, q, cores, seconds):
 
 # ------------------------------------------------------------------------------------------------ counters
 def load_pmc(build_id):
-    """profiles/r03_pmc.json: rocprofv3 --pmc passes of tools/pmc_collect.sh, stamped with the build id of the library
+    """profiles/r04_pmc.json: rocprofv3 --pmc passes of tools/pmc_collect.sh, stamped with the build id of the library
     they were collected on.  Used only when that stamp equals the LOADED library's cpi_build_id(); otherwise the
     counter-derived fields are null (the file is stale for this library)."""
     try:

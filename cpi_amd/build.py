@@ -180,6 +180,39 @@ def build_test_hooks():
     return LIB_TEST
 
 
+def build_custom(tag, defines):
+    """A/B builds of kernel variants (development; tools/exp/): every unit compiled with the extra defines into
+    _obj/<unit>__<tag>.o and linked into cpi_amd/libcpi_amd_<tag>.so -- load it with CPI_AMD_LIB.  Never the product path.
+        python -m cpi_amd.build --custom lean0 -DCPI_MEAN_LEAN=0"""
+    lib = os.path.join(HERE, "libcpi_amd_%s.so" % tag)
+    with _BuildLock():
+        def one(unit):
+            # a unit is rebuilt only when one of the files it includes mentions one of the macros; the others are the default build's objects
+            text = "".join(open(_path(d), errors="ignore").read() for d in UNITS[unit])
+            defs = [d for d in defines if d[2:].split("=")[0] in text]
+            if unit == "cpi_abi":
+                defs.append('-DCPI_BUILD_ID="%s"' % (source_id() + "+" + tag)[:31])
+            elif not defs:
+                return _compile(unit, "", False)[0]
+            obj = os.path.join(OBJ, "%s__%s.o" % (unit, tag))
+            key = _unit_key(unit, defs, False)
+            if os.path.exists(obj) and os.path.exists(obj + ".key") and open(obj + ".key").read() == key:
+                return obj
+            p = subprocess.run([HIPCC] + CFLAGS + defs + ["-c", "-o", obj, os.path.join(CSRC, unit + ".hip")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if p.returncode != 0:
+                sys.stderr.write(p.stdout)
+                raise RuntimeError("hipcc failed on %s.hip (%s)" % (unit, tag))
+            with open(obj + ".log", "w") as f:
+                f.write(p.stdout)
+            with open(obj + ".key", "w") as f:
+                f.write(key)
+            return obj
+        with ThreadPoolExecutor(len(UNITS)) as ex:
+            objs = list(ex.map(one, UNITS))
+        _link(lib, objs)
+    return lib
+
+
 def _build_locked(force, report, experiments, test_hooks):
     todo = []   # staleness is judged INSIDE the lock: whoever waited for another builder finds the library fresh
     for variant, wanted in (("", True), ("exp", experiments), ("test", test_hooks)):
@@ -206,6 +239,10 @@ def _build_locked(force, report, experiments, test_hooks):
 
 
 if __name__ == "__main__":
+    if "--custom" in sys.argv:
+        i = sys.argv.index("--custom")
+        print(build_custom(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")]))
+        sys.exit(0)
     build(force="--force" in sys.argv, report="--report" in sys.argv, experiments="--experiments" in sys.argv,
           test_hooks="--test-hooks" in sys.argv)
     print(LIB)

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
                     double mt[D::NR];
                     const double *Xs = cov_stage_X(Ln, stg);
 #pragma unroll
-                    for (int i = 0; i < D::NR; i++) mt[i] = dpp_shr6_bank3(ex_row[exch_pos<MODEL>(i)], Xs[i]);
+                    for (int i = 0; i < D::NR; i++)
+                        mt[i] = (MODEL == 1) ? dpp_shr6_bank3(ex_row[exch_pos<MODEL>(i)], Xs[i])
+                                             : dpp_shr6_bank3_oddrows(ex_row[exch_pos<MODEL>(i)], Xs[i]);
                     cov_stage_finish_regs(Ln, stg, M, mt);
                 } else {
                     cov_stage_finish(Ln, stg, M, ex_row);

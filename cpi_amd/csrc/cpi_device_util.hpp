@@ -155,6 +155,13 @@ __device__ __forceinline__ double dpp_shr6_bank3(double old, double src) {
     const int nhi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x116, 0xf, 0x8, false);
     return __hiloint2double(nhi, nlo);
 }
+// the same for the odd DPP rows only (row_mask 0b1010): lanes 28..31 / 60..63 <- 22..25 / 54..57 -- model 2's p lanes take
+// the stage value of its v lanes (cpi_math.hpp: CPI_COV2_PSYM lane map)
+__device__ __forceinline__ double dpp_shr6_bank3_oddrows(double old, double src) {
+    const int nlo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0x116, 0xa, 0x8, false);
+    const int nhi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x116, 0xa, 0x8, false);
+    return __hiloint2double(nhi, nlo);
+}
 // Maximum over the wavefront, wave-uniform result.  DPP reduction (row_shr 1/2/4/8 -> lane 15 of each row holds the row
 // maximum; row_bcast:15 / row_bcast:31 carry it across rows; lane 63 holds the total) instead of six dependent
 // ds_bpermute round trips: it sits on the critical path of every wavefront's start-up.

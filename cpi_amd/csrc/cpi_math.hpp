@@ -800,8 +800,18 @@ static const int EXCH_WIN = 192;
 // 15-17) | 8-19 (columns 3-14); a ds_write_b64 is served 16 contiguous lanes at a time on 32 banks, so the columns the
 // first 16 lanes own (0-10 and 15-17) must sit on distinct positions mod 16: the clone columns move to 11-13 and
 // columns 11-14 to 14-17.  (With the identity, columns 16 and 17 collide with 0 and 1 on every exchange write.)
+#ifndef CPI_COV2_PSYM
+#define CPI_COV2_PSYM 0   // model 2: rows p of F X by symmetry + DPP (needs the lane map that puts v and p in one DPP row); see CovPBySymmetry
+#endif
+#if CPI_COV2_PSYM
+// lane map with v / p in DPP row 1 (cov_col_of_lane): the first 16 lanes own columns 0-5, 9-11 and the clone columns 15-17,
+// the second 16 own 6-8 and 12-14: clone columns at positions 12-14, p columns at 15-17 keep both groups distinct mod 16
+template <int MODEL>
+CPI_HD constexpr int exch_pos(int c) { return (MODEL == 1 || c <= 11) ? c : (c <= 14 ? c + 3 : c - 3); }
+#else
 template <int MODEL>
 CPI_HD constexpr int exch_pos(int c) { return (MODEL == 1 || c <= 10) ? c : (c <= 14 ? c + 3 : c - 4); }
+#endif
 CPI_HD constexpr int exch_doubles(int G) { return G * EXCH_WIN + 20 + (EXCH_SHARED_ROWS - 1) * EXCH_PITCH; }
 CPI_HD int exch_shared_off(int G, int s) {   // offset (doubles) of shared row s = layout row 9 + s
     return (s == 0) ? EXCH_GROUP_ROWS * EXCH_PITCH : G * EXCH_WIN + 20 + (s - 1) * EXCH_PITCH;
@@ -828,11 +838,25 @@ template <int MODEL>
 CPI_HD int cov_col_of_lane(int l) {
     typedef CovDims<MODEL> D;
     if (MODEL == 1) return (l < D::NCOL) ? l : D::NCOL;
+#if CPI_COV2_PSYM
+    // DPP row 0: theta 0-2 | idle | clone 4-6 | idle | b_w 8-10 | b_a 11-13 | idle 14, 15
+    // DPP row 1: transition 16-21 | v 22-24 | transition 25-27 | p 28-30 | idle 31   -- p lanes = v lanes + 6 inside one row
+    if (l < 3) return l;
+    if (l == 3 || l == 7 || l == 14 || l == 15 || l == 31) return D::NCOL;
+    if (l < 7) return 15 + (l - 4);
+    if (l < 11) return 3 + (l - 8);
+    if (l < 14) return 9 + (l - 11);
+    if (l < 22) return 18 + (l - 16);
+    if (l < 25) return 6 + (l - 22);
+    if (l < 28) return 24 + (l - 25);
+    return 12 + (l - 28);
+#else
     if (l < 3) return l;
     if (l == 3 || l == 7 || l >= 29) return D::NCOL;
     if (l < 7) return 15 + (l - 4);
     if (l < 20) return l - 5;
     return 18 + (l - 20);
+#endif
 }
 // Which exchange row this column reads as its transposed contribution.
 CPI_HD int cov_exch_row(int j) {
@@ -937,7 +961,10 @@ CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, const M3 &Rs, double M[9
 // puts the p lanes in one 4-lane DPP bank and the v lanes a fixed distance below (model 1: lanes 12-14 <- 6-8), the
 // kernel takes them with masked row_shr DPP moves instead of sending 3 of the 9 exchange rows through LDS (the LDS pipe,
 // shared by the 8 wavefronts of a CU, is what bounds the covariance kernels; the VALU has slack).
-template <int MODEL> struct CovPBySymmetry { static const bool V = (MODEL == 1); };
+template <int MODEL> struct CovPBySymmetry { static const bool V = (MODEL == 1) || (CPI_COV2_PSYM != 0); };
+// the p lanes of a window group and the distance to their v lanes (same DPP row): model 1 lanes 12-15 <- 6-9, model 2 (lane
+// map above) lanes 28-31 <- 22-25
+template <int MODEL> struct CovPLanes { static const int FIRST = (MODEL == 1) ? 12 : 28, SHIFT = 6; };
 template <int MODEL> struct CovExchRows { static const int V = CovPBySymmetry<MODEL>::V ? 6 : 9; };   // rows written per stage
 template <int MODEL>
 CPI_HD const double *cov_stage_X(const CovLane<MODEL> &L, int s) { return (s == 0) ? L.P0 : L.X; }

@@ -26,11 +26,27 @@ bool mean_lanes_supported(int L) {
     return false;
 }
 
+// Stream entry, model 1, one lane per window, mean-only: from this many windows the three-knots-per-chunk instantiation
+// (cpi_mean_kernel<..., BIG>) is used.  It runs ONE wavefront per SIMD, which pays only when the batch fills the chip many times
+// over.  Measured (profiles/r04_mean_chunk_ab.md, same box, alternating): the 1 M x 51 stream 680-700 -> 664-670 us with HBM
+// traffic 1.42 x -> 1.11 x algorithmic; the DENSE layout gains the same traffic (1.26 x -> 1.08 x) but not time (one box 670 ->
+// 650 us, another 612-635 -> 640-647 us; 100 k - 700 k windows lose 2-9 %) and model 2 loses 5 % -- both keep two knots per chunk.
+#ifndef CPI_MEAN_BIG_W
+#define CPI_MEAN_BIG_W 500000
+#endif
 template <int MODEL, bool JAC, bool AVG>
 static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
     // 0: plain knots; 1: windows cut by cpi_cut_windows_kernel (workspace route); 2: the wavefront cuts its own windows
     // (mean-only requests of cpi_preintegrate_stream; no analytic-Jacobian instantiations -- the caller never asks)
     const int cut = a.update != nullptr ? 2 : (a.tstart != nullptr ? 1 : 0);
+    if constexpr (!JAC && MODEL == 1) {
+        if (L == 1 && cut != 0 && a.W >= (long long)CPI_MEAN_BIG_W) {
+            const unsigned nb = (unsigned)((a.W + 63) / 64);
+            if (cut == 2) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 2, true>), dim3(nb), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 1, true>), dim3(nb), dim3(64), 0, st, a);
+            return;
+        }
+    }
 #define CPI_LAUNCH_L(LL)                                                                         \
     case LL: {                                                                                   \
         const long long nb = (a.W + (64 / LL) - 1) / (64 / LL);                                  \

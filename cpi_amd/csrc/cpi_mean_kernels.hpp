@@ -64,24 +64,29 @@ __device__ __forceinline__ long long knots_not_after_near(const double *stream, 
 #ifndef CPI_MEAN_WPS
 #define CPI_MEAN_WPS 1
 #endif
+
 // CUT: the windows are cut out of one stream in flight (cpi_preintegrate_stream) -- a template parameter, so that the
 // plain-knot instantiations carry none of it (the 10 k-window headline launch is issue-bound: a few extra live registers
 // and selects per interval cost it 3-4 %).  1: the cut was made by cpi_cut_windows_kernel (PreArgs::first / count / tstart /
 // tend: the workspace route, shared with the covariance kernels); 2: FUSED -- the wavefront cuts its own windows in its
 // prologue from PreArgs::update (mean-only requests: no cut kernel, no 56 bytes of workspace traffic per window, and the
 // search probes land on the lines the window reads anyway).
-template <int MODEL, bool JAC, bool AVG, int L, int CUT>
-__global__ __launch_bounds__(64, (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) && L == 1 ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
+// BIG (one lane per window, mean-only, batches that fill the chip many times over): THREE knots per chunk instead of two.  The
+// longer pieces (168 B) re-touch fewer 128-byte lines -- HBM traffic of a 1 M-window launch 1.26 x -> 1.08 x algorithmic on the
+// dense layout, 1.42 x -> 1.11 x on the stream entry (FETCH_SIZE, rocprofv3) -- at the price of the second wavefront per SIMD
+// (266 registers).  Used for the stream entry only (cpi_mean.hip: launch_mean_L says why); 5 knots per chunk and 3 knots held to
+// two wavefronts per SIMD (40 B of scratch) are slower than either (profiles/r04_mean_chunk_ab.md).
+template <int MODEL, bool JAC, bool AVG, int L, int CUT, bool BIG = false>
+__global__ __launch_bounds__(64, BIG ? 1 : (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) && L == 1 ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
+    static_assert(!BIG || (L == 1 && !JAC && MODEL == 1 && CUT != 0), "BIG: stream entry, model 1, one lane per window, mean-only");
     constexpr int WPB = 64 / L;       // windows per wavefront
     // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has several intervals (L <= 8; 20 k x 50 with
     // L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us, 15 k with L = 4: 16.0 -> 15.3 us, 10 k with L = 6:
     // 12.5 -> 11.8 us once the padded second step of an odd last chunk is skipped), 1 when a wave is latency-bound
-    // with few intervals per lane (L >= 12: 5 k windows 9.55 vs 9.65 us, 2.5 k 7.7 vs 8.0 us); 3 / 4 knots per chunk cost the second
-    // wavefront per SIMD (L = 1, 1 M x 50 windows: 659 / 665 us against 651 us, model 2 700 / 1 919 against 640 us -- the longer
-    // pieces do not buy back what the re-touched 128-byte lines cost)
-    constexpr int C = (L <= 8 && !JAC) ? 2 : 1;
+    // with few intervals per lane (L >= 12: 5 k windows 9.55 vs 9.65 us, 2.5 k 7.7 vs 8.0 us); 3 for BIG (above)
+    constexpr int C = BIG ? 3 : ((L <= 8 && !JAC) ? 2 : 1);
     constexpr int SEGD = 7 * C;       // doubles per lane per chunk
-    constexpr int PITCH = SEGD + 1;   // odd pitch: conflict-free ds_read_b64 across the lanes of a half-wave
+    constexpr int PITCH = BIG ? SEGD : SEGD + 1;   // odd pitch (15, 21 doubles): a half-wave's ds_read_b64 hit 32 distinct even banks
     __shared__ double tile[64 * PITCH];
     __shared__ unsigned long long segdesc[64];  // per lane-segment: (first double of the segment << 16) | intervals
 
@@ -601,13 +606,16 @@ __global__ __launch_bounds__(256) void cpi_cut_windows_kernel(long long K, const
 //     instruction image: 2-way bank conflicts, the minimum of this placement) for the row stores.
 // The DMA route needs the wavefront's windows within 2^24 knots above the first one and K >= RB (wave-uniform test); any
 // other wavefront takes the per-lane loads of round 3.
+#ifndef CPI_ASM_RB
+#define CPI_ASM_RB 8
+#endif
 __global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) {
-    constexpr int RB = 8;                       // rows per trip
+    constexpr int RB = CPI_ASM_RB;              // rows per trip
     constexpr int PPW = RB * 56 / 16;           // 16-byte pieces of a window's trip: 28
     constexpr int WPI = 64 / PPW;               // windows per DMA instruction: 2
     constexpr int NI = 64 / WPI;                // DMA instructions per trip: 32
-    constexpr int IMG = 1040;                   // bytes between instruction images (1024 + 16: see above)
-    static_assert(WPI == 2 && NI == 32, "lane maps below assume two windows per instruction");
+    constexpr int IMG = (RB == 8) ? 1040 : 1072;   // bytes between instruction images: 2-way (RB = 8) / 3-way (RB = 4) read conflicts, the minima of these placements
+    static_assert((RB == 8 && WPI == 2) || (RB == 4 && WPI == 4), "RB = 8: two windows per instruction; RB = 4: four");
     __shared__ __attribute__((aligned(1024))) char img[NI * IMG];
     __shared__ int srel[64];
     const int lane = threadIdx.x;

@@ -137,8 +137,8 @@ void cov_window(int n, const double *kn, const double *lin, const double *qk, co
                         const double *row = exch.data() + cov_row_off<MODEL>(1, 0, colof[j]);
                         for (int i = 0; i < D::NR; i++) mt[j][i] = row[exch_pos<MODEL>(i)];
                     }
-                    for (int j = 12; j < 16 && j < NL; j++)
-                        for (int i = 0; i < D::NR; i++) mt[j][i] = cov_stage_X(lane[j - 6], st)[i];
+                    for (int j = CovPLanes<MODEL>::FIRST; j < CovPLanes<MODEL>::FIRST + 4 && j < NL; j++)
+                        for (int i = 0; i < D::NR; i++) mt[j][i] = cov_stage_X(lane[j - CovPLanes<MODEL>::SHIFT], st)[i];
                     for (int j = 0; j < NL; j++) cov_stage_finish_regs(lane[j], st, M[j], mt[j]);
                 } else {
                     for (int j = 0; j < NL; j++)

@@ -229,6 +229,57 @@ def test_gpu_stream_entry_reads_the_stream_in_place(mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["long", "mixed", "tiny", "end"])
+def test_gpu_device_assembler_every_pass_geometry(case):
+    """cpi_assemble_tiles copies the contiguous stream span of 16 consecutive windows through a 44-KB LDS image (804 knots) and
+    falls back to 8 / 4 / 2 / 1 windows per pass, and to row chunks of a single window, when the span does not fit.  Window
+    lengths chosen to hit every geometry -- windows of 900 and 2 000 intervals (chunked), groups of 300-interval windows (2 per
+    pass), empty windows, repeated update times, a stream shorter than 4 readings, the last window ending past the last
+    reading -- against the host assembler (the deque loop) slot for slot, and counts exactly."""
+    import torch
+    import cpi_amd
+    eng = cpi_amd.Engine()
+    rng = np.random.default_rng(7)
+    if case == "tiny":
+        K, lens = 3, [1, 0, 1, 0]
+    elif case == "long":
+        lens = [900, 3, 0, 410, 410, 50, 2000, 1, 1, 805, 804, 803, 2, 0, 0, 60, 17, 300, 300, 300, 300, 300, 300, 300, 300]
+        K = sum(lens) + 40
+    elif case == "mixed":
+        lens = list(rng.integers(0, 120, 200)) + [500, 500, 10] + list(rng.integers(40, 60, 77))
+        K = int(sum(lens)) + 5
+    else:
+        lens = [50] * 40
+        K = 50 * 40 - 7          # the last windows run past the stream's end
+    t = 100.0 + np.cumsum(np.full(K, 0.005)) - 0.005
+    stream = np.concatenate([t[:, None], rng.standard_normal((K, 6))], axis=1)
+    edges = np.minimum(np.cumsum(lens), K - 1 + 30)
+    ut = 100.0 + 0.005 * edges + 0.002                     # every window ends 2 ms behind a reading: a tail interval
+    ut[::7] -= 0.002                                        # ... except some that end exactly on a reading
+    ut = np.maximum.accumulate(ut)
+    knots, first, count = st.assemble_windows(stream, ut)
+    U, N = len(ut), max(int(count.max()), 1)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    tiles = torch.full(((U + 63) // 64, N + 1, 7, 64), float("nan"), dtype=torch.float64, device=eng.device)
+    _, cnt = eng.assemble_tiles(T(stream), T(ut), N, tiles=tiles)
+    torch.cuda.synchronize()
+    assert np.array_equal(cnt.cpu().numpy(), count), case
+    td = tiles.cpu().numpy()
+    for u in range(U):
+        assert np.array_equal(td[u // 64, :count[u] + 1, :, u % 64], knots[first[u]:first[u] + count[u] + 1]), (case, u, count[u])
+    # a bound N smaller than the longest window: rows beyond N are not written, the true counts still are
+    if N > 4:
+        small = torch.full(((U + 63) // 64, 5, 7, 64), float("nan"), dtype=torch.float64, device=eng.device)
+        _, cnt2 = eng.assemble_tiles(T(stream), T(ut), 4, tiles=small)
+        torch.cuda.synchronize()
+        assert np.array_equal(cnt2.cpu().numpy(), count)
+        sd = small.cpu().numpy()
+        for u in range(U):
+            n = min(int(count[u]), 4)
+            assert np.array_equal(sd[u // 64, :n + 1, :, u % 64], knots[first[u]:first[u] + n + 1]), (case, u)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model", [1, 2])
 def test_gpu_stream_entry_never_reads_behind_the_last_reading(model):
     """with several lanes per window an EMPTY trailing lane segment of a tail window started on the virtual tail
