@@ -137,8 +137,12 @@ int cpi_preintegrate_batch(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int32
  *                 (cpi_params.lanes_per_window = 0) is chosen from N, not from the counts
  *   lin, q_k_lin  per window, as in cpi_preintegrate_batch
  *   workspace     cpi_stream_workspace_bytes(U) bytes of device memory, 16-byte aligned (28 bytes per window: where the
- *                 reference's deque stands at each update, found by binary search because the stamps are sorted)
+ *                 reference's deque stands at each update, found by interpolation search because the stamps are sorted).
+ *                 After the call it holds the TRUE interval counts (cpi_stream_counts); the rest of its contents is
+ *                 unspecified: a mean-only request (DT / alpha / beta / q and nothing else, models 1 and 2) runs NO cut kernel --
+ *                 every wavefront of the mean kernel finds its own windows in its prologue and only the counts are written
  * The kernels patch the first knot's stamp and build the tail interval's closing knot from its predecessor in flight.
+ * The readings must be finite: a NaN / Inf reading invalidates (only) the windows that contain it.
  * Results are bit-identical to cpi_preintegrate_batch on the knots / first / count that the host assemblers
  * (cpi_amd/stream.py, cpi_host::assemble_windows) produce from the same stream. */
 size_t cpi_stream_workspace_bytes(int64_t U);
