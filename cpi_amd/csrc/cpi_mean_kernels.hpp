@@ -597,13 +597,20 @@ __global__ __launch_bounds__(256) void cpi_cut_windows_kernel(long long K, const
     first[u] = fp; count[u] = m + (tail ? 1 : 0); tstart[u] = start_t;
     tend[u] = tail ? T : __builtin_nan("");
 }
-// Rows leave as coalesced 512-byte stores (lane = window).  The READ side decides the speed of this kernel -- it is a copy:
-//   * round 3 let lane i load its own window's knots (8 B per lane and instruction, 64 different 128-byte lines per
-//     instruction): 1.46-1.48 ms per 1 M x 50 = 3.9 TB/s of read + write;
-//   * now the RB = 8 rows of a trip travel as LDS-DMA (glds16): one instruction fetches the 448 contiguous bytes of TWO
-//     windows (28 lanes x 16 B each), 32 instructions fill a 33-KB image of the trip's 64 x 8 knots -- no staging registers,
-//     8 lines per instruction instead of 64 --, and lane i then reads ITS window's values out of the image (pitch 1040 B per
-//     instruction image: 2-way bank conflicts, the minimum of this placement) for the row stores.
+// Rows leave as coalesced 512-byte stores (lane = window).  It is a copy with a transposition in it; designs measured on the
+// 1 M x 50 batch (profiles/r04_assembler.md):
+//   * round 3: lane i loads its own window's knots (8 B per lane and instruction, 64 different 128-byte lines per instruction):
+//     1.46-1.48 ms = 3.9 TB/s of read + write;
+//   * SHIPPED: the RB = 8 rows of a trip travel as LDS-DMA (glds16) -- one instruction fetches the 448 contiguous bytes of TWO
+//     windows (28 lanes x 16 B each), 32 instructions fill a 33-KB image of the trip's 64 x 8 knots, no staging registers, 8
+//     lines per instruction instead of 64 --, and lane i then reads ITS window's values out of the image (pitch 1040 B per
+//     instruction image: 2-way bank conflicts, the minimum of this placement) for the row stores: 1.16-1.21 ms = 4.7-4.9 TB/s
+//     algorithmic, 5.96 TB/s of real traffic (the 8-byte aligned pieces over-fetch 1.49 x on the read side);
+//   * 16-byte stores / 4 rows per trip (9 wavefronts per CU): 1.20 / 1.27 ms -- neither store issue nor occupancy paces it;
+//   * every line once: a wavefront owning 16 whole windows (128-byte row pieces: 1.79 ms -- small write pieces stream at half
+//     rate), line-aligned 512-byte trips with a carry for the straddling knot, rows stored out of step (reads 1.14 x, writes
+//     + 29 %: 1.40 ms) or in step with a 320-byte carry (traffic 1.05 x in total, but 54 KB of LDS = 3 wavefronts per CU:
+//     1.34 ms).  Commit "experiment (not shipped): line-aligned assembler" holds the last of them.
 // The DMA route needs the wavefront's windows within 2^24 knots above the first one and K >= RB (wave-uniform test); any
 // other wavefront takes the per-lane loads of round 3.
 #ifndef CPI_ASM_RB
@@ -645,90 +652,6 @@ __global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) 
     const int rmax = __builtin_amdgcn_readfirstlane(wave_max(rows));
     double *tb = A.tiles + (long long)blockIdx.x * A.ts + lane;
 
-#ifndef CPI_ASM_ALIGNED
-#define CPI_ASM_ALIGNED 1
-#endif
-#if CPI_ASM_ALIGNED
-    // LINE-ALIGNED trips (the stream pointer is 128-byte aligned -- every device allocation is): trip t of window i is the FOUR
-    // whole lines [a_i + 512 t, a_i + 512 (t + 1)) with a_i = its first knot's byte offset rounded down to a line, so every
-    // line of the stream is fetched exactly once (the 448-byte pieces of the route below start on 8-byte boundaries, touch 4.5
-    // lines for 3.5 lines of data and lose the straddled line before the next trip: 1.49 x read traffic by counters).  Rows
-    // are stored IN STEP -- every lane the same row, 512 contiguous bytes per (row, field) -- which a trip can do only for the
-    // rows ALL windows have complete: the windows' phases (first knot's offset in its line, 0 .. 120 B) put them up to three
-    // rows apart, so the last CARRY bytes of a piece are kept for the rows (and the straddling knot) a window is ahead by.
-    // (Letting every lane store the rows it has -- out of step -- was built first: reads 1.14 x, but the 512-byte rows then
-    // leave in two or three partial instructions and the WRITE traffic grew 29 %: 1.40 ms against 1.20 ms.)
-    {
-        constexpr int TB = 512, AIMG = 1040, CARRY = 320;
-        static_assert(RB != 8 || NI * AIMG <= (int)sizeof(img), "image fits");
-        __shared__ __attribute__((aligned(16))) char carry[64 * CARRY];
-        const long long b0 = fp * 56, abyte = b0 & ~127ll;
-        const int ph = (int)(b0 - abyte);                               // 0 .. 120, multiple of 8
-        const long long nbytes = ((long long)m + 1) * 56;               // knots 0 .. m of the window
-        const long long abase = readfirstlane64(abyte);                 // wave-uniform base of the DMA offsets
-        const long long send = A.K * 56;                                // bytes of the stream
-        const bool aligned = __all((((unsigned long long)(size_t)A.stream & 127ull) == 0) && (abyte >= abase) &&
-                                   (abyte - abase + ph + nbytes < (1ll << 31)) && (RB == 8));
-        if (aligned) {
-            const char *sbase = reinterpret_cast<const char *>(A.stream) + abase;
-            const int dw = lane >> 5, dp = lane & 31;                   // two windows per instruction, 32 pieces of 16 B each
-            const unsigned img_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)img);
-            const char *mine = img + (lane >> 1) * AIMG + (lane & 1) * TB;
-            char *mycarry = carry + lane * CARRY;
-            const unsigned lastpiece = (unsigned)min(((send & ~15ll) - 16) - abase, (long long)0x7ffffff0);   // last whole 16-byte piece of the stream
-            const int ntr = (int)((ph + nbytes + TB - 1) / TB);
-            const int ntrips = __builtin_amdgcn_readfirstlane(wave_max(ntr));
-            const unsigned arel = (unsigned)(abyte - abase);
-            const int phmax = __builtin_amdgcn_readfirstlane(wave_max(ph));
-            const int mmax1 = __builtin_amdgcn_readfirstlane(wave_max(min(m, rows))) + 1;   // knot rows 0 .. mmax1 - 1 exist somewhere in the tile
-            int rdone = 0;                                              // rows 0 .. rdone - 1 are stored (wave-uniform)
-            for (int t = 0; t < ntrips; ++t) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous trip's image reads (and carry copy) have retired
-                srel[lane] = (int)min((long long)arel + (long long)t * TB, (long long)lastpiece);
-                wave_lds_fence();
-                unsigned so[NI];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) so[j] = (unsigned)srel[j * 2 + dw];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) glds16(min(so[j] + (unsigned)dp * 16u, lastpiece), sbase, img_base + j * AIMG);
-                // knot rows complete in EVERY window after this trip: knot r ends at ph + 56 (r + 1) <= 512 (t + 1); the last trip takes the rest
-                const int rall = (t + 1 < ntrips) ? (int)(((long long)(t + 1) * TB - phmax) / 56) : mmax1;
-                wait_vmcnt<0>();
-                wave_lds_fence();
-                for (int r = rdone; r < rall; ++r) {
-                    const int so_ = ph + 56 * min(r, m) - t * TB;       // byte offset of knot r in this trip's piece: > -CARRY for every r <= m
-                    double v[7];
-#pragma unroll
-                    for (int k = 0; k < 7; k++) {
-                        const int o = so_ + 8 * k;
-                        const char *src = (o >= 0) ? mine + min(o, TB - 8) : mycarry + CARRY + max(o, -CARRY);
-                        v[k] = *reinterpret_cast<const double *>(src);
-                    }
-                    // the stream's last 8 bytes when K is odd: they lie in a 16-byte piece that ends behind the stream and was
-                    // never fetched
-                    if (r <= m && b0 + 56ll * r + 56 > (send & ~15ll)) v[6] = A.stream[(fp + r) * 7 + 6];
-                    if (r <= m && r <= rows) {
-                        tb[(long long)r * A.ss] = (r == 0) ? start_t : v[0];
-#pragma unroll
-                        for (int k = 1; k < 7; k++) tb[(long long)r * A.ss + k * 64] = v[k];
-                        if (r == m && tail && m + 1 <= rows) {          // the tail row: knot m's reading under the update time
-                            tb[(long long)(m + 1) * A.ss] = T;
-#pragma unroll
-                            for (int k = 1; k < 7; k++) tb[(long long)(m + 1) * A.ss + k * 64] = v[k];
-                        }
-                    }
-                }
-                rdone = max(rdone, rall);
-                // keep the last CARRY bytes of this piece: rows this window is ahead by, and the knot that straddles into the next piece
-#pragma unroll
-                for (int c = 0; c < CARRY; c += 16)
-                    *reinterpret_cast<double2 *>(mycarry + c) = *reinterpret_cast<const double2 *>(mine + TB - CARRY + c);
-                wave_lds_fence();
-            }
-            return;
-        }
-    }
-#endif
     const long long base = min(readfirstlane64(fp), A.K - RB);        // wave-uniform; the DMA offsets are relative to it
     const bool dma = __all((A.K >= RB) && (fp >= readfirstlane64(fp)) && (fp + (long long)m - base < (1ll << 24)));
     if (dma) {
