@@ -323,6 +323,47 @@ def test_gpu_stream_entry_never_reads_behind_the_last_reading(model):
 
 
 @pytest.mark.gpu
+def test_gpu_stream_entry_refuses_invalid_calls_before_enqueueing_anything():
+    """the entry used to launch the cut kernel -- which writes the caller's workspace -- before prm / out / lin,
+    the model, N and q_k_lin were validated.  An invalid call must return CPI_ERR_INVALID and leave the workspace untouched."""
+    import ctypes as C
+    import torch
+    import cpi_amd
+    from cpi_amd import _lib, synth
+    eng = cpi_amd.Engine()
+    lib = eng.lib
+    stream, upd, lin, q = synth.make_stream(64, 10, seed=3, device=eng.device, phase=0.3)
+    U, K = upd.shape[0], stream.shape[0]
+    out = eng.alloc_outputs(U, ("mean", "jac", "cov"), 2)
+    o = eng._outputs_struct(out)
+    ws = eng.stream_workspace(U)
+    ws.fill_(-7.0)
+    torch.cuda.synchronize()
+    good = eng.make_params(2)
+    bad_model = eng.make_params(2); bad_model.model = 9
+    bad_lanes = eng.make_params(1); bad_lanes.lanes_per_window = 7
+    P = lambda t: C.c_void_p(t.data_ptr())
+    calls = [
+        (None, 11, P(lin), P(q), C.byref(o)),                        # prm NULL
+        (C.byref(good), 11, P(lin), P(q), None),                     # out NULL
+        (C.byref(good), 11, None, P(q), C.byref(o)),                 # lin NULL
+        (C.byref(good), 11, P(lin), None, C.byref(o)),               # model 2 without q_k_lin
+        (C.byref(bad_model), 11, P(lin), P(q), C.byref(o)),          # unknown model
+        (C.byref(good), 70000, P(lin), P(q), C.byref(o)),            # N > 65535
+        (C.byref(bad_lanes), 11, P(lin), P(q), C.byref(o)),          # unsupported lane split
+    ]
+    for prm, N, l, qq, oo in calls:
+        rc = lib.cpi_preintegrate_stream(eng.ctx, prm, K, P(stream), U, P(upd), N, l, qq, P(ws), oo)
+        assert rc == _lib.CPI_ERR_INVALID, (rc, N)
+    torch.cuda.synchronize()
+    assert bool((ws == -7.0).all()), "an invalid call wrote the workspace"
+    rc = lib.cpi_preintegrate_stream(eng.ctx, C.byref(good), K, P(stream), U, P(upd), 11, P(lin), P(q), P(ws), C.byref(o))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert not bool((ws == -7.0).all())
+
+
+@pytest.mark.gpu
 def test_gpu_stream_entry_forster_and_many_windows():
     """The same entry for the Forster comparator, and on a synthetic stream cut into thousands of windows (every window ends
     in a partial tail interval; wavefronts of the covariance kernels mix windows of different lengths): bit for bit equal to
