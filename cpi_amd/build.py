@@ -218,11 +218,20 @@ def _build_locked(force, report, experiments, test_hooks):
     for variant, wanted in (("", True), ("exp", experiments), ("test", test_hooks)):
         if wanted and (force or stale(VARIANTS[variant][0], variant=variant)):
             todo.append(variant)
+    # every object of every wanted variant in ONE pool (the default build's four units + the units a variant compiles with its own
+    # define): __graft_entry__.build() rebuilds three libraries in the time of the slowest translation unit
+    jobs = {}
+    for variant in todo:
+        vunits = VARIANTS[variant][2]
+        for u in UNITS:
+            own = bool(variant) and u in vunits
+            jobs.setdefault((u, variant if own else ""), force and (not variant or own))
+    with ThreadPoolExecutor(min(len(jobs), os.cpu_count() or 4) or 1) as ex:
+        done = dict(zip(jobs, ex.map(lambda k: _compile(k[0], k[1], jobs[k]), jobs)))
     for variant in todo:
         lib, _, vunits, _ = VARIANTS[variant]
         exp = variant
-        with ThreadPoolExecutor(len(UNITS)) as ex:
-            res = list(ex.map(lambda u: _compile(u, variant, force and (not variant or u in vunits)), UNITS))
+        res = [done[(u, variant if (variant and u in vunits) else "")] for u in UNITS]
         _link(lib, [o for o, _ in res])
         with open(lib + ".id", "w") as f:
             f.write(source_id(variant=variant))
