@@ -323,6 +323,49 @@ def test_gpu_stream_entry_never_reads_behind_the_last_reading(model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("phase", [0.0, 0.4])
+def test_gpu_stream_entry_large_batches_take_the_three_knot_kernel_bitwise(phase):
+    """From 500 000 windows the mean-only stream entry of model 1 runs cpi_mean_kernel<..., BIG> (three knots per chunk, one
+    wavefront per SIMD; cpi_mean.hip).  Chunking does not touch the arithmetic: 600 000 windows x 12 intervals cut out of one
+    stream must equal, BIT FOR BIT, cpi_preintegrate_batch on the same windows laid out densely on the device (first knot under
+    the previous update time, the tail knot = the front reading under the update time), with and without tail intervals, both
+    imu_avg settings; a strided sample is held against the oracle.  (A request with Jacobians takes the workspace route and the
+    analytic-Jacobian kernel at the same size: its means are compared too.)"""
+    import torch
+    import cpi_amd
+    from cpi_amd import synth
+    eng = cpi_amd.Engine()
+    W, N = 600000, 12
+    stream, upd, lin, q = synth.make_stream(W, N, seed=77, device=eng.device, phase=phase)
+    K = stream.shape[0]
+    n = N + (1 if phase > 0 else 0)
+    # the windows, densely: window u = readings u N .. (u + 1) N (+ the tail knot); knot 0 carries the previous update time
+    idx = (torch.arange(W, device=eng.device) * N)[:, None] + torch.arange(N + 1, device=eng.device)[None, :]
+    dense = stream[idx]                                                     # [W, N + 1, 7]
+    prev = torch.cat([stream[:1, 0], upd[:-1]])
+    dense[:, 0, 0] = torch.maximum(prev, stream[0, 0])
+    if phase > 0:
+        tailk = dense[:, -1:, :].clone()
+        tailk[:, 0, 0] = upd
+        dense = torch.cat([dense, tailk], dim=1)
+    dense = dense.contiguous()
+    for avg in (False, True):
+        prm = eng.make_params(1, avg)
+        out, cnt = eng.preintegrate_stream(stream, upd, lin, q, prm, want=("mean",), N=n, return_counts=True)
+        ref = eng.preintegrate(dense, lin, q, eng.make_params(1, avg, lanes_per_window=1), want=("mean",))
+        full = eng.preintegrate_stream(stream, upd, lin, q, prm, want=("mean", "jac"), N=n)
+        torch.cuda.synchronize()
+        assert int(cnt.min()) == n and int(cnt.max()) == n
+        for k in ("DT", "alpha", "beta", "q"):
+            assert torch.equal(out[k], ref[k]), (phase, avg, k)
+            # (the analytic-Jacobian kernel forms R by a 3x3 product instead of rotating its columns: equal to rounding, not bitwise)
+            assert (full[k] - ref[k]).abs().max().item() < 1e-12, ("workspace route", phase, avg, k)
+    pick = torch.arange(0, W, 9973, device=eng.device)
+    o = op.oracle().run(op.make_params(1, 1, 1), dense[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
+    check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, o, what=("mean",), label="BIG stream kernel, phase %.1f" % phase)
+
+
+@pytest.mark.gpu
 def test_gpu_stream_entry_refuses_invalid_calls_before_enqueueing_anything():
     """the entry used to launch the cut kernel -- which writes the caller's workspace -- before prm / out / lin,
     the model, N and q_k_lin were validated.  An invalid call must return CPI_ERR_INVALID and leave the workspace untouched."""
