@@ -764,7 +764,10 @@ def main():
         # whole-job rate of the K steps alone: sum of units / MAX over ranks of the HIP-event time around the K steps -- the
         # collective tail of a 0.3 ms timed region is separable from the kernels this way
         res["config"]["value_kernel_only"] = total_units * a.steps / (kern_ms * 1e-3)
-        res["config"]["rccl"] = rccl_info(rehearsal, eng)
+        try:
+            res["config"]["rccl"] = rccl_info(rehearsal, eng)
+        except Exception as ex:      # an informational field must never cost the line
+            res["config"]["rccl"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "error": repr(ex)}
     if wall_ng is not None:
         res["config"]["value_without_gather"] = total_units * a.steps / wall_ng
         res["config"]["ms_final_gather"] = max(0.0, (wall - wall_ng) * 1e3)
@@ -842,35 +845,43 @@ def verify_gather(eng, wl, tm, world, rank, base_seed, rehearsal):
     if wl.kind != "pre":
         why = "not verified: only the dense-layout workloads regenerate another rank's batch"
     elif rank == 0:
-        g = tm.get("gathered")
-        b = tm["last_step"] % wl.nbatch
-        ok, maxdiff = g is not None, 0.0
-        parts = []
-        for r in range(world if g is not None else 0):
-            kn, lin, q = synth.make_windows(wl.W, wl.N, seed=base_seed(r) + 101 * b, device=eng.device)
-            out = eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
-            torch.cuda.synchronize()
-            for name, n in wl.outs[0]["_fields"]:
-                ok = ok and torch.equal(g[name][r].reshape(out[name].shape), out[name])
-            parts.append((kn, lin, q))
-            del out
-        if ok and world * wl.W * (wl.N + 1) * 56 <= (64 << 30):
-            kn = torch.cat([p[0] for p in parts]); lin = torch.cat([p[1] for p in parts]); q = torch.cat([p[2] for p in parts])
-            del parts
-            out = eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
-            torch.cuda.synchronize()
-            for name, n in wl.outs[0]["_fields"]:
-                got, ref = g[name].reshape(out[name].shape), out[name]
-                scale = ref.abs().amax().clamp_min(1.0) if name != "P" else ref.abs().amax().clamp_min(1e-300)
-                maxdiff = max(maxdiff, float(((got - ref).abs().amax() / scale).item()))
-            ok = ok and maxdiff <= 2e-13
+        try:
+            g = tm.get("gathered")
+            b = tm["last_step"] % wl.nbatch
+            ok, maxdiff = g is not None, 0.0
+            parts = []
+            for r in range(world if g is not None else 0):
+                kn, lin, q = synth.make_windows(wl.W, wl.N, seed=base_seed(r) + 101 * b, device=eng.device)
+                out = eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
+                torch.cuda.synchronize()
+                for name, n in wl.outs[0]["_fields"]:
+                    ok = ok and torch.equal(g[name][r].reshape(out[name].shape), out[name])
+                parts.append((kn, lin, q))
+                del out
+            if ok and world * wl.W * (wl.N + 1) * 56 <= (64 << 30):
+                kn = torch.cat([p[0] for p in parts]); lin = torch.cat([p[1] for p in parts]); q = torch.cat([p[2] for p in parts])
+                del parts
+                out = eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
+                torch.cuda.synchronize()
+                for name, n in wl.outs[0]["_fields"]:
+                    got, ref = g[name].reshape(out[name].shape), out[name]
+                    scale = ref.abs().amax().clamp_min(1.0) if name != "P" else ref.abs().amax().clamp_min(1e-300)
+                    maxdiff = max(maxdiff, float(((got - ref).abs().amax() / scale).item()))
+                ok = ok and maxdiff <= 2e-13
+        except Exception as ex:      # the verification must never cost the timing record (e.g. no memory for N regenerated batches)
+            ok, why = None, "not verified: %r" % (ex,)
+            torch.cuda.empty_cache()
     flag = torch.tensor([1.0 if ok else (0.0 if ok is not None else -1.0)], dtype=torch.float64, device="cpu" if rehearsal else eng.device)
     dist.broadcast(flag, src=0)
     if flag.item() == 0.0:
-        raise SystemExit("bench.py: the gathered outputs of the last timed step differ from rank 0's recomputation")
-    return {"gather_verified": (bool(ok) if ok is not None else None) if rank == 0 else None,
-            "gather_verified_how": why or "rank 0 recomputed every rank's last-step batch: gathered blocks bitwise equal; one unsharded "
-                                          "call over all %d x %d windows agrees to %.1e (relative; gate 2e-13)" % (world, wl.W, maxdiff or 0.0)}
+        # a mismatch is reported IN the line (gather_verified: false) so that the timing record survives; CPI_BENCH_STRICT=1 (the
+        # tests) turns it into a non-zero exit on every rank
+        sys.stderr.write("bench.py: the gathered outputs of the last timed step DIFFER from rank 0's recomputation\n")
+        if os.environ.get("CPI_BENCH_STRICT"):
+            raise SystemExit(3)
+    how = why or ("rank 0 recomputed every rank's last-step batch: gathered blocks %s; one unsharded call over all %d x %d windows "
+                  "agrees to %.1e (relative; gate 2e-13)" % ("bitwise equal" if ok else "DIFFER (or the unsharded call is off the gate)", world, wl.W, maxdiff or 0.0))
+    return {"gather_verified": (bool(ok) if ok is not None else None) if rank == 0 else None, "gather_verified_how": how}
 
 
 def emit(res, extra):

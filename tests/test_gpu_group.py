@@ -225,6 +225,7 @@ def test_bench_gpus_2_end_to_end_rehearsal_on_one_gpu():
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env["CPI_BENCH_SINGLE_DEVICE"] = "1"
+    env["CPI_BENCH_STRICT"] = "1"
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     for extra in ([], ["--workload", "v2_full", "--windows", "20000", "--scaling", "strong"]):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extra",

@@ -25,6 +25,7 @@ def _env():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CPI_BENCH_SINGLE_DEVICE", "CPI_AMD_RCCL_LIB", "CPI_AMD_LIB", "CPI_BENCH_FORCE_DIST"):
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["CPI_BENCH_STRICT"] = "1"          # a gathered block that differs from rank 0's recomputation is a failure, not a field
     return env
 
 
