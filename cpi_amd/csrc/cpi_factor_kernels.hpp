@@ -18,6 +18,15 @@ __device__ __forceinline__ NavState ld_state(const double *p) {
 // One SoA input field (K doubles per factor) of the FPW consecutive factors of a wavefront: FPW*K contiguous
 // doubles, lane i takes doubles i, i + 64, ...  load() is unconditional (index clamped to the last valid double),
 // store() writes record-major into the LDS staging area.
+// 16 bytes at an 8-byte aligned address with the non-temporal hint: the sweeps' outputs are written once and read by a later
+// kernel (the solver), never by this one.  Round 4, same-box A/B per 1 M factors: square-root information 709-716 -> 674-680 us,
+// Hessian blocks 1414 -> 1388 us (v2 1490 -> 1470), dense H1 / H2 793-804 -> 771-775 us on one box and unchanged on another,
+// whitened 1271 -> 1250 us; the same hint on the record LOADS is neutral (packed sweep -2 %, dense + 0-1 %): not used.
+typedef double cpi_d2v __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void st16_nt(double *dst2, double a, double b) {
+    cpi_d2v v; v.x = a; v.y = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<cpi_d2v *>(dst2));
+}
 template <int FPW, int K>
 struct FieldFetch {
     static constexpr int R = (FPW * K + 63) / 64;
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     struct __attribute__((packed, aligned(8))) d2u { double a, b; };
     auto flush = [&](double *dst, const double *src, int n) {
         const int n2 = n >> 1;
-        for (int i = lane; i < n2; i += 64) { d2u v; v.a = src[2 * i]; v.b = src[2 * i + 1]; ((d2u *)dst)[i] = v; }
+        for (int i = lane; i < n2; i += 64) st16_nt(dst + 2 * i, src[2 * i], src[2 * i + 1]);
         if ((n & 1) && lane == 0) dst[n - 1] = src[n - 1];
     };
     const Q4 qi = ldq(m.xi);
@@ -411,8 +420,7 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
     wave_lds_fence();
     {
         const int n2 = (nf * 225) >> 1;
-        d2u *dst = reinterpret_cast<d2u *>(Rout + f0 * 225);
-        for (int i = lane; i < n2; i += 64) { d2u v; v.a = sA[2 * i]; v.b = sA[2 * i + 1]; dst[i] = v; }
+        for (int i = lane; i < n2; i += 64) st16_nt(Rout + f0 * 225 + 2 * i, sA[2 * i], sA[2 * i + 1]);
         if (((nf * 225) & 1) && lane == 0) Rout[f0 * 225 + nf * 225 - 1] = sA[nf * 225 - 1];
     }
 }
@@ -637,11 +645,8 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
         *((q == 15) ? st + pk(30, 30) : trash) = fq;
     }
     wave_lds_fence();
-    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
-    d2u *dst = reinterpret_cast<d2u *>(hess + f0 * HESS_PACKED);
     for (int idx = lane; idx < nf * (HESS_PACKED / 2); idx += 64) {
-        d2u v; v.a = sAll[2 * idx]; v.b = sAll[2 * idx + 1];
-        dst[idx] = v;
+        st16_nt(hess + f0 * HESS_PACKED + 2 * idx, sAll[2 * idx], sAll[2 * idx + 1]);
     }
 }
 

@@ -391,6 +391,7 @@ __global__ __launch_bounds__(64, BIG ? 1 : (((MODEL == 2 && !JAC) || (MODEL == 1
 #ifndef CPI_TILED_BUFS
 #define CPI_TILED_BUFS 5
 #endif
+
 // SPLIT (small batches: fewer tiles than the chip has SIMDs): a workgroup of S = blockDim.x / 64 wavefronts owns the
 // tile; wavefront j integrates the steps [j per, (j + 1) per) of all 64 windows from the identity (model 2: from the raw
 // specific force, with the segment's gravity response -- cpi_math.hpp mean_step_v2seg), parks its segment in LDS, and
@@ -418,8 +419,11 @@ __global__ __launch_bounds__(SPLIT ? 512 : 64, SPLIT ? 1 : CPI_TILED_OCC) void c
         // COUNTED: past its own last knot a lane re-reads that knot (dt = 0) -- what lies behind it in the column is
         // never read.  Otherwise the row offset is wave-uniform (scalar address arithmetic).
         const double *p = tb + (long long)(COUNTED ? min(s, n) : min(s, A.N)) * A.ss;
+        // non-temporal: every byte of a tile is read exactly once, by one wavefront (round 4, same-box A/B: 1 M x 50 582-588 ->
+        // 565-569 us, model 2 561-576 -> 540 us, 100 k 60.5 -> 56 us; the same hint on the dense layout's staged loads, whose
+        // 128-byte lines ARE touched again by the next chunk, costs 35 %: 619 -> 840-874 us)
 #pragma unroll
-        for (int f = 0; f < 7; f++) k[f] = p[f * 64];
+        for (int f = 0; f < 7; f++) k[f] = __builtin_nontemporal_load(p + f * 64);
     };
     MeanState<false> st;
     mean_init(st);
@@ -685,8 +689,10 @@ __global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) 
                 if (r == 0) v[0] = start_t;
                 if (tail && r == m + 1) v[0] = T;
                 if (r <= rows) {
+                    // non-temporal row stores: 1.17-1.21 -> 1.13 ms per 1 M x 50 (the same hint on the LDS-DMA reads, whose pieces
+                    // share lines with the next trip: 1.20 -> 1.35 ms)
 #pragma unroll
-                    for (int k = 0; k < 7; k++) tb[(long long)r * A.ss + k * 64] = v[k];
+                    for (int k = 0; k < 7; k++) __builtin_nontemporal_store(v[k], tb + (long long)r * A.ss + k * 64);
                 }
             }
         }
