@@ -21,7 +21,8 @@ __device__ __forceinline__ NavState ld_state(const double *p) {
 // 16 bytes at an 8-byte aligned address with the non-temporal hint: the sweeps' outputs are written once and read by a later
 // kernel (the solver), never by this one.  Round 4, same-box A/B per 1 M factors: square-root information 709-716 -> 674-680 us,
 // Hessian blocks 1414 -> 1388 us (v2 1490 -> 1470), dense H1 / H2 793-804 -> 771-775 us on one box and unchanged on another,
-// whitened 1271 -> 1250 us; the same hint on the record LOADS is neutral (packed sweep -2 %, dense + 0-1 %): not used.
+// whitened 1271 -> 1250 us, packed sweep 292 -> 280 us (v2 327 -> 318); the same hint on the LOADS -- the records, R of the whitened /
+// Hessian sweeps, P of the square-root information -- is neutral (within +-1 %): not used.
 typedef double cpi_d2v __attribute__((ext_vector_type(2), aligned(8)));
 __device__ __forceinline__ void st16_nt(double *dst2, double a, double b) {
     cpi_d2v v; v.x = a; v.y = b;
@@ -331,9 +332,7 @@ __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, dou
     }
     if (q == LPF - 1) { out[69] = 0.0; out[70] = 0.0; out[71] = 0.0; }
     wave_lds_fence();
-    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
-    d2u *dst = reinterpret_cast<d2u *>(packed + f0 * PD);
-    for (int i = lane; i < nf * (PD / 2); i += 64) { d2u v; v.a = sP[2 * i]; v.b = sP[2 * i + 1]; dst[i] = v; }
+    for (int i = lane; i < nf * (PD / 2); i += 64) st16_nt(packed + f0 * PD + 2 * i, sP[2 * i], sP[2 * i + 1]);
 }
 
 // R = chol_upper(P^-1) = B^-1 with P = B B^T, B upper triangular ("reverse" Cholesky, from the last pivot up).
