@@ -1,5 +1,10 @@
 #!/bin/bash
-# A/B of the non-temporal hint, second set: loads of R in the whitened (1) / Hessian (2) sweeps, of P in sqrt-information (4), packed stores (8)
+# Same-box A/B of --custom variant libraries (python -m cpi_amd.build --custom <tag> -D...) on microbench rows, two alternating rounds:
+#   bash tools/exp/nt_ab.sh "<tag> <tag> ..." "<row> <row> ..."      ("" = the default library)
+# e.g. the round-4 non-temporal hints (profiles/r04_nt_hints.md):
+#   bash tools/exp/nt_ab.sh "'' ntl8" "factor_v1_packed:1000000:0 factor_v2_packed:1000000:0"
 cd ${GRAFT_REPO_ROOT:-.}
-mb() { CPI_AMD_LIB=$PWD/cpi_amd/libcpi_amd$1.so python tools/microbench.py "${@:2}" 2>&1 | grep "launch_us"; }
-for v in "" _ntl1 _ntl2 _ntl4 _ntl8 _ntl15 "" _ntl1 _ntl2 _ntl4 _ntl8 _ntl15; do mb "$v" factor_v1_whitened:1000000:0 factor_v1_hessian:1000000:0 sqrt_info:1000000:0 factor_v1_packed:1000000:0 factor_v2_packed:1000000:0; done
+TAGS=${1:-"''"}
+ROWS=${2:-"v1_mean:1000000:0"}
+mb() { local lib=cpi_amd/libcpi_amd${1:+_$1}.so; echo "== $lib"; CPI_AMD_LIB=$PWD/$lib python tools/microbench.py $ROWS 2>&1 | grep "launch_us"; }
+for round in 1 2; do for t in $TAGS; do [ "$t" = "''" ] && t=""; mb "$t"; done; done
