@@ -26,24 +26,38 @@ bool mean_lanes_supported(int L) {
     return false;
 }
 
-// Stream entry, model 1, one lane per window, mean-only: from this many windows the three-knots-per-chunk instantiation
-// (cpi_mean_kernel<..., BIG>) is used.  It runs ONE wavefront per SIMD, which pays only when the batch fills the chip many times
-// over.  Measured (profiles/r04_mean_chunk_ab.md, same box, alternating): the 1 M x 51 stream 680-700 -> 664-670 us with HBM
-// traffic 1.42 x -> 1.11 x algorithmic; the DENSE layout gains the same traffic (1.26 x -> 1.08 x) but not time (one box 670 ->
-// 650 us, another 612-635 -> 640-647 us; 100 k - 700 k windows lose 2-9 %) and model 2 loses 5 % -- both keep two knots per chunk.
+// One lane per window, mean-only: from this many windows the three-knots-per-chunk instantiation (cpi_mean_kernel<..., BIG>:
+// 32-bit staging offsets from a wave-uniform base, flat LDS tile, two wavefronts per SIMD at ~200 registers) replaces the
+// two-knot one -- stream entry, dense layout (CPI_MEAN_BIG_W_DENSE) and model 2 (CPI_MEAN_BIG_W_M2) alike.  Admission rule of
+// the 32-bit offsets: every lane-segment of a wavefront within 2^32 bytes above the wavefront's lowest -- any 64 stream windows
+// of a stream of < 2^26 readings, any 64 consecutive windows of the dense layout (N <= 65 535); a CSR `first` array (arbitrary
+// addresses) and per-window counts keep the two-knot kernel.
+// Measured on one box, alternating (profiles/r04_mean_chunk_ab.md, part D): 1 M x 50 dense 644-648 -> 629-630 us, 1 M x 100
+// 1 230 -> 1 210-1 219, the 1 M x 51 stream 668-671 -> 655-658 (jittered update times, every wavefront on the per-element path:
+// 772 -> 718), model 2 671-673 -> 661-663; 65 k - 500 k windows equal within the noise (with a fifth less HBM traffic), 40 k
+// windows 1-3 % slower -- hence the threshold.
 #ifndef CPI_MEAN_BIG_W
-#define CPI_MEAN_BIG_W 500000
+#define CPI_MEAN_BIG_W 100000
+#endif
+#ifndef CPI_MEAN_BIG_W_DENSE
+#define CPI_MEAN_BIG_W_DENSE 100000
+#endif
+#ifndef CPI_MEAN_BIG_W_M2
+#define CPI_MEAN_BIG_W_M2 100000
 #endif
 template <int MODEL, bool JAC, bool AVG>
 static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
     // 0: plain knots; 1: windows cut by cpi_cut_windows_kernel (workspace route); 2: the wavefront cuts its own windows
     // (mean-only requests of cpi_preintegrate_stream; no analytic-Jacobian instantiations -- the caller never asks)
     const int cut = a.update != nullptr ? 2 : (a.tstart != nullptr ? 1 : 0);
-    if constexpr (!JAC && MODEL == 1) {
-        if (L == 1 && cut != 0 && a.W >= (long long)CPI_MEAN_BIG_W) {
+    if constexpr (!JAC) {
+        const long long wmin = MODEL == 2 ? (long long)CPI_MEAN_BIG_W_M2 : (cut != 0 ? (long long)CPI_MEAN_BIG_W : (long long)CPI_MEAN_BIG_W_DENSE);
+        const bool admitted = cut != 0 ? (a.K > 0 && a.K < (1ll << 26)) : (a.first == nullptr && a.count == nullptr);
+        if (L == 1 && admitted && a.W >= wmin) {
             const unsigned nb = (unsigned)((a.W + 63) / 64);
             if (cut == 2) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 2, true>), dim3(nb), dim3(64), 0, st, a);
-            else hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 1, true>), dim3(nb), dim3(64), 0, st, a);
+            else if (cut == 1) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 1, true>), dim3(nb), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 0, true>), dim3(nb), dim3(64), 0, st, a);
             return;
         }
     }

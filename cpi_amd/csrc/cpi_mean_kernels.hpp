@@ -73,12 +73,17 @@ __device__ __forceinline__ long long knots_not_after_near(const double *stream, 
 // search probes land on the lines the window reads anyway).
 // BIG (one lane per window, mean-only, batches that fill the chip many times over): THREE knots per chunk instead of two.  The
 // longer pieces (168 B) re-touch fewer 128-byte lines -- HBM traffic of a 1 M-window launch 1.26 x -> 1.08 x algorithmic on the
-// dense layout, 1.42 x -> 1.11 x on the stream entry (FETCH_SIZE, rocprofv3) -- at the price of the second wavefront per SIMD
-// (266 registers).  Used for the stream entry only (cpi_mean.hip: launch_mean_L says why); 5 knots per chunk and 3 knots held to
-// two wavefronts per SIMD (40 B of scratch) are slower than either (profiles/r04_mean_chunk_ab.md).
+// dense layout, 1.42 x -> 1.11 x on the stream entry (FETCH_SIZE, rocprofv3).  21 staged doubles per lane do not fit beside
+// round 3's per-element bookkeeping (a 64-bit pointer, a 32-bit fast-path offset, the last valid chunk and the LDS slot per
+// element: 266 registers, one wavefront per SIMD -- which gave the traffic but not the time, profiles/r04_mean_chunk_ab.md), so
+// BIG keeps ONE 32-bit byte offset per element, relative to the wavefront's lowest knot (a wave-uniform base in SGPRs), for the
+// fast path (constant) and the per-element path (advanced per chunk) alike, and its LDS tile is flat (pitch 21 doubles: element
+// e of lane i sits at 64 e + i, an immediate offset) -- two wavefronts per SIMD again.  The launcher admits BIG only where every
+// lane-segment of a wavefront lies within 2^32 bytes above the lowest one: stream windows of a stream of < 2^26 readings, or
+// the dense layout (cpi_mean.hip: launch_mean_L).  5 knots per chunk are slower.
 template <int MODEL, bool JAC, bool AVG, int L, int CUT, bool BIG = false>
-__global__ __launch_bounds__(64, BIG ? 1 : (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) && L == 1 ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
-    static_assert(!BIG || (L == 1 && !JAC && MODEL == 1 && CUT != 0), "BIG: stream entry, model 1, one lane per window, mean-only");
+__global__ __launch_bounds__(64, BIG ? 2 : (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) && L == 1 ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
+    static_assert(!BIG || (L == 1 && !JAC), "BIG: one lane per window, mean-only");
     constexpr int WPB = 64 / L;       // windows per wavefront
     // knots staged per lane per chunk: measured on MI355X -- 2 when a lane has several intervals (L <= 8; 20 k x 50 with
     // L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us, 15 k with L = 4: 16.0 -> 15.3 us, 10 k with L = 6:
@@ -211,21 +216,28 @@ __global__ __launch_bounds__(64, BIG ? 1 : (((MODEL == 2 && !JAC) || (MODEL == 1
     // which its knot exists (later chunks re-read that knot; the value is never consumed), so the hot loop
     // spends ~3 VALU per element on addressing and no load is ever out of bounds.
     double stage[SEGD];
-    const double *sptr[SEGD];
-    unsigned voff[SEGD];   // byte offset of the element from the block's first knot (dense layouts)
+    const double *sptr[SEGD];   // !BIG
+    unsigned voff[SEGD];   // byte offset of the element from blk0: the fast path's constant (dense layouts, uniform streams); BIG: of both paths
     int smax[SEGD];
-    int tofs[SEGD];
+    int tofs[SEGD];             // !BIG (BIG: the tile is flat, element e of lane i at 64 e + i)
     const double *blk0 = A.knots + (long long)blockIdx.x * WPB * (long long)(A.N + 1) * 7;   // wave-uniform (dense layout)
     bool fast_stream = false;
+    const long long b = k0 + sb;
+    long long b0 = 0;
+    if constexpr (BIG) {
+        // the wavefront's lowest first knot (stream windows out of time order may start below lane 0's)
+        const long long bf = readfirstlane64(b);
+        b0 = bf - (long long)wave_max((int)min(max(bf - b, 0ll), 0x7fffffffll));
+        blk0 = A.knots + b0 * 7;
+    }
     if constexpr (cut) {
         // The stream entry's twin of the dense layout's fast path below: "wave-uniform base + chunk stride in SGPRs + constant
         // 32-bit lane offsets" is valid for a stream whenever (a) every lane-segment of the wavefront has the same length --
         // then no lane ever CONSUMES a knot behind its own segment (the padded step of an odd last chunk is skipped, a tail
         // knot is replaced by a select), so reading on is harmless whatever those knots hold --, (b) the segments lie within
         // 2^30 bytes above the first one and (c) the furthest read stays inside the stream (PreArgs::K).  A uniform update
-        // grid satisfies all three for every wavefront but the last; ragged wavefronts keep the per-element pointers.
-        const long long b = k0 + sb;
-        const long long b0 = readfirstlane64(b);
+        // grid satisfies all three for every wavefront but the last; ragged wavefronts keep the per-element path.
+        if constexpr (!BIG) b0 = readfirstlane64(b);
         const int nch = (maxlen + C - 1) / C;
         const bool ok = (A.K > 0) && (len == maxlen) && (b >= b0) && (b - b0 < (1ll << 24)) && (b + (long long)nch * C <= A.K - 1);
         fast_stream = __all(ok);
@@ -243,10 +255,14 @@ __global__ __launch_bounds__(64, BIG ? 1 : (((MODEL == 2 && !JAC) || (MODEL == 1
             const int slen = (int)(d & 0xffffULL);
             const int kn = off / 7;                       // knot (1 + kn) of chunk 0
             const bool ok = slen >= 1 + kn;
-            sptr[e] = A.knots + base + (ok ? 7 + off : off - 7 * kn);
-            voff[e] = (unsigned)((sptr[e] - blk0) * 8);   // only used when safe_overread (then 0 <= offset < 2^32)
+            if constexpr (BIG) {
+                voff[e] = (unsigned)((base - b0 * 7 + (ok ? 7 + off : off - 7 * kn)) * 8);   // < 2^32: the launcher's admission rule
+            } else {
+                sptr[e] = A.knots + base + (ok ? 7 + off : off - 7 * kn);
+                voff[e] = (unsigned)((sptr[e] - blk0) * 8);   // only used when safe_overread (then 0 <= offset < 2^32)
+                tofs[e] = seg * PITCH + off;
+            }
             smax[e] = ok ? (slen - 1 - kn) / C : 0;       // never-valid elements keep re-reading knot 0
-            tofs[e] = seg * PITCH + off;
             off += 64 % SEGD; seg += 64 / SEGD;   // idx advances by 64 per staged element
             if (off >= SEGD) { off -= SEGD; seg += 1; }
         }
@@ -267,6 +283,14 @@ __global__ __launch_bounds__(64, BIG ? 1 : (((MODEL == 2 && !JAC) || (MODEL == 1
                 asm volatile("" : "+v"(voff[e]));   // keeps the zero-extension next to the load: `global_load v, v_off32, s[base]`
                 stage[e] = *reinterpret_cast<const double *>(cb + voff[e]);
             }
+        } else if constexpr (BIG) {
+            const char *cb = reinterpret_cast<const char *>(blk0);
+#pragma unroll
+            for (int e = 0; e < SEGD; ++e) {
+                asm volatile("" : "+v"(voff[e]));
+                stage[e] = *reinterpret_cast<const double *>(cb + voff[e]);
+                voff[e] += (it < smax[e]) ? (unsigned)(SEGD * 8) : 0u;
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < SEGD; ++e) { stage[e] = *sptr[e]; sptr[e] += (it < smax[e]) ? SEGD : 0; }
@@ -274,7 +298,9 @@ __global__ __launch_bounds__(64, BIG ? 1 : (((MODEL == 2 && !JAC) || (MODEL == 1
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int e = 0; e < SEGD; ++e) tile[tofs[e]] = stage[e];
+        for (int e = 0; e < SEGD; ++e) {
+            if constexpr (BIG) tile[e * 64 + lane] = stage[e]; else tile[tofs[e]] = stage[e];
+        }
     };
 
     // One chunk ahead: the HBM round trip of chunk it+1 overlaps the FP64 work of chunk it.  Measured alternatives:

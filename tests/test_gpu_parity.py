@@ -134,6 +134,29 @@ def test_window_of_100_samples(eng, orc):
         check_pre(_run(eng, mode, kn, lin, q), ref, v2=(mode[0] == 2), regression=from_ref)
 
 
+@pytest.mark.parametrize("model", [1, 2])
+@pytest.mark.parametrize("W,N", [(100003, 50), (130001, 7), (100000, 100)])
+def test_three_knot_kernel_on_the_dense_layout_bitwise_vs_two_knot_and_vs_reference(eng, orc, model, W, N):
+    """From 100 000 windows a one-lane mean-only launch on the dense layout runs cpi_mean_kernel<..., BIG> (three knots per
+    chunk, 32-bit staging offsets from the wavefront's lowest knot, flat LDS tile; cpi_mean.hip), unless per-window counts are
+    given.  Chunking does not touch the arithmetic: BIT FOR BIT the two-knot kernel's outputs (same batch with counts, all
+    full), for a batch whose last block is ragged (W = 64 k + 3: clamped idle lanes, the per-element path of the last two
+    blocks), for N not a multiple of three (padded steps of the last chunk) and N = 100; a strided sample against the
+    compiled reference (CpiV1.h:67-154 / CpiV2.h:88-205) at the regression gates."""
+    kn, lin, q = synth.make_windows(W, N, seed=4100 + N + model, device=eng.device)
+    for avg in (0, 1):
+        prm = eng.make_params(model, avg, lanes_per_window=1)
+        a = eng.preintegrate(kn, lin, q, prm, want=("mean",))
+        b = eng.preintegrate(kn, lin, q, prm, want=("mean",), count=torch.full((W,), N, dtype=torch.int32, device=eng.device))
+        torch.cuda.synchronize()
+        for k in ("DT", "alpha", "beta", "q"):
+            assert torch.equal(a[k], b[k]), (model, avg, W, N, k)
+        pick = torch.cat([torch.arange(0, W, 1013, device=eng.device), torch.arange(W - 70, W, device=eng.device)])
+        ref, from_ref = _cpu(orc, (model, avg, 1), kn[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
+        check_pre({k: v[pick].cpu().numpy() for k, v in a.items()}, ref, what=("mean",), v2=(model == 2),
+                  label="three-knot dense kernel m%d avg%d W=%d N=%d" % (model, avg, W, N), regression=from_ref)
+
+
 # --------------------------------------------------------------------------- ragged / shared-knot windows
 def test_ragged_windows_cut_from_one_stream(eng, orc):
     """Windows cut from ONE IMU stream at irregular update times (GraphSolver_IMU.cpp:50-69):

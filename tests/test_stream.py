@@ -325,12 +325,14 @@ def test_gpu_stream_entry_never_reads_behind_the_last_reading(model):
 @pytest.mark.gpu
 @pytest.mark.parametrize("phase", [0.0, 0.4])
 def test_gpu_stream_entry_large_batches_take_the_three_knot_kernel_bitwise(phase):
-    """From 500 000 windows the mean-only stream entry of model 1 runs cpi_mean_kernel<..., BIG> (three knots per chunk, one
-    wavefront per SIMD; cpi_mean.hip).  Chunking does not touch the arithmetic: 600 000 windows x 12 intervals cut out of one
-    stream must equal, BIT FOR BIT, cpi_preintegrate_batch on the same windows laid out densely on the device (first knot under
-    the previous update time, the tail knot = the front reading under the update time), with and without tail intervals, both
-    imu_avg settings; a strided sample is held against the oracle.  (A request with Jacobians takes the workspace route and the
-    analytic-Jacobian kernel at the same size: its means are compared too.)"""
+    """From 100 000 windows every one-lane mean-only launch -- stream entry and dense layout -- runs cpi_mean_kernel<..., BIG>
+    (three knots per chunk, 32-bit staging offsets from a wave-uniform base; cpi_mean.hip), except dense batches with per-window
+    counts, which keep the two-knot kernel.  Chunking does not touch the arithmetic: 600 000 windows x 12 intervals cut out of
+    one stream must equal, BIT FOR BIT, cpi_preintegrate_batch on the same windows laid out densely on the device (first knot
+    under the previous update time, the tail knot = the front reading under the update time) -- through the three-knot kernel
+    (no counts) AND through the two-knot kernel (counts given, all full) --, with and without tail intervals, both imu_avg
+    settings, models 1 and 2; a strided sample is held against the oracle.  (A request with Jacobians takes the workspace route
+    and the analytic-Jacobian kernel at the same size: its means are compared too.)"""
     import torch
     import cpi_amd
     from cpi_amd import synth
@@ -349,17 +351,26 @@ def test_gpu_stream_entry_large_batches_take_the_three_knot_kernel_bitwise(phase
         tailk[:, 0, 0] = upd
         dense = torch.cat([dense, tailk], dim=1)
     dense = dense.contiguous()
-    for avg in (False, True):
-        prm = eng.make_params(1, avg)
-        out, cnt = eng.preintegrate_stream(stream, upd, lin, q, prm, want=("mean",), N=n, return_counts=True)
-        ref = eng.preintegrate(dense, lin, q, eng.make_params(1, avg, lanes_per_window=1), want=("mean",))
-        full = eng.preintegrate_stream(stream, upd, lin, q, prm, want=("mean", "jac"), N=n)
+    full_counts = torch.full((W,), n, dtype=torch.int32, device=eng.device)
+    for model, avg in ((1, False), (1, True), (2, False), (2, True)):
+        prm = eng.make_params(model, avg)
+        out_m, cnt = eng.preintegrate_stream(stream, upd, lin, q, prm, want=("mean",), N=n, return_counts=True)
+        one = eng.make_params(model, avg, lanes_per_window=1)
+        ref = eng.preintegrate(dense, lin, q, one, want=("mean",))
+        ref2 = eng.preintegrate(dense, lin, q, one, want=("mean",), count=full_counts)
         torch.cuda.synchronize()
         assert int(cnt.min()) == n and int(cnt.max()) == n
         for k in ("DT", "alpha", "beta", "q"):
-            assert torch.equal(out[k], ref[k]), (phase, avg, k)
-            # (the analytic-Jacobian kernel forms R by a 3x3 product instead of rotating its columns: equal to rounding, not bitwise)
-            assert (full[k] - ref[k]).abs().max().item() < 1e-12, ("workspace route", phase, avg, k)
+            assert torch.equal(out_m[k], ref[k]), (phase, model, avg, k)
+            assert torch.equal(ref[k], ref2[k]), ("three knots per chunk vs two", phase, model, avg, k)
+        if model == 1:
+            full = eng.preintegrate_stream(stream, upd, lin, q, prm, want=("mean", "jac"), N=n)
+            torch.cuda.synchronize()
+            for k in ("DT", "alpha", "beta", "q"):
+                # (the analytic-Jacobian kernel forms R by a 3x3 product instead of rotating its columns: equal to rounding, not bitwise)
+                assert (full[k] - ref[k]).abs().max().item() < 1e-12, ("workspace route", phase, avg, k)
+            if avg:
+                out = out_m
     pick = torch.arange(0, W, 9973, device=eng.device)
     o = op.oracle().run(op.make_params(1, 1, 1), dense[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
     check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, o, what=("mean",), label="BIG stream kernel, phase %.1f" % phase)
