@@ -28,22 +28,29 @@ bool mean_lanes_supported(int L) {
 
 // One lane per window, mean-only: from this many windows the three-knots-per-chunk instantiation (cpi_mean_kernel<..., BIG>:
 // 32-bit staging offsets from a wave-uniform base, flat LDS tile, two wavefronts per SIMD at ~200 registers) replaces the
-// two-knot one -- stream entry, dense layout (CPI_MEAN_BIG_W_DENSE) and model 2 (CPI_MEAN_BIG_W_M2) alike.  Admission rule of
-// the 32-bit offsets: every lane-segment of a wavefront within 2^32 bytes above the wavefront's lowest -- any 64 stream windows
-// of a stream of < 2^26 readings, any 64 consecutive windows of the dense layout (N <= 65 535); a CSR `first` array (arbitrary
-// addresses) and per-window counts keep the two-knot kernel.
-// Measured on one box, alternating (profiles/r04_mean_chunk_ab.md, part D): 1 M x 50 dense 644-648 -> 629-630 us, 1 M x 100
-// 1 230 -> 1 210-1 219, the 1 M x 51 stream 668-671 -> 655-658 (jittered update times, every wavefront on the per-element path:
-// 772 -> 718), model 2 671-673 -> 661-663; 65 k - 500 k windows equal within the noise (with a fifth less HBM traffic), 40 k
-// windows 1-3 % slower -- hence the threshold.
+// two-knot one.  Admission rule of the 32-bit offsets: every lane-segment of a wavefront within 2^32 bytes above the wavefront's
+// lowest -- any 64 stream windows of a stream of < 2^26 readings, any 64 consecutive windows of the dense layout (N <= 65 535);
+// a CSR `first` array (arbitrary addresses) and per-window counts keep the two-knot kernel.
+// Measured on one box, alternating (profiles/r04_mean_chunk_ab.md, part D): the stream entry gains from 65 k windows (100 k:
+// 74-76 -> 72-73 us, 1 M x 51: 668-671 -> 655-658; jittered update times, every wavefront on the per-element path: 772 -> 718);
+// the dense layout at 1 M x 50 644-648 -> 629-630 us (1 M x 100: 1 230 -> 1 210-1 219), model 2 671-673 -> 661-663, both EQUAL
+// within the noise from 65 k to 500 k windows -- hence the three thresholds.  What it does NOT buy at two wavefronts per SIMD is
+// HBM traffic: FETCH_SIZE of the 1 M launches is 1.37 x (dense) / 1.48 x (stream) algorithmic at 8 wavefronts per CU, 1.14 /
+// 1.17 x at 6, 1.10 / 1.12 x at 4-5 -- the lines a chunk leaves half-read survive in the L2 only while few wavefronts stream
+// through it -- and the time goes the other way (dense 628 / 656 / 694 us, stream 673 / 685 / 714 us at 8 / 6 / 4 per CU).
+// CPI_MEAN_BIG_LDS_PAD (bytes of unused dynamic LDS per wavefront: 16 000 = 6 per CU, 29 000 = 4) is that knob; shipped: 0,
+// the fastest point.
 #ifndef CPI_MEAN_BIG_W
 #define CPI_MEAN_BIG_W 100000
 #endif
 #ifndef CPI_MEAN_BIG_W_DENSE
-#define CPI_MEAN_BIG_W_DENSE 100000
+#define CPI_MEAN_BIG_W_DENSE 700000
 #endif
 #ifndef CPI_MEAN_BIG_W_M2
-#define CPI_MEAN_BIG_W_M2 100000
+#define CPI_MEAN_BIG_W_M2 700000
+#endif
+#ifndef CPI_MEAN_BIG_LDS_PAD
+#define CPI_MEAN_BIG_LDS_PAD 0
 #endif
 template <int MODEL, bool JAC, bool AVG>
 static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
@@ -55,9 +62,10 @@ static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
         const bool admitted = cut != 0 ? (a.K > 0 && a.K < (1ll << 26)) : (a.first == nullptr && a.count == nullptr);
         if (L == 1 && admitted && a.W >= wmin) {
             const unsigned nb = (unsigned)((a.W + 63) / 64);
-            if (cut == 2) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 2, true>), dim3(nb), dim3(64), 0, st, a);
-            else if (cut == 1) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 1, true>), dim3(nb), dim3(64), 0, st, a);
-            else hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 0, true>), dim3(nb), dim3(64), 0, st, a);
+            const size_t pad = CPI_MEAN_BIG_LDS_PAD;   // unused dynamic LDS: caps the wavefronts per CU (see above)
+            if (cut == 2) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 2, true>), dim3(nb), dim3(64), pad, st, a);
+            else if (cut == 1) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 1, true>), dim3(nb), dim3(64), pad, st, a);
+            else hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 0, true>), dim3(nb), dim3(64), pad, st, a);
             return;
         }
     }

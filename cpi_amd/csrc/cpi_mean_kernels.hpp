@@ -74,16 +74,17 @@ __device__ __forceinline__ long long knots_not_after_near(const double *stream, 
 // tend: the workspace route, shared with the covariance kernels); 2: FUSED -- the wavefront cuts its own windows in its
 // prologue from PreArgs::update (mean-only requests: no cut kernel, no 56 bytes of workspace traffic per window, and the
 // search probes land on the lines the window reads anyway).
-// BIG (one lane per window, mean-only, batches that fill the chip many times over): THREE knots per chunk instead of two.  The
-// longer pieces (168 B) re-touch fewer 128-byte lines -- HBM traffic of a 1 M-window launch 1.26 x -> 1.08 x algorithmic on the
-// dense layout, 1.42 x -> 1.11 x on the stream entry (FETCH_SIZE, rocprofv3).  21 staged doubles per lane do not fit beside
-// round 3's per-element bookkeeping (a 64-bit pointer, a 32-bit fast-path offset, the last valid chunk and the LDS slot per
-// element: 266 registers, one wavefront per SIMD -- which gave the traffic but not the time, profiles/r04_mean_chunk_ab.md), so
-// BIG keeps ONE 32-bit byte offset per element, relative to the wavefront's lowest knot (a wave-uniform base in SGPRs), for the
-// fast path (constant) and the per-element path (advanced per chunk) alike, and its LDS tile is flat (pitch 21 doubles: element
-// e of lane i sits at 64 e + i, an immediate offset) -- two wavefronts per SIMD again.  The launcher admits BIG only where every
-// lane-segment of a wavefront lies within 2^32 bytes above the lowest one: stream windows of a stream of < 2^26 readings, or
-// the dense layout (cpi_mean.hip: launch_mean_L).  5 knots per chunk are slower.
+// BIG (one lane per window, mean-only, batches that fill the chip many times over): THREE knots per chunk instead of two.
+// 21 staged doubles per lane do not fit beside round 3's per-element bookkeeping (a 64-bit pointer, a 32-bit fast-path offset,
+// the last valid chunk and the LDS slot per element: 266 registers, one wavefront per SIMD -- which cut the HBM traffic of a 1 M
+// launch from 1.26 x to 1.08 x algorithmic but not its time, profiles/r04_mean_chunk_ab.md part B), so BIG keeps ONE 32-bit byte
+// offset per element, relative to the wavefront's lowest knot (a wave-uniform base in SGPRs), for the fast path (constant) and
+// the per-element path (advanced per chunk) alike, and its LDS tile is flat (pitch 21 doubles: element e of lane i sits at
+// 64 e + i, an immediate offset) -- two wavefronts per SIMD again, 2-3 % faster than the two-knot kernel on large batches and 7 %
+// on ragged stream windows; the over-fetch at that occupancy is back at 1.37-1.48 x (it is an L2-capacity effect: part D).  The
+// launcher admits BIG only where every lane-segment of a wavefront lies within 2^32 bytes above the lowest one: stream windows of
+// a stream of < 2^26 readings, or the dense layout (cpi_mean.hip: launch_mean_L).  5 knots per chunk, and two chunks fetched
+// back to back per trip, are slower.
 template <int MODEL, bool JAC, bool AVG, int L, int CUT, bool BIG = false>
 __global__ __launch_bounds__(64, BIG ? 2 : (((MODEL == 2 && !JAC) || (MODEL == 1 && JAC)) && L == 1 ? 2 : CPI_MEAN_WPS)) void cpi_mean_kernel(PreArgs A) {
     static_assert(!BIG || (L == 1 && !JAC), "BIG: one lane per window, mean-only");

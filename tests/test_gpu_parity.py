@@ -135,12 +135,12 @@ def test_window_of_100_samples(eng, orc):
 
 
 @pytest.mark.parametrize("model", [1, 2])
-@pytest.mark.parametrize("W,N", [(100003, 50), (130001, 7), (100000, 100)])
+@pytest.mark.parametrize("W,N", [(700003, 50), (830001, 7), (700000, 100)])
 def test_three_knot_kernel_on_the_dense_layout_bitwise_vs_two_knot_and_vs_reference(eng, orc, model, W, N):
-    """From 100 000 windows a one-lane mean-only launch on the dense layout runs cpi_mean_kernel<..., BIG> (three knots per
+    """From 700 000 windows a one-lane mean-only launch on the dense layout runs cpi_mean_kernel<..., BIG> (three knots per
     chunk, 32-bit staging offsets from the wavefront's lowest knot, flat LDS tile; cpi_mean.hip), unless per-window counts are
     given.  Chunking does not touch the arithmetic: BIT FOR BIT the two-knot kernel's outputs (same batch with counts, all
-    full), for a batch whose last block is ragged (W = 64 k + 3: clamped idle lanes, the per-element path of the last two
+    full), for a batch whose last block is ragged (W not a multiple of 64: clamped idle lanes, the per-element path of the last two
     blocks), for N not a multiple of three (padded steps of the last chunk) and N = 100; a strided sample against the
     compiled reference (CpiV1.h:67-154 / CpiV2.h:88-205) at the regression gates."""
     kn, lin, q = synth.make_windows(W, N, seed=4100 + N + model, device=eng.device)

@@ -325,14 +325,14 @@ def test_gpu_stream_entry_never_reads_behind_the_last_reading(model):
 @pytest.mark.gpu
 @pytest.mark.parametrize("phase", [0.0, 0.4])
 def test_gpu_stream_entry_large_batches_take_the_three_knot_kernel_bitwise(phase):
-    """From 100 000 windows every one-lane mean-only launch -- stream entry and dense layout -- runs cpi_mean_kernel<..., BIG>
-    (three knots per chunk, 32-bit staging offsets from a wave-uniform base; cpi_mean.hip), except dense batches with per-window
-    counts, which keep the two-knot kernel.  Chunking does not touch the arithmetic: 600 000 windows x 12 intervals cut out of
-    one stream must equal, BIT FOR BIT, cpi_preintegrate_batch on the same windows laid out densely on the device (first knot
-    under the previous update time, the tail knot = the front reading under the update time) -- through the three-knot kernel
-    (no counts) AND through the two-knot kernel (counts given, all full) --, with and without tail intervals, both imu_avg
-    settings, models 1 and 2; a strided sample is held against the oracle.  (A request with Jacobians takes the workspace route
-    and the analytic-Jacobian kernel at the same size: its means are compared too.)"""
+    """From 100 000 windows the mean-only stream entry of model 1 runs cpi_mean_kernel<..., BIG> (three knots per chunk, 32-bit
+    staging offsets from a wave-uniform base; cpi_mean.hip; model 2 and the dense layout from 700 000).  Chunking does not touch
+    the arithmetic: 600 000 windows x 12 intervals cut out of one stream must equal, BIT FOR BIT, cpi_preintegrate_batch on the
+    same windows laid out densely on the device (first knot under the previous update time, the tail knot = the front reading
+    under the update time) -- the two-knot kernel at this size, with and without per-window counts --, with and without tail
+    intervals, both imu_avg settings, models 1 and 2; a strided sample is held against the oracle.  (A request with Jacobians
+    takes the workspace route and the analytic-Jacobian kernel at the same size: its means are compared too.  The dense layout's
+    own three-knot launches: tests/test_gpu_parity.py::test_three_knot_kernel_on_the_dense_layout_...)"""
     import torch
     import cpi_amd
     from cpi_amd import synth
@@ -362,7 +362,7 @@ def test_gpu_stream_entry_large_batches_take_the_three_knot_kernel_bitwise(phase
         assert int(cnt.min()) == n and int(cnt.max()) == n
         for k in ("DT", "alpha", "beta", "q"):
             assert torch.equal(out_m[k], ref[k]), (phase, model, avg, k)
-            assert torch.equal(ref[k], ref2[k]), ("three knots per chunk vs two", phase, model, avg, k)
+            assert torch.equal(ref[k], ref2[k]), ("dense with / without counts", phase, model, avg, k)
         if model == 1:
             full = eng.preintegrate_stream(stream, upd, lin, q, prm, want=("mean", "jac"), N=n)
             torch.cuda.synchronize()
