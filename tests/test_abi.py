@@ -145,6 +145,38 @@ def test_dpp_sources_are_not_fresh_valu_results():
     assert not bad, bad[:5]
 
 
+def test_three_knot_kernel_addresses_its_staged_loads_from_a_scalar_base():
+    """cpi_mean_kernel<..., BIG> exists to fit three knots per chunk into two wavefronts per SIMD: ONE 32-bit offset per staged
+    element against a wave-uniform base, on the fast path and on the per-element path alike.  That is a property of the generated
+    code, not of the source: every staged load of the shipped kernel must have the `global_load_dwordx2 v[..], v_off32, s[base]`
+    form (21 elements x {first chunk, loop} x {fast, per-element} = 84), and the kernel must fit two wavefronts per SIMD without
+    scratch (cpi_amd/csrc/resource_usage.txt, written by the build)."""
+    import subprocess
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import dpp_hazards
+    from cpi_amd import _lib, build
+    _lib.load()
+    with tempfile.TemporaryDirectory() as tmp:
+        found = 0
+        for co in dpp_hazards.code_objects(build.LIB, tmp):
+            out = subprocess.run([os.path.join(dpp_hazards.LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co],
+                                 stdout=subprocess.PIPE, text=True, check=True).stdout
+            for part in re.split(r"\n(?=[0-9a-f]{16} <)", out):
+                head = part.split("\n", 1)[0]
+                if "cpi_mean_kernelILi1ELb0ELb0ELi1ELi0ELb1E" in head or "cpi_mean_kernelILi1ELb0ELb0ELi1ELi2ELb1E" in head:
+                    loads = re.findall(r"global_load_dwordx2 v\[\d+:\d+\], (?:v\d+|v\[\d+:\d+\]), (s\[\d+:\d+\]|off)", part)
+                    assert sum(1 for b in loads if b != "off") == 84, (head, len(loads))
+                    found += 1
+        assert found == 2
+    rows = [ln.split() for ln in open(build.REPORT) if ln.startswith("cpi_mean_kernel<") and ln.split(">")[0].endswith("true")]
+    assert len(rows) >= 6
+    for r in rows:        # name tokens ..., SGPR VGPR AGPR scratch occ LDS
+        vgpr, agpr, scratch, occ = int(r[-5]), int(r[-4]), int(r[-3]), int(r[-2])
+        assert vgpr + agpr <= 256 and scratch == 0 and occ == 2, r
+
+
 def test_cpp_hosts_compile_against_the_facade_without_a_gpu():
     """Every C++ host under tests/cpp/ must compile (syntax + semantics, no link, no GPU) against cpi_host.hpp and
     include/cpi_amd.h: a change of the facade or of the C-ABI that breaks a caller shows up in the CPU suite, not only on
