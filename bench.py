@@ -40,7 +40,11 @@ import socket
 import sys
 import time
 
-import torch
+# multi-process GPU work on this host driver needs dmabuf IPC (RCCL fails with `hipIpcGetMemHandle: invalid argument` otherwise);
+# the boxes export it already -- kept here so that a launcher with a scrubbed environment still gets it, before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
