@@ -1,7 +1,9 @@
 """ctypes binding of include/cpi_amd.h -> cpi_amd/libcpi_amd.so (the HIP library).
 
 There is NO CPU fallback: if the library is missing and cannot be built with hipcc this module
-raises, and creating a context on a machine without a GPU raises (CPI_ERR_NO_DEVICE).
+raises, a hipcc compile / link error propagates, a library built from other sources than the tree holds is refused
+(cpi_build_id() vs build.source_id(); CPI_AMD_ALLOW_STALE=1 overrides), and creating a context on a machine without a GPU
+raises (CPI_ERR_NO_DEVICE).
 """
 import ctypes as C
 import os
@@ -40,19 +42,18 @@ def load():
     if _lib is not None:
         return _lib
     from . import build as _build
+    hipcc_missing = None
     if LIB_PATH == _build.LIB and _build.stale():
         # missing, or built from other sources than the tree holds (content hash); hipcc cross-compiles without a GPU.
-        # A box without hipcc, a library shipped without its git-ignored .id sidecar, a comment-only edit: when the rebuild
-        # fails but a library IS there, say so and load it -- the ABI / symbol guard below still rejects a stale one.
+        # Compile and link errors PROPAGATE (a source edit that does not build must not be hidden behind the previous
+        # library).  Only a machine without the compiler may go on with the library that is there -- and then only when that
+        # library was built from this tree's sources (cpi_build_id() == source_id(), checked below).
         try:
             _build.build()
-        except Exception as ex:
-            if not os.path.exists(LIB_PATH):
-                raise ImportError("cpi_amd: %s is missing and could not be built (%r); no CPU fallback exists" % (LIB_PATH, ex))
-            import warnings
-            warnings.warn("cpi_amd: could not rebuild %s (%r); loading the existing library" % (LIB_PATH, ex))
+        except FileNotFoundError as ex:            # subprocess could not start HIPCC: no compiler on this machine
+            hipcc_missing = ex
     if not os.path.exists(LIB_PATH):
-        raise ImportError("cpi_amd: %s is missing and could not be built (no CPU fallback exists)" % LIB_PATH)
+        raise ImportError("cpi_amd: %s is missing and could not be built (%r); no CPU fallback exists" % (LIB_PATH, hipcc_missing))
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
     # the ABI guard comes FIRST: a stale library must fail with this message, not with an AttributeError on a new symbol
@@ -65,6 +66,17 @@ def load():
     if missing:
         raise ImportError("cpi_amd: %s lacks %s (a build from before round 3: run python -m cpi_amd.build --force)" % (LIB_PATH, ", ".join(missing)))
     lib.cpi_build_id.restype = C.c_char_p
+    if LIB_PATH == _build.LIB:
+        # the in-tree product library must be the build of the in-tree sources: same-ABI libraries with old kernels would
+        # otherwise pass every guard above.  CPI_AMD_ALLOW_STALE=1 loads it anyway (a box without hipcc and a comment-only edit).
+        have, want = (lib.cpi_build_id() or b"").decode(), _build.source_id()
+        if have != want:
+            msg = "cpi_amd: %s was built from other sources than this tree holds (build id %s, sources %s)%s" % (
+                LIB_PATH, have, want, "; hipcc is not available here (%r)" % (hipcc_missing,) if hipcc_missing else "")
+            if os.environ.get("CPI_AMD_ALLOW_STALE") != "1":
+                raise ImportError(msg + " -- run python -m cpi_amd.build, or set CPI_AMD_ALLOW_STALE=1 to load it anyway")
+            import warnings
+            warnings.warn(msg + " (CPI_AMD_ALLOW_STALE=1: loaded anyway)")
     lib.cpi_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     lib.cpi_group_destroy.argtypes = [vp]
     lib.cpi_group_destroy.restype = None

@@ -188,14 +188,15 @@ def build_custom(tag, defines):
     with _BuildLock():
         def one(unit):
             # a unit is rebuilt only when one of the files it includes mentions one of the macros; the others are the default build's objects
-            text = "".join(open(_path(d), errors="ignore").read() for d in UNITS[unit])
+            exp = "-DCPI_EXPERIMENTS" in defines          # an experiments variant: the unit also includes its EXP_EXTRA headers
+            text = "".join(open(_path(d), errors="ignore").read() for d in UNITS[unit] + (EXP_EXTRA.get(unit, []) if exp else []))
             defs = [d for d in defines if d[2:].split("=")[0] in text]
             if unit == "cpi_abi":
                 defs.append('-DCPI_BUILD_ID="%s"' % (source_id() + "+" + tag)[:31])
             elif not defs:
                 return _compile(unit, "", False)[0]
             obj = os.path.join(OBJ, "%s__%s.o" % (unit, tag))
-            key = _unit_key(unit, defs, False)
+            key = _unit_key(unit, defs, exp)
             if os.path.exists(obj) and os.path.exists(obj + ".key") and open(obj + ".key").read() == key:
                 return obj
             p = subprocess.run([HIPCC] + CFLAGS + defs + ["-c", "-o", obj, os.path.join(CSRC, unit + ".hip")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

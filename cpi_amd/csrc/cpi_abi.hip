@@ -150,6 +150,7 @@ static launch::MeanDmaCfg mean_dma() {   // CPI_AMD_MEAN_DMA = "off" | "KC,S,A" 
 }
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static int mean_blk() { static int v = [] { const char *e = getenv("CPI_AMD_MEAN_BLK"); return e ? (strcmp(e, "off") == 0 ? -1 : atoi(e)) : 0; }(); return v; }
+static bool mean_line() { static int v = env_int("CPI_AMD_MEAN_LINE", 0); return v != 0; }   // cpi_mean_line_kernel on the leading groups of a dense one-lane batch
 static int blk_mode() { static int v = env_int("CPI_AMD_BLK_MODE", 0); return v; }
 static int probe_lds() { static int v = env_int("CPI_AMD_PROBE_LDS", 0); return v; }
 static bool no_overlap() { static int v = env_int("CPI_AMD_NO_OVERLAP", 0); return v != 0; }
@@ -327,12 +328,15 @@ static int preintegrate_impl(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int
 #ifdef CPI_EXPERIMENTS
         const int bl = expsw::mean_blk();
         m.dbg = expsw::blk_mode();
-        if (!mean_jac && !first && bl > 0 && (size_t)(64 / bl) * (size_t)(N + 1) * 56 <= 65536 && N >= 1) {
+        // (both experimental kernels address `knots` as the dense [W][N + 1][7] layout: never on a stream call, whose outer
+        //  first / count are NULL on the fused-cut route although the windows are anything but dense)
+        if (!sc && !mean_jac && !first && bl > 0 && (size_t)(64 / bl) * (size_t)(N + 1) * 56 <= 65536 && N >= 1) {
             if (launch::mean_blk(prm->model, bl, avg, m, ctx->stream)) done = W;
         }
         const launch::MeanDmaCfg dc = expsw::mean_dma();
-        if (!done && !mean_jac && LL == 1 && !first && !count && dc.kc > 0 && N >= 2 * dc.kc)
+        if (!sc && !done && !mean_jac && LL == 1 && !first && !count && dc.kc > 0 && N >= 2 * dc.kc)
             done = launch::mean_dma(prm->model, dc, avg, m, ctx->stream);
+        if (!sc && !done && !mean_jac && LL == 1 && !first && !count && expsw::mean_line()) done = launch::mean_line(prm->model, avg, m, ctx->stream);
         if (done && done < W) m = shift_windows(m, done);
 #endif
         if (done < W) launch::mean(prm->model, mean_jac, avg, LL, m, mean_stream);

@@ -131,6 +131,7 @@ void unpack_slabs(int n, const long long *lo, const long long *cnt, const long l
 struct MeanDmaCfg { int kc, s, aligned; };
 long long mean_dma(int model, const MeanDmaCfg &c, bool avg, const PreArgs &a, hipStream_t st);   // leading windows handled
 bool mean_blk(int model, int L, bool avg, const PreArgs &a, hipStream_t st);
+long long mean_line(int model, bool avg, const PreArgs &a, hipStream_t st);                       // leading windows handled
 void tiled_fetch_probe(const TiledArgs &a, size_t lds, hipStream_t st);
 #endif
 }  // namespace launch

@@ -6,9 +6,11 @@
 //   while (...) cpi.feed_IMU(t0, t1, w0, a0, w1, a1);                   // CpiBase.h:86
 //   use cpi.DT, cpi.alpha_tau, cpi.beta_tau, cpi.q_k2tau, cpi.J_q ... cpi.P_meas   // CpiBase.h:99-124
 //
-// Differences forced by the device boundary: feed_IMU() only records the interval; the recursion
-// runs on the GPU when finalize() is called (or through CpiBatch, which flushes many windows in one
-// launch -- the intended use).  Matrices are plain column-major arrays (Eigen::Map them if needed).
+// Differences forced by the device boundary: feed_IMU() only records the interval; the recursion runs on the GPU when a
+// result member is READ (round 5: the members are lazy -- code shaped like GraphSolver_IMU.cpp:43-75 compiles unchanged, no
+// finalize() between the feed_IMU loop and `ImuFactorCPIv1(..., cpi.P_meas, cpi.DT, cpi.grav, cpi.alpha_tau, ...)`), when
+// finalize(ctx) is called, or through CpiBatch, which flushes many windows in one launch -- the intended use for more than a
+// handful of windows.  Matrices are plain column-major arrays (Eigen::Map them if needed).
 // Header-only; link with -lcpi_amd.  No CPU fallback: errors throw std::runtime_error.
 #pragma once
 #include <algorithm>
@@ -67,7 +69,7 @@ private:
     cpi_group *g_ = nullptr;
 };
 
-// Results of one window: the public members of CpiBase / CpiV2.
+// Results of one window: the public members of CpiBase / CpiV2, as plain values.
 struct CpiResult {
     double DT = 0;
     Vec3 alpha_tau{}, beta_tau{};
@@ -76,10 +78,56 @@ struct CpiResult {
     Mat15 P_meas{};
 };
 
-class CpiBase : public CpiResult {
+// The context a lazy read runs on when the preintegrator was not bound to one (CpiBase::bind): one per process, on the
+// current device.  Calls on a context are not re-entrant: threads that read results concurrently bind their own contexts.
+inline const Context &default_context() {
+    static Context ctx;
+    return ctx;
+}
+
+class CpiBase;
+// A result member of CpiBase (CpiBase.h:99-124: DT, alpha_tau, ... P_meas).  The reference's members are live after every
+// feed_IMU; here the recorded intervals run on the GPU the first time ANY member is read after a feed_IMU (one launch for the
+// whole window so far), so caller code keeps the reference's shape.  Reading = conversion to const T &, get(), and for the
+// array members operator[], begin() / end(), data().  Assignment stores a value and runs nothing.
+template <class T>
+class Lazy {
+public:
+    explicit Lazy(const CpiBase *owner, const T &init = T{}) : v_(init), owner_(owner) {}
+    Lazy(const Lazy &) = delete;                       // members of ONE preintegrator: CpiBase's copy operations re-bind them
+    Lazy &operator=(const Lazy &) = delete;
+    Lazy &operator=(const T &v) { v_ = v; return *this; }
+    operator const T &() const { sync(); return v_; }
+    const T &get() const { sync(); return v_; }
+    template <class U = T> auto operator[](size_t i) const -> decltype(std::declval<const U &>()[i]) { sync(); return v_[i]; }
+    template <class U = T> auto begin() const -> decltype(std::declval<const U &>().begin()) { sync(); return v_.begin(); }
+    template <class U = T> auto end() const -> decltype(std::declval<const U &>().end()) { sync(); return v_.end(); }
+    template <class U = T> auto data() const -> decltype(std::declval<const U &>().data()) { sync(); return v_.data(); }
+    template <class U = T> auto size() const -> decltype(std::declval<const U &>().size()) { return v_.size(); }
+private:
+    friend class CpiBase;
+    inline void sync() const;
+    T v_;
+    const CpiBase *owner_;
+};
+
+class CpiBase {
 public:
     CpiBase(int model, double sigma_w, double sigma_wb, double sigma_a, double sigma_ab, bool imu_avg_ = false)
         : imu_avg(imu_avg_), model_(model) { sig_[0] = sigma_w; sig_[1] = sigma_wb; sig_[2] = sigma_a; sig_[3] = sigma_ab; }
+    CpiBase(const CpiBase &o) { *this = o; }
+    CpiBase &operator=(const CpiBase &o) {
+        if (this == &o) return *this;
+        imu_avg = o.imu_avg; state_transition_jacobians = o.state_transition_jacobians;
+        b_w_lin = o.b_w_lin; b_a_lin = o.b_a_lin; q_k_lin = o.q_k_lin; grav = o.grav;
+        knots_ = o.knots_; model_ = o.model_; ctx_ = o.ctx_; dirty_ = o.dirty_;
+        for (int i = 0; i < 4; i++) sig_[i] = o.sig_[i];
+        put(o.peek());
+        return *this;
+    }
+    virtual ~CpiBase() {}
+    // the context lazy reads run on (default: default_context()); the Context must outlive the reads
+    void bind(const Context &ctx) { ctx_ = &ctx; }
     void setLinearizationPoints(const Vec3 &b_w_lin_, const Vec3 &b_a_lin_, const Vec4 &q_k_lin_ = Vec4{{0, 0, 0, 0}},
                                 const Vec3 &grav_ = Vec3{{0, 0, 0}}) {
         b_w_lin = b_w_lin_; b_a_lin = b_a_lin_; q_k_lin = q_k_lin_; grav = grav_;
@@ -102,6 +150,7 @@ public:
             if (!imu_avg && k[0] == t_0) {   // times chain, closing readings unused: this interval's reading opens it
                 for (int i = 0; i < 3; i++) { k[1 + i] = w_m_0[i]; k[4 + i] = a_m_0[i]; }
                 chained = true;
+                touch();
             } else {
                 chained = k[0] == t_0 && k[1] == w_m_0[0] && k[2] == w_m_0[1] && k[3] == w_m_0[2] && k[4] == a_m_0[0] &&
                           k[5] == a_m_0[1] && k[6] == a_m_0[2];
@@ -115,15 +164,23 @@ public:
         }
         push(t_1, w_m_1, a_m_1);
     }
-    // Runs this single window on the GPU and fills the result members.
+    // Runs this single window on the GPU and fills the result members (what a first read of any member does by itself).
     void finalize(const Context &ctx) {
         cpi_params p = params();
         const double lin[6] = { b_w_lin[0], b_w_lin[1], b_w_lin[2], b_a_lin[0], b_a_lin[1], b_a_lin[2] };
-        cpi_outputs o = outputs_of(*this);
+        CpiResult r;
+        cpi_outputs o = outputs_of(r);
         const int32_t n = knots_.empty() ? 0 : (int32_t)(knots_.size() / 7 - 1);
         static const double zero_knot[7] = { 0, 0, 0, 0, 0, 0, 0 };
         ctx.check(cpi_preintegrate_batch_host(ctx.get(), &p, 1, n, knots_.empty() ? zero_knot : knots_.data(), nullptr, nullptr,
                                               n + 1, lin, q_k_lin.data(), &o));
+        set_result(r);
+    }
+    // the result members as plain values (runs the pending intervals first) / stored from outside (CpiBatch)
+    CpiResult result() const { ensure(); return peek(); }
+    void set_result(const CpiResult &r) { put(r); dirty_ = false; }
+    void set_means(double DT_, const Vec3 &alpha, const Vec3 &beta, const Vec4 &q) {   // CpiBatch::flush_means: the other members keep their values
+        DT.v_ = DT_; alpha_tau.v_ = alpha; beta_tau.v_ = beta; q_k2tau.v_ = q; dirty_ = false;
     }
     cpi_params params() const {
         cpi_params p{};
@@ -152,18 +209,43 @@ public:
     Vec3 b_w_lin{}, b_a_lin{};
     Vec4 q_k_lin{};
     Vec3 grav{};
+    // CpiBase.h:99-124 (+ CpiV2.h O_a / O_b): computed on first read after a feed_IMU
+    Lazy<double> DT{this, 0.0};
+    Lazy<Vec3> alpha_tau{this}, beta_tau{this};
+    Lazy<Vec4> q_k2tau{this, Vec4{{0, 0, 0, 1}}};
+    Lazy<Mat3> J_q{this}, J_a{this}, J_b{this}, H_a{this}, H_b{this}, O_a{this}, O_b{this};
+    Lazy<Mat15> P_meas{this};
 
 protected:
     void push(double t, const Vec3 &w, const Vec3 &a) {
         knots_.push_back(t);
         for (int i = 0; i < 3; i++) knots_.push_back(w[i]);
         for (int i = 0; i < 3; i++) knots_.push_back(a[i]);
+        dirty_ = true;
     }
+    void touch() { dirty_ = true; }              // a recorded knot was rewritten in place
     std::vector<double> knots_;
 private:
-    int model_;
-    double sig_[4];
+    template <class T> friend class Lazy;
+    void ensure() const { if (dirty_) const_cast<CpiBase *>(this)->finalize(ctx_ ? *ctx_ : default_context()); }
+    CpiResult peek() const {                     // the stored values, without running anything
+        CpiResult r;
+        r.DT = DT.v_; r.alpha_tau = alpha_tau.v_; r.beta_tau = beta_tau.v_; r.q_k2tau = q_k2tau.v_;
+        r.J_q = J_q.v_; r.J_a = J_a.v_; r.J_b = J_b.v_; r.H_a = H_a.v_; r.H_b = H_b.v_; r.O_a = O_a.v_; r.O_b = O_b.v_;
+        r.P_meas = P_meas.v_;
+        return r;
+    }
+    void put(const CpiResult &r) {
+        DT.v_ = r.DT; alpha_tau.v_ = r.alpha_tau; beta_tau.v_ = r.beta_tau; q_k2tau.v_ = r.q_k2tau;
+        J_q.v_ = r.J_q; J_a.v_ = r.J_a; J_b.v_ = r.J_b; H_a.v_ = r.H_a; H_b.v_ = r.H_b; O_a.v_ = r.O_a; O_b.v_ = r.O_b;
+        P_meas.v_ = r.P_meas;
+    }
+    int model_ = CPI_MODEL_V1;
+    double sig_[4] = {0, 0, 0, 0};
+    const Context *ctx_ = nullptr;
+    bool dirty_ = false;                         // intervals recorded since the result members were last computed
 };
+template <class T> inline void Lazy<T>::sync() const { owner_->ensure(); }
 
 class CpiV1 : public CpiBase {
 public:
@@ -195,6 +277,7 @@ public:
         else {   // the closing knot of the previous interval becomes the opening knot of this one: give it this reading
             double *k = &knots_[knots_.size() - 7];
             for (int i = 0; i < 3; i++) { k[1 + i] = measuredOmega[i]; k[4 + i] = measuredAcc[i]; }
+            touch();
         }
         // intervals are stored as knot times; t += dt reproduces dt to within one rounding of the running time
         t_ += dt;
@@ -236,7 +319,7 @@ public:
         ctx.check(cpi_preintegrate_batch_host(ctx.get(), &p, W, N, knots.data(), dense ? nullptr : first.data(), dense ? nullptr : count.data(),
                                               (int64_t)(knots.size() / 7), lin.data(), qk.data(), &o));
         for (int64_t w = 0; w < W; w++) {
-            CpiResult &r = *win_[w];
+            CpiResult r;
             r.DT = DT[w];
             for (int i = 0; i < 3; i++) { r.alpha_tau[i] = al[w * 3 + i]; r.beta_tau[i] = be[w * 3 + i]; }
             for (int i = 0; i < 4; i++) r.q_k2tau[i] = q[w * 4 + i];
@@ -245,6 +328,7 @@ public:
                 r.H_b[i] = Hb[w * 9 + i]; r.O_a[i] = Oa[w * 9 + i]; r.O_b[i] = Ob[w * 9 + i];
             }
             for (int i = 0; i < 225; i++) r.P_meas[i] = P[w * 225 + i];
+            win_[w]->set_result(r);
         }
         win_.clear();
     }
@@ -277,12 +361,9 @@ public:
         cpi_outputs o{};
         o.DT = DT.data(); o.alpha = al.data(); o.beta = be.data(); o.q = q.data();
         ctx.check(cpi_preintegrate_tiled_batch_host(ctx.get(), &p, W, N, tiles.data(), count.data(), lin.data(), qk.data(), &o));
-        for (int64_t w = 0; w < W; w++) {
-            CpiResult &r = *win_[w];
-            r.DT = DT[w];
-            for (int i = 0; i < 3; i++) { r.alpha_tau[i] = al[w * 3 + i]; r.beta_tau[i] = be[w * 3 + i]; }
-            for (int i = 0; i < 4; i++) r.q_k2tau[i] = q[w * 4 + i];
-        }
+        for (int64_t w = 0; w < W; w++)
+            win_[w]->set_means(DT[w], Vec3{{al[w * 3], al[w * 3 + 1], al[w * 3 + 2]}}, Vec3{{be[w * 3], be[w * 3 + 1], be[w * 3 + 2]}},
+                               Vec4{{q[w * 4], q[w * 4 + 1], q[w * 4 + 2], q[w * 4 + 3]}});
         win_.clear();
     }
 private:
@@ -457,8 +538,29 @@ private:
 class ImuFactorCPI {
 public:
     // built straight from a finished preintegrator, with the field->ctor mapping of GraphSolver_IMU.cpp:74-75,129-130
-    explicit ImuFactorCPI(const CpiBase &cpi) : model_(cpi.factor_model()), m_(cpi), grav_(cpi.grav), qk_(cpi.q_k_lin) {
+    explicit ImuFactorCPI(const CpiBase &cpi) : model_(cpi.factor_model()), m_(cpi.result()), grav_(cpi.grav), qk_(cpi.q_k_lin) {
         for (int i = 0; i < 3; i++) { lin_[i] = cpi.b_w_lin[i]; lin_[3 + i] = cpi.b_a_lin[i]; }
+    }
+    // the reference's constructor shape (ImuFactorCPIv1.h:78-81 / ImuFactorCPIv2.h:82-85 without the two keys), so that the last
+    // line of createimufactor_cpi_v1 (GraphSolver_IMU.cpp:74-75) keeps its argument list:
+    //   ImuFactorCPI(cpi.P_meas, cpi.DT, cpi.grav, cpi.alpha_tau, cpi.beta_tau, cpi.q_k2tau, cpi.b_a_lin, cpi.b_w_lin,
+    //                cpi.J_q, cpi.J_b, cpi.J_a, cpi.H_b, cpi.H_a)                                    model 1
+    //   ImuFactorCPI(..., cpi.q_k2tau, cpi.q_k_lin, cpi.b_a_lin, ..., cpi.H_a, cpi.O_b, cpi.O_a)     model 2 (:129-130)
+    ImuFactorCPI(const Mat15 &covariance, double deltatime, const Vec3 &grav, const Vec3 &alpha, const Vec3 &beta, const Vec4 &q_KtoK1,
+                 const Vec3 &ba_lin, const Vec3 &bg_lin, const Mat3 &J_q, const Mat3 &J_beta, const Mat3 &J_alpha, const Mat3 &H_beta,
+                 const Mat3 &H_alpha)
+        : model_(CPI_MODEL_V1), grav_(grav), qk_(Vec4{{0, 0, 0, 1}}) {
+        m_.P_meas = covariance; m_.DT = deltatime; m_.alpha_tau = alpha; m_.beta_tau = beta; m_.q_k2tau = q_KtoK1;
+        m_.J_q = J_q; m_.J_b = J_beta; m_.J_a = J_alpha; m_.H_b = H_beta; m_.H_a = H_alpha;
+        for (int i = 0; i < 3; i++) { lin_[i] = bg_lin[i]; lin_[3 + i] = ba_lin[i]; }
+    }
+    ImuFactorCPI(const Mat15 &covariance, double deltatime, const Vec3 &grav, const Vec3 &alpha, const Vec3 &beta, const Vec4 &q_KtoK1,
+                 const Vec4 &q_K_lin, const Vec3 &ba_lin, const Vec3 &bg_lin, const Mat3 &J_q, const Mat3 &J_beta, const Mat3 &J_alpha,
+                 const Mat3 &H_beta, const Mat3 &H_alpha, const Mat3 &O_beta, const Mat3 &O_alpha)
+        : model_(CPI_MODEL_V2), grav_(grav), qk_(q_K_lin) {
+        m_.P_meas = covariance; m_.DT = deltatime; m_.alpha_tau = alpha; m_.beta_tau = beta; m_.q_k2tau = q_KtoK1;
+        m_.J_q = J_q; m_.J_b = J_beta; m_.J_a = J_alpha; m_.H_b = H_beta; m_.H_a = H_alpha; m_.O_b = O_beta; m_.O_a = O_alpha;
+        for (int i = 0; i < 3; i++) { lin_[i] = bg_lin[i]; lin_[3 + i] = ba_lin[i]; }
     }
     // from a window of ImuStream::preintegrate: the measurement, the model (1 / 2) and the linearisation point it was made with
     ImuFactorCPI(int model, const CpiResult &meas, const Vec3 &grav, const Vec3 &b_w_lin, const Vec3 &b_a_lin, const Vec4 &q_k_lin = Vec4{{0, 0, 0, 1}})

@@ -188,6 +188,24 @@ bool mean_blk(int model, int L, bool avg, const PreArgs &a, hipStream_t st) {
         default: return false;
     }
 }
+// cpi_mean_line_kernel: the leading whole groups of 64 P windows of a dense batch; returns the number of windows handled
+long long mean_line(int model, bool avg, const PreArgs &a, hipStream_t st) {
+    if (a.first || a.count || a.update || a.tstart || a.N < 8 || a.N > 60000 || ((uintptr_t)a.knots & 127) != 0) return 0;
+    const long long S = (long long)(a.N + 1) * 7;
+    int P = 16;
+    while (P > 1 && ((S * (P / 2)) & 15) == 0) P /= 2;            // smallest P with P S = 0 mod 16
+    const long long groups = (a.W - 1) / (64ll * P);
+    if (groups <= 0) return 0;
+    const unsigned nb = (unsigned)(((groups + 7) / 8) * 8 * P);
+    if (model == CPI_MODEL_V2) {
+        if (avg) hipLaunchKernelGGL((cpi_mean_line_kernel<2, true>), dim3(nb), dim3(64), 0, st, a, P, groups);
+        else     hipLaunchKernelGGL((cpi_mean_line_kernel<2, false>), dim3(nb), dim3(64), 0, st, a, P, groups);
+    } else {
+        if (avg) hipLaunchKernelGGL((cpi_mean_line_kernel<1, true>), dim3(nb), dim3(64), 0, st, a, P, groups);
+        else     hipLaunchKernelGGL((cpi_mean_line_kernel<1, false>), dim3(nb), dim3(64), 0, st, a, P, groups);
+    }
+    return groups * 64 * P;
+}
 void tiled_fetch_probe(const TiledArgs &a, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL(cpi_tiled_fetch_probe_kernel, dim3((unsigned)((a.W + 63) / 64)), dim3(64), lds, st, a);
 }

@@ -277,4 +277,149 @@ __global__ __launch_bounds__(64, 1) void cpi_mean_blk_kernel(PreArgs A) {
 }
 
 
+// ============================================================================================
+// mean kernel, dense layout, WHOLE 128-byte lines: cpi_mean_line_kernel (round 5; CPI_AMD_MEAN_LINE=1)
+// ============================================================================================
+// "stop paying for half-read lines".  The staged cpi_mean_kernel fetches a window's knots in 112- /
+// 168-byte pieces that start anywhere in a 128-byte line; every piece leaves a half-read line behind that the next chunk comes
+// back for one chunk period later, and at 8 wavefronts per CU the L2 has evicted a good half of them by then (1.35 x the
+// algorithmic bytes on the dense 1 M x 50 launch).  Here a window is fetched LINE BY LINE -- trip j brings line j (TL = 2: lines
+// 2 j, 2 j + 1) of each of the wavefront's 64 windows, 16 lanes per line, four whole lines per load instruction -- and the
+// doubles go into a per-window RING in LDS at (position in the window) mod RING, from which the window's lane takes its knots
+// as they complete.  What makes that cheap is the choice of the 64 windows: the dense layout's window stride is 7 (N + 1)
+// doubles, so the offset of a window's first double within its line ("phase") repeats with period P = 16 / gcd(7 (N + 1), 16)
+// windows, and a wavefront takes 64 windows of ONE phase class (w, w + P, w + 2 P, ...): every lane's window completes its
+// knots at the same trips -- the ring never holds more than 6 + 16 TL doubles, the write slots of a trip are the same for every
+// window (one LDS address per lane and trip mod 3 / 5; the element index is an immediate), the consumer's slot is wave-uniform,
+// and there is no per-lane bookkeeping at all (158 registers, 12.8 KB of LDS: 12 wavefronts per CU).  The P wavefronts of a
+// group of 64 P consecutive windows run on one XCD (block b -> XCD b mod 8) at the same time, so the output lines they share
+// are mostly combined in that L2.  Lines are counted from A.knots (no byte outside the caller's array is touched); the launcher
+// takes the leading whole groups only when A.knots is 128-byte aligned, never the batch's last 64 P windows (a window's last
+// line reaches into the next window).  Bit-identical to cpi_mean_kernel (tests/tools/dma_check.py, and the three-knot parity
+// test run against a build that uses it).
+// MEASURED (MI355X, profiles/r05_mean_traffic.md; dense 1 M x 50, same box, alternating): HBM traffic 1.35 x -> 1.09 x (reads
+// 1.04 x; the strided output stores are written back ~1.8 times) -- and the launch is SLOWER: 677-706 us against 632-662 for the
+// shipped three-knot kernel, whatever the lines in flight (one or two trips ahead), the occupancy (9 or 12 wavefronts per CU)
+// or the piece (TL = 2: 681-689 us).  Its fetch alone (no arithmetic) takes 642-653 us, its arithmetic alone 384 us.  The
+// memory system, not the kernel, sets that: a pure-load probe of the pattern (tools/exp/stride_probe.hip: 64 windows per
+// wavefront visited in lock step, B contiguous bytes per window and visit, nothing else) streams 4.6-4.7 TB/s at B = 128, 5.0 at
+// 256, 5.6-5.7 at 512, 5.8 at 1024, 6.3 linearly -- DRAM row locality -- and the staged kernel's re-fetched half-lines are served
+// by the Infinity Cache beside that stream (tools/exp/mall_probe.hip: a re-touch within 64 MB of traffic costs 0.7 of a DRAM
+// fetch and adds to, rather than queues behind, the DRAM stream).  Both designs draw ~4.6-4.7 TB/s from DRAM; B >= 512 at one
+// lane per window would need >= 36 KB of LDS per wavefront.  NOT the default: CPI_AMD_MEAN_LINE=1 for A/B measurements only.
+#ifndef CPI_MEAN_LINE_TL
+#define CPI_MEAN_LINE_TL 1               // lines per window and trip (1 | 2)
+#endif
+#ifndef CPI_MEAN_LINE_OCC
+#define CPI_MEAN_LINE_OCC ((MODEL == 2 || CPI_MEAN_LINE_TL > 1) ? 2 : 3)
+#endif
+template <int MODEL, bool AVG>
+__global__ __launch_bounds__(64, CPI_MEAN_LINE_OCC) void cpi_mean_line_kernel(PreArgs A, int P, long long ngroups) {
+    constexpr int TL = CPI_MEAN_LINE_TL;
+    constexpr int D = 16 * TL;               // doubles per window and trip = lanes per window of a load instruction = staged elements per lane
+    constexpr int WPI = 64 / D;              // windows per load instruction
+    // RING: a trip adds D doubles to at most 6 left over (an incomplete knot): 24 slots (12.8 KB per wavefront = 12 per CU) / 40
+    constexpr int RING = (D + 6 + 7) / 8 * 8, PITCH = RING + 1;   // odd pitch: the consumer's ds_read_b64 of a half-wave hit 32 distinct even banks
+    constexpr int NP = RING / 8;             // write slots repeat every NP trips (D = 16: 3, D = 32: 5)
+    __shared__ double tile[64 * PITCH];
+    const int lane = threadIdx.x;
+    const unsigned b = blockIdx.x, t = b >> 3;
+    const int c = (int)(t % (unsigned)P);
+    const long long grp = (long long)(t / (unsigned)P) * 8 + (b & 7u);
+    if (grp >= ngroups) return;
+    const long long S = (long long)(A.N + 1) * 7;          // doubles per window
+    const long long wbase = grp * 64 * P + c;               // wave-uniform
+    const long long w = wbase + (long long)P * lane;        // this lane's window (as consumer)
+    const long long G0 = wbase * S;
+    const int ph = (int)(G0 & 15);                          // phase of every window of this wavefront
+    const long long PS = (long long)P * S;                  // doubles between consecutive lanes' windows: a multiple of 16
+    const double *blk0 = A.knots + (G0 - ph);
+
+    // producer side: element e of lane i = double (i mod D) of the current piece of window WPI e + i / D; position D j + d - ph
+    // of the window, slot = position mod RING: NP write addresses per lane (by trip mod NP), the element index is an immediate
+    const int g = lane / D, d = lane % D;
+    unsigned voff[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) voff[e] = (unsigned)(((long long)(WPI * e + g) * PS + d) * 8);
+    const int s0 = (d - ph + RING) % RING;
+    double *wp[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) wp[k] = tile + g * PITCH + (s0 + k * D) % RING;
+    const double *const row = tile + lane * PITCH;
+
+    const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
+    V3 gk = mk(0, 0, 0);
+    if (MODEL == 2) gk = mul(quat_2_Rot(ldq4(A.qk + w * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
+    MeanState<false> st;
+    mean_init(st);
+
+    const int K1 = A.N + 1;                                 // knots per window
+    const int T = (int)((ph + S + D - 1) / D);              // trips per window
+    double stage[D];
+#ifdef CPI_MEAN_LINE_MODE
+#pragma unroll
+    for (int e = 0; e < D; ++e) stage[e] = 0.01 * (e + 1) + 1e-4 * lane;   // measurement builds (tools/exp/): mode 2 = no fetch
+#endif
+    auto issue = [&](int j) {
+#if defined(CPI_MEAN_LINE_MODE) && CPI_MEAN_LINE_MODE == 2
+        (void)j;
+#else
+        const char *cb = reinterpret_cast<const char *>(blk0) + (long long)j * (D * 8);
+#pragma unroll
+        for (int e = 0; e < D; ++e) {
+            asm volatile("" : "+v"(voff[e]));   // `global_load v, v_off32, s[base]`
+            stage[e] = *reinterpret_cast<const double *>(cb + voff[e]);
+        }
+#endif
+    };
+    double pk[7] = {0, 0, 0, 0, 0, 0, 0};
+    int kdone = 0, jm = 0, p0 = 0;                          // knots integrated; trip mod NP; ring slot of the next knot -- all wave-uniform
+    issue(0);
+    for (int j = 0; j < T; ++j) {
+        double *wb = wp[0];
+#pragma unroll
+        for (int k = 1; k < NP; ++k) wb = (jm == k) ? wp[k] : wb;
+        jm = (jm == NP - 1) ? 0 : jm + 1;
+#pragma unroll
+        for (int e = 0; e < D; ++e) wb[e * WPI * PITCH] = stage[e];
+        __syncthreads();
+        if (j + 1 < T) issue(j + 1);
+        const int ka = min(K1, (D * (j + 1) - ph) / 7);     // complete knots in the ring or behind it
+        for (int kk = kdone; kk < ka; ++kk) {
+            double q[7];
+            if (p0 <= RING - 7) {
+                const double *nk = row + p0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) q[i] = nk[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 7; i++) q[i] = row[(p0 + i) % RING];
+            }
+            p0 = (p0 + 7 >= RING) ? p0 + 7 - RING : p0 + 7;
+#if defined(CPI_MEAN_LINE_MODE) && CPI_MEAN_LINE_MODE == 1
+            st.DT += ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + q[6]);    // measurement build: fetch without arithmetic
+#else
+            if (kk > 0)
+                mean_step<MODEL, false, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
+                                             mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, true);
+#endif
+#pragma unroll
+            for (int i = 0; i < 7; i++) pk[i] = q[i];
+        }
+        kdone = ka;
+        __syncthreads();
+    }
+    if (A.write_means) {
+        if (A.out.DT) A.out.DT[w] = st.DT;
+        if (A.out.alpha) stv3(A.out.alpha + w * 3, st.alpha);
+        if (A.out.beta) stv3(A.out.beta + w * 3, st.beta);
+        if (A.out.q) {
+            const Q4 q = rot_2_quat(st.R);
+            double *p = A.out.q + w * 4;
+            p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+        }
+    }
+}
+
+
 }  // namespace

@@ -206,14 +206,16 @@ class Engine:
         """One IMU stream cut at update times and preintegrated IN PLACE (cpi_preintegrate_stream: the caller-side loop of
         GraphSolver_IMU.cpp:43-75 for all windows at once, zero copies of the IMU data, every model and output).
         stream [K, 7] with non-decreasing stamps, update_times [U] non-decreasing, lin [U, 6], q_k_lin [U, 4]: CUDA float64.
-        N = upper bound of the intervals per window (default: the whole stream -- safe, give a tight one for speed: the
-        kernels' loops run to N); with check_counts (one synchronisation) raises when a window holds more."""
+        N = upper bound of the intervals per window; with check_counts (one synchronisation) raises when a window holds more.
+        Default: the exact bound, computed from the stamps (one searchsorted over the K stamps + one synchronisation) -- the
+        library picks the mean kernel's lane split from N, so a loose bound (round 4's default was the whole stream) costs
+        speed on small batches; pass N to skip that pass."""
         params = params or self.make_params()
         K, U = stream.shape[0], update_times.shape[0]
         for t in (stream, update_times, lin, q_k_lin):
             assert t is None or (t.is_cuda and t.is_contiguous() and t.dtype == torch.float64), "inputs must be contiguous CUDA float64 tensors"
         if N is None:
-            N = min(int(K), 65535)
+            N = self._stream_bound(stream, update_times)
         if out is None:
             out = self.alloc_outputs(U, want, params.model)
         ws = workspace if workspace is not None else self.stream_workspace(U)
@@ -235,6 +237,19 @@ class Engine:
             if check_counts and int(counts.max().item()) > N:
                 raise ValueError("preintegrate_stream: a window has %d intervals, more than N = %d" % (int(counts.max().item()), N))
         return (out, counts) if return_counts else out
+
+    @staticmethod
+    def _stream_bound(stream, update_times):
+        """Longest window (whole intervals + a tail) that cutting `stream` at `update_times` can produce: the closed form of
+        the deque loop (GraphSolver_IMU.cpp:50-69; cpi_cut_windows_kernel) on the stamps, tail assumed."""
+        K, U = stream.shape[0], update_times.shape[0]
+        if K == 0 or U == 0:
+            return 1
+        c = torch.searchsorted(stream[:, 0].contiguous(), update_times, right=True)
+        fp = torch.zeros_like(c)
+        fp[1:] = (c[:-1] - 1).clamp_min(0)
+        m = torch.maximum((c - 1).clamp_min(0), fp) - fp
+        return max(1, min(int(m.max().item()) + 1, 65535))
 
     def stream_workspace(self, U):
         """Device workspace of preintegrate_stream for U windows (28 bytes per window; re-usable across calls)."""

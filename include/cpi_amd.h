@@ -37,7 +37,11 @@ extern "C" {
                                round 3: cpi_preintegrate_stream (+ _workspace_bytes, _counts), cpi_tile_windows,
                                cpi_assemble_tiles, cpi_preintegrate_tiled_batch_host,
                                cpi_outputs_slab_doubles / _bind_slab, cpi_group_last_gather_messages,
-                               cpi_preintegrate_stream_host */
+                               cpi_preintegrate_stream_host;
+                               round 4, a CONTRACT change without a new symbol: after cpi_preintegrate_stream the workspace
+                               holds the true interval counts (cpi_stream_counts) and NOTHING ELSE a caller may read -- a
+                               mean-only request runs no cut kernel, so the first / tstart / tend records round 3 left there
+                               are no longer written (they were never declared) */
 
 enum { CPI_OK = 0, CPI_ERR_INVALID = 1, CPI_ERR_HIP = 2, CPI_ERR_NO_DEVICE = 3, CPI_ERR_RCCL = 4 };
 enum {

@@ -42,12 +42,48 @@ int main(int argc, char **argv) {
                     cpi->feed_IMU(a[0], b[0], {{a[1], a[2], a[3]}}, {{a[4], a[5], a[6]}}, {{b[1], b[2], b[3]}}, {{b[4], b[5], b[6]}});
             }
             wins.push_back(cpi);
-            if (w == 0) cpi->finalize(ctx); else batch.add(cpi);   // both paths: single-window and batched
+            // three paths: explicit finalize(ctx), NOTHING (window 1: the members compute themselves on first read, on the
+            // process's default context -- the caller shape of GraphSolver_IMU.cpp:43-75, no added line), batched
+            if (w == 0) cpi->finalize(ctx); else if (w != 1) batch.add(cpi);
         }
         batch.flush(ctx);
+        if (W > 1 && model != 3) {
+            // window 1 again, written like createimufactor_cpi_v1 / _v2: ctor, setLinearizationPoints, the feed_IMU loop, then the
+            // factor straight from the members with the reference's own argument list (GraphSolver_IMU.cpp:74-75 / 129-130) --
+            // and a read between two feed_IMU calls sees the state after the calls so far (CpiBase.h:99-124 are live members)
+            const double *l = &lin[6], *qq = &q[4], *k = &kn[(size_t)(n + 1) * 7];
+            CpiV1 c1(0.005, 4e-6, 0.01, 2e-4);
+            CpiV2 c2(0.005, 4e-6, 0.01, 2e-4);
+            CpiBase &cpi = (model == 1) ? (CpiBase &)c1 : (CpiBase &)c2;
+            cpi.setLinearizationPoints({{l[0], l[1], l[2]}}, {{l[3], l[4], l[5]}}, {{qq[0], qq[1], qq[2], qq[3]}}, {{0, 0, 9.8}});
+            cpi.imu_avg = false;
+            double dt_half = -1, dt_sum = 0;
+            for (int i = 0; i < n; i++) {
+                const double *a = k + 7 * i, *b = k + 7 * (i + 1);
+                if (b[0] - a[0] >= 0) { cpi.feed_IMU(a[0], b[0], {{a[1], a[2], a[3]}}, {{a[4], a[5], a[6]}}, {{b[1], b[2], b[3]}}, {{b[4], b[5], b[6]}}); dt_sum += b[0] - a[0]; }
+                if (i == n / 2) { dt_half = cpi.DT; if (!(dt_half > 0) || dt_half > dt_sum + 1e-12 || dt_half < dt_sum - 1e-12) { fprintf(stderr, "mid-window read: DT %.17g, fed %.17g\n", dt_half, dt_sum); return 1; } }
+            }
+            ImuFactorCPI fac = (model == 1)
+                ? ImuFactorCPI(cpi.P_meas, cpi.DT, cpi.grav, cpi.alpha_tau, cpi.beta_tau, cpi.q_k2tau, cpi.b_a_lin, cpi.b_w_lin, cpi.J_q, cpi.J_b,
+                               cpi.J_a, cpi.H_b, cpi.H_a)
+                : ImuFactorCPI(cpi.P_meas, cpi.DT, cpi.grav, cpi.alpha_tau, cpi.beta_tau, cpi.q_k2tau, cpi.q_k_lin, cpi.b_a_lin, cpi.b_w_lin, cpi.J_q,
+                               cpi.J_b, cpi.J_a, cpi.H_b, cpi.H_a, cpi.O_b, cpi.O_a);
+            ImuFactorCPI ref(*wins[1]);
+            double xi[16] = { qq[0], qq[1], qq[2], qq[3], l[0], l[1], l[2], 0.3, -0.2, 0.1, l[3], l[4], l[5], 1, 2, 3 };
+            double xj[16] = { qq[0], qq[1], qq[2], qq[3], l[0] + 1e-3, l[1], l[2] - 2e-3, 0.35, -0.1, 0.1, l[3], l[4] + 1e-2, l[5], 1.1, 2.2, 2.9 };
+            double e1[15], e2[15], Ha[225], Hb[225], Hc[225], Hd[225];
+            fac.evaluateError(ctx, xi, xj, e1, Ha, Hb);
+            ref.evaluateError(ctx, xi, xj, e2, Hc, Hd);
+            for (int i = 0; i < 15; i++) if (e1[i] != e2[i]) { fprintf(stderr, "reference-shaped factor: err[%d] %.17g vs %.17g\n", i, e1[i], e2[i]); return 1; }
+            for (int i = 0; i < 225; i++) if (Ha[i] != Hc[i] || Hb[i] != Hd[i]) { fprintf(stderr, "reference-shaped factor: H[%d] differs\n", i); return 1; }
+            CpiBase copy(cpi);                                       // copies re-bind the lazy members to the copy
+            copy.feed_IMU(k[7 * n], k[7 * n] + 0.005, {{0, 0, 0}}, {{0, 0, 9.8}});
+            if (!((double)copy.DT > (double)cpi.DT)) { fprintf(stderr, "copy: DT %.17g vs %.17g\n", (double)copy.DT, (double)cpi.DT); return 1; }
+            printf("SHAPE ok %.17g\n", dt_half);
+        }
         for (int w = 0; w < W; w++) {
             const CpiBase &c = *wins[w];
-            printf("%.17g", c.DT);
+            printf("%.17g", (double)c.DT);
             for (double v : c.alpha_tau) printf(" %.17g", v);
             for (double v : c.beta_tau) printf(" %.17g", v);
             for (double v : c.q_k2tau) printf(" %.17g", v);
@@ -77,7 +113,7 @@ int main(int argc, char **argv) {
             means.flush_means(ctx);
             for (int w = 0; w < W; w++) {
                 const CpiBase &c = *wins[w];
-                printf("MEAN %.17g", c.DT);
+                printf("MEAN %.17g", (double)c.DT);
                 for (double v : c.alpha_tau) printf(" %.17g", v);
                 for (double v : c.beta_tau) printf(" %.17g", v);
                 for (double v : c.q_k2tau) printf(" %.17g", v);

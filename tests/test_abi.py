@@ -69,6 +69,38 @@ def test_no_cpu_fallback():
         cpi_amd.Engine()
 
 
+def _load_in_subprocess(prelude, env=None):
+    import subprocess
+    import sys
+    code = "import sys, warnings; sys.path.insert(0, %r)\nfrom cpi_amd import build, _lib\n%s\nlib = _lib.load(); print('LOADED', lib.cpi_build_id().decode())" % (ROOT, prelude)
+    e = dict(os.environ)
+    e.pop("CPI_AMD_LIB", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, "-W", "always", "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+
+
+def test_a_library_built_from_other_sources_is_refused():
+    """a same-ABI library with old kernels must not pass the loader.  (i) a failing compile propagates instead of
+    falling back to the library that is there; (ii) without a compiler, a library whose cpi_build_id() differs from the tree's
+    source id is refused, unless CPI_AMD_ALLOW_STALE=1 says otherwise; (iii) without a compiler, the library of THIS tree loads."""
+    from cpi_amd import _lib
+    _lib.load()                                             # the in-tree library exists and is fresh from here on
+    # (i) the tree looks edited and the compiler fails: RuntimeError from the build, not a warning
+    r = _load_in_subprocess("build.stale = lambda *a, **k: True\n"
+                            "def boom(*a, **k): raise RuntimeError('hipcc failed on cpi_mean.hip')\nbuild.build = boom")
+    assert r.returncode != 0 and "hipcc failed on cpi_mean.hip" in r.stderr and "LOADED" not in r.stdout
+    # (ii) no compiler, and the tree's sources hash differently from what the library was built from
+    no_cc = ("build.stale = lambda *a, **k: True\n"
+             "def nocc(*a, **k): raise FileNotFoundError(2, 'No such file or directory', build.HIPCC)\nbuild.build = nocc\n")
+    r = _load_in_subprocess(no_cc + "build.source_id = lambda *a, **k: '0123456789abcdef'")
+    assert r.returncode != 0 and "built from other sources" in r.stderr and "LOADED" not in r.stdout
+    r = _load_in_subprocess(no_cc + "build.source_id = lambda *a, **k: '0123456789abcdef'", env={"CPI_AMD_ALLOW_STALE": "1"})
+    assert r.returncode == 0 and "LOADED" in r.stdout and "loaded anyway" in r.stderr
+    # (iii) no compiler, sidecar lost, but the library IS this tree's build
+    r = _load_in_subprocess(no_cc)
+    assert r.returncode == 0 and "LOADED" in r.stdout, r.stderr
+
+
 def test_product_never_imports_oracle():
     """Neither the product package nor its development tools nor the C-ABI header may reference the oracle (test
     infrastructure): only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do."""

@@ -37,6 +37,11 @@ def test_cpp_facade_vs_golden(exe, golden_dir, model):
     p = subprocess.run([exe, path, str(model)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     lines = p.stdout.strip().split("\n")
+    # the unchanged caller shape: no finalize() between the feed_IMU loop and the factor built from the
+    # members with the reference's argument list; a read between two feed_IMU calls; copies -- checked inside the program
+    shape = [ln for ln in lines if ln.startswith("SHAPE")]
+    assert len(shape) == 1 and shape[0].startswith("SHAPE ok"), p.stdout[:400]
+    lines = [ln for ln in lines if not ln.startswith("SHAPE")]
     rows = np.array([[float(x) for x in ln.split()] for ln in lines[:W]])
     names = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9), ("H_a", 9), ("H_b", 9),
              ("O_a", 9), ("O_b", 9), ("P", 225)]

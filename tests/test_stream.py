@@ -58,6 +58,20 @@ def test_assembly_equals_reference_deque_loop(mode):
     assert abs(ref["DT"].sum() - (ut[-1] - kn[0, 0])) < 1e-9
 
 
+def test_default_interval_bound_of_the_stream_entry_is_the_longest_window():
+    """Engine.preintegrate_stream without N: the bound is computed from the stamps (the library picks the mean
+    kernel's lane split from N; the old default -- the whole stream -- was as loose as a bound gets).  It must never be below a
+    true count (a longer window would be truncated) and is at most one above the longest (the tail is assumed)."""
+    import torch
+    from cpi_amd.engine import Engine
+    kn = st.parse_imu_text(open(DATA).read())
+    for ut in (_updates(kn), np.array([kn[0, 0] - 1.0, kn[3, 0], kn[3, 0], kn[400, 0] + 1e-4, kn[-1, 0] + 5.0]), kn[:1, 0] + 100.0):
+        _, _, count = st.assemble_windows(kn, ut)
+        b = Engine._stream_bound(torch.from_numpy(kn), torch.from_numpy(np.ascontiguousarray(ut)))
+        assert int(count.max()) <= b <= max(int(count.max()), 0) + 1, (b, count.max())
+    assert Engine._stream_bound(torch.zeros((0, 7), dtype=torch.float64), torch.zeros((3,), dtype=torch.float64)) == 1
+
+
 def test_cpp_twins_match_python():
     kn = st.parse_imu_text(open(DATA).read())
     ut = _updates(kn)
@@ -374,6 +388,80 @@ def test_gpu_stream_entry_large_batches_take_the_three_knot_kernel_bitwise(phase
     pick = torch.arange(0, W, 9973, device=eng.device)
     o = op.oracle().run(op.make_params(1, 1, 1), dense[pick].cpu().numpy(), lin[pick].cpu().numpy(), q[pick].cpu().numpy())
     check_pre({k: v[pick].cpu().numpy() for k, v in out.items()}, o, what=("mean",), label="BIG stream kernel, phase %.1f" % phase)
+
+
+def _torch_cut(stream, upd):
+    """The closed form of the deque loop (cpi_cut_windows_kernel / the fused cut), vectorised on the stream's device: ->
+    (knots [M, 7], first [U] int64, count [U] int32) in the CSR layout of st.assemble_windows.  Valid for non-decreasing stamps
+    and update times; the callers below hold its head against st.assemble_windows bit for bit before using it at full size."""
+    import torch
+    t = stream[:, 0].contiguous()
+    K, U = t.shape[0], upd.shape[0]
+    cT = torch.searchsorted(t, upd, right=True)
+    fp = torch.zeros_like(cT)
+    fp[1:] = (cT[:-1] - 1).clamp_min(0)
+    start = torch.cat([t[:1], torch.maximum(upd[:-1], t[0])])
+    fu = torch.maximum((cT - 1).clamp_min(0), fp)
+    m = fu - fp
+    front_t = torch.where(m > 0, t[fu], start)
+    tail = (upd - front_t) > 0
+    count = m + tail.long()
+    first = torch.cumsum(count + 1, 0) - (count + 1)
+    M = int((count + 1).sum().item())
+    u_of = torch.repeat_interleave(torch.arange(U, device=t.device), count + 1, output_size=M)
+    j = torch.arange(M, device=t.device) - first[u_of]
+    knots = stream[fp[u_of] + torch.minimum(j, m[u_of])].clone()
+    knots[first, 0] = start
+    last = first + count
+    knots[last[tail], 0] = upd[tail]
+    return knots.contiguous(), first.contiguous(), count.to(torch.int32).contiguous()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,W", [(1, 120000), (2, 720000)])
+def test_gpu_stream_entry_jittered_updates_three_knot_kernel_ragged_bitwise(model, W):
+    """the shipped cpi_mean_kernel<MODEL, false, AVG, 1, CUT = 2, BIG> instantiations on the grids a camera-rate
+    caller produces -- update times that are image stamps, not multiples of the IMU period: every window holds N - 2 ... N + 1
+    whole intervals plus (mostly) a tail, so NO wavefront has equally long lane-segments and every one runs BIG's per-element
+    staging path (the 32-bit offsets advanced per chunk, elements that stop at their own segment's last chunk).  Model 1 from
+    100 000 windows, model 2 from 700 000 (cpi_mean.hip: CPI_MEAN_BIG_W / CPI_MEAN_BIG_W_M2).  Expectation: the SAME windows in
+    the ragged CSR layout (knots, first, count) through cpi_preintegrate_batch -- the two-knot kernel; a CSR `first` array is
+    never admitted to BIG -- bit for bit, the counts exactly, and a strided sample against the oracle."""
+    import torch
+    import cpi_amd
+    from cpi_amd import synth
+    eng = cpi_amd.Engine()
+    N = 12
+    stream, upd, lin, q = synth.make_stream(W, N, seed=91 + model, device=eng.device, phase=0.37)
+    g = torch.Generator(device=eng.device); g.manual_seed(5)
+    upd = upd + (torch.rand(upd.shape, generator=g, dtype=torch.float64, device=eng.device) * 3.0 - 2.0) / 200.0   # -2 ... +1 samples
+    upd = torch.sort(upd).values.contiguous()
+    upd[7] = stream[7 * N + 3, 0]                                    # one update exactly ON a reading: no tail interval
+    upd = torch.sort(upd).values.contiguous()
+    knots, first, count = _torch_cut(stream, upd)
+    # the vectorised cut against the host assembler (the deque loop, pinned to the reference by the CPU tests above)
+    H = 3000
+    hk, hf, hc = st.assemble_windows(stream[: H * N + 4 * N].cpu().numpy(), upd[:H].cpu().numpy())
+    assert np.array_equal(hc, count[:H].cpu().numpy()) and np.array_equal(hf, first[:H].cpu().numpy())
+    assert np.array_equal(hk, knots[: hk.shape[0]].cpu().numpy())
+    cnt_np = count.cpu().numpy()
+    assert cnt_np.min() <= N - 1 and cnt_np.max() >= N + 2 and len(np.unique(cnt_np)) >= 4      # ragged for real
+    Nb = int(cnt_np.max())
+    for avg in (False, True):
+        prm = eng.make_params(model, avg, lanes_per_window=1)
+        out, cnt = eng.preintegrate_stream(stream, upd, lin, q, prm, want=("mean",), N=Nb, return_counts=True)
+        csr = eng.preintegrate(knots, lin, q, prm, want=("mean",), first=first, count=count, N=Nb)
+        torch.cuda.synchronize()
+        assert torch.equal(cnt.to(torch.int32), count), (model, avg)
+        for k in ("DT", "alpha", "beta", "q"):
+            assert torch.equal(out[k], csr[k]), (model, avg, k)
+    pick = torch.arange(0, W, 7919, device=eng.device)
+    pk = pick.cpu().numpy()
+    f_np, k_np = first.cpu().numpy(), knots
+    wins = [k_np[int(f_np[u]): int(f_np[u]) + int(cnt_np[u]) + 1].cpu().numpy() for u in pk]
+    oo = [op.oracle().run(op.make_params(model, 1, 1), w_[None], lin[u:u + 1].cpu().numpy(), q[u:u + 1].cpu().numpy()) for w_, u in zip(wins, pk)]
+    ref = {k: np.concatenate([o[k] for o in oo]) for k in ("DT", "alpha", "beta", "q")}
+    check_pre({k: out[k][pick].cpu().numpy() for k in ref}, ref, what=("mean",), v2=(model == 2), label="BIG stream kernel, jittered updates, model %d" % model)
 
 
 @pytest.mark.gpu

@@ -28,7 +28,13 @@ def run(eng, kn, lin, q, prm, cnt, N):
 def main():
     eng = cpi_amd.Engine(device=0)
     worst = 0.0
-    for (W, N, use_count) in ((64 * 20 + 37, 50, False), (64 * 9 + 5, 23, False), (64 * 6 + 1, 50, True), (700, 100, False), (64 * 4, 8, False)):
+    cases = [(64 * 20 + 37, 50, False), (64 * 9 + 5, 23, False), (64 * 6 + 1, 50, True), (700, 100, False), (64 * 4, 8, False)]
+    if os.environ.get("CPI_AMD_MEAN_LINE"):
+        # cpi_mean_line_kernel takes the leading whole groups of 64 P windows (P = phase classes of the window stride): batches of
+        # several groups + a tail for P = 16 (N = 50, 100), P = 4 (N = 51: 7 x 52 = 4 x 91), P = 2 (N = 9: 70), P = 1 (N = 15: 112)
+        cases = [(1024 * 3 + 37, 50, False), (1024 * 2 + 1, 100, False), (256 * 5 + 70, 51, False), (128 * 9, 9, False),
+                 (64 * 21 + 3, 15, False), (1024 + 5, 50, True)]
+    for (W, N, use_count) in cases:
         kn, lin, q = synth.make_windows(W, N, seed=77 + W + N, device=eng.device)
         cnt = None
         if use_count:
@@ -53,7 +59,8 @@ def main():
                     e = float(np.abs(out[k] - ref[k]).max())
                     worst = max(worst, e)
                     assert e < 1e-11, (W, N, model, avg, k, e)
-    print("dma_check ok cfg=%s worst=%.3e" % (os.environ.get("CPI_AMD_MEAN_DMA", "default"), worst), flush=True)
+    cfg = ",".join("%s=%s" % (k[8:], os.environ[k]) for k in ("CPI_AMD_MEAN_DMA", "CPI_AMD_MEAN_BLK", "CPI_AMD_MEAN_LINE") if os.environ.get(k))
+    print("dma_check ok cfg=%s worst=%.3e" % (cfg or "default", worst), flush=True)
 
 
 if __name__ == "__main__":
