@@ -52,7 +52,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernels are VALU / LDS-bound
 MALL_BYTES = 256 << 20
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 
 # name -> kind, model, default units per step, samples, algorithmic HBM bytes per unit at 50 samples (SURVEY.md 8(d):
 # read + write, f64, compulsory traffic only), dominant kernel.  kinds: "pre" preintegration (dense layout), "tiled" the
@@ -557,7 +557,7 @@ def sparse_port_rate(wl, kn, lin, q, cores, seconds):
 
 # ------------------------------------------------------------------------------------------------ counters
 def load_pmc(build_id):
-    """profiles/r04_pmc.json: rocprofv3 --pmc passes of tools/pmc_collect.sh, stamped with the build id of the library
+    """profiles/r05_pmc.json: rocprofv3 --pmc passes of tools/pmc_collect.sh, stamped with the build id of the library
     they were collected on.  Used only when that stamp equals the LOADED library's cpi_build_id(); otherwise the
     counter-derived fields are null (the file is stale for this library)."""
     try:
@@ -601,33 +601,40 @@ def roofline_of(name, W, N, launch_s, pmc_rows, pmc_note):
     return r
 
 
-def overlapped_rate(W, N, nctx, steps):
-    """Whole-job rate when independent batches are issued round-robin through nctx engine contexts (one HIP stream
-    each, cpi_amd.EnginePool), so that consecutive launches overlap.  Reported as an `extra` row only: with overlapping
-    launches the duration of one launch is no longer the inverse of the throughput, which is what the roofline line
-    is defined on."""
+def overlapped_rate(W, N, nctxs, steps):
+    """Whole-job rate when independent batches are issued round-robin through several engine contexts (one HIP stream each,
+    cpi_amd.EnginePool), so that consecutive launches overlap -- the one route to north_star's 40 % of the HBM roof at
+    configs[1]'s 10 000 windows per launch.  With overlapping launches the duration of one launch is no longer the inverse of the
+    throughput (which is what `roofline` is defined on), so this is reported as its own object (`overlapped`): seconds per
+    batch = wall time of `steps` batches / steps, for every context count of `nctxs`.  Same pool of > 256 MiB of distinct batches
+    as the headline."""
     import cpi_amd
     from cpi_amd import synth
     dev = torch.device("cuda", torch.cuda.current_device())
-    pool = cpi_amd.EnginePool(nctx, device=dev)
-    nb = max(nctx, -(-(MALL_BYTES * 5 // 4) // (W * (N + 1) * 56)))
+    nmax = max(nctxs)
+    pool = cpi_amd.EnginePool(nmax, device=dev)
+    nb = max(nmax, -(-(MALL_BYTES * 5 // 4) // (W * (N + 1) * 56)))
     batches = [synth.make_windows(W, N, seed=977 + b, device=dev) for b in range(nb)]
-    outs = [pool.engines[0].alloc_outputs(W, ("mean",), 1) for _ in range(2 * nctx)]
+    outs = [pool.engines[0].alloc_outputs(W, ("mean",), 1) for _ in range(2 * nmax)]
     prm = pool.engines[0].make_params(1)
-
-    def go(k):
-        for i in range(k):
-            kn, lin, q = batches[i % nb]
-            pool.engines[i % nctx].preintegrate(kn, lin, q, prm, want=("mean",), out=outs[i % len(outs)])
-    torch.cuda.synchronize()
-    go(max(50, steps // 10))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    go(steps)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    per = {}
+    for nctx in nctxs:
+        def go(k):
+            for i in range(k):
+                kn, lin, q = batches[i % nb]
+                pool.engines[i % nctx].preintegrate(kn, lin, q, prm, want=("mean",), out=outs[i % len(outs)])
+        torch.cuda.synchronize()
+        go(max(50, steps // 10))
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            go(steps)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / steps)
+        per[nctx] = best
     pool.close()
-    return wall / steps
+    return per
 
 
 # ------------------------------------------------------------------------------------------------ launch
@@ -758,7 +765,20 @@ def main():
         # batch alone takes 8.2 us = 0.45); said here, in the line, not only in prose
         res["goal_40pct_hbm"] = bool(res["roofline"]["frac"] >= 0.40)
         res["goal_note"] = ("north_star asks >= 0.40 of 8 TB/s: reached from ~17 k windows per launch (30 k: 0.46-0.48, 1 M: 0.55-0.64) or "
-                            "with 3 batches in flight (0.43); one 10 k-window launch is launch / first-burst bound")
+                            "with several batches in flight (`overlapped`, measured in this run); one 10 k-window launch is launch / first-burst bound")
+        if rank == 0 and world == 1 and not a.no_extra and W == 10000:
+            # the same workload issued through 2 / 3 / 4 engine contexts (HIP streams): consecutive launches overlap
+            try:
+                per = overlapped_rate(W, N, (2, 3, 4), 3000)
+                bpb = bytes_per_unit("v1_mean", N) * W
+                res["overlapped"] = {"contexts": 3, "value": W / per[3], "unit": "windows/s", "ms_per_batch": per[3] * 1e3,
+                                     "frac": bpb / per[3] / 1e9 / HBM_PEAK_GBS, "batches": 3000,
+                                     "frac_by_contexts": {str(k): round(bpb / v / 1e9 / HBM_PEAK_GBS, 4) for k, v in per.items()},
+                                     "how": "independent batches round-robin over N engine contexts (one HIP stream each, eager launches, "
+                                            "host wall clock / batches): an aggregate rate, not a launch duration"}
+                res["goal_40pct_hbm_overlapped"] = bool(res["overlapped"]["frac"] >= 0.40)
+            except Exception as ex:       # an additional object must never cost the line
+                res["overlapped"] = {"error": repr(ex)}
     if dist_on:
         import torch.distributed as dist
         res["config"]["gather_schedule"] = schedule if do_gather else "none"
@@ -775,6 +795,16 @@ def main():
     if wall_ng is not None:
         res["config"]["value_without_gather"] = total_units * a.steps / wall_ng
         res["config"]["ms_final_gather"] = max(0.0, (wall - wall_ng) * 1e3)
+    if world > 1:
+        # a collective-latency-shaped `value` explains itself: how long the timed region is, and how much of it is the exchange
+        share = (gather_ms / (wall * 1e3)) if (do_gather and wall > 0) else 0.0
+        res["config"]["scaling_note"] = (
+            "timed region %.3f ms = %d steps (%.3f ms of kernels, HIP events) + %.3f ms of exposed exchange (%.0f %% of the region; %s schedule): "
+            "%s  Scaling efficiency of the hot path itself: value_kernel_only / (n_gpus x the 1-GPU value); with the exchange: value." % (
+                wall * 1e3, a.steps, kern_ms, gather_ms, 100.0 * share, schedule if do_gather else "no",
+                ("the region is shorter than a collective's start-up on this fabric, so `value` measures the exchange, not the kernels -- "
+                 "the millisecond-scale rows (`--workload cfg5_mean`, `--scaling strong --workload v2_full`) are the ones a curve means something on."
+                 if wall * 1e3 < 2.0 else "the steps dominate the region.")))
     if do_gather and a.gather == "root":
         res["config"].update(verify_gather(eng, wl, tm, world, rank, base_seed, rehearsal))
     extra = None
@@ -805,15 +835,11 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as ex:  # an extra config must never take the headline down
                 extra.append({"workload": name, "units_per_step": Wx, "error": repr(ex)})
-        try:   # the headline workload again, issued through 3 contexts so that consecutive launches overlap
-            per = overlapped_rate(10000, 50, 3, 3000)
-            ach = bytes_per_unit("v1_mean", 50) * 10000 / per / 1e9
-            extra.append({"workload": "v1_mean_3ctx", "units_per_step": 10000, "value": 10000 / per, "unit": "windows/s",
-                          "contexts": 3, "us_per_batch": per * 1e6, "hbm_GBs": ach, "hbm_frac": ach / HBM_PEAK_GBS,
-                          "note": "independent batches round-robin over 3 engine contexts (3 HIP streams): launches "
-                                  "overlap, so this is an aggregate rate, not a per-launch duration"})
-        except Exception as ex:
-            extra.append({"workload": "v1_mean_3ctx", "units_per_step": 10000, "error": repr(ex)})
+        ov = res.get("overlapped", {})
+        if "value" in ov:
+            extra.append({"workload": "v1_mean_3ctx", "units_per_step": 10000, "value": ov["value"], "unit": "windows/s", "contexts": 3,
+                          "us_per_batch": ov["ms_per_batch"] * 1e3, "hbm_GBs": ov["frac"] * HBM_PEAK_GBS, "hbm_frac": ov["frac"],
+                          "note": "the headline's `overlapped` object: " + ov["how"]})
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -928,7 +954,7 @@ def emit(res, extra):
                 sys.stderr.write("bench.py: could not write %s (%r)\n" % (pth, ex))
         res["extra_file"] = "bench_extra.json (%d rows, each with roofline / counters / cpu_baseline)" % len(extra)
     line = json.dumps(res)
-    for drop in ("extra_rows", "routes_1M_x_50", "goal_note"):          # the contract: one line the driver can parse (< 6 KB)
+    for drop in ("extra_rows", "routes_1M_x_50", "goal_note", "extra_rows_key"):   # the contract: one line the driver can parse (< 6 KB)
         if len(line) < 6000:
             break
         res.pop(drop, None)

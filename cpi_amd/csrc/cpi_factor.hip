@@ -72,7 +72,7 @@ namespace launch {
 void factor(int model, bool whiten, int lpf, const FactorArgs &a, hipStream_t st) {
     const long long F = a.F;
 #define CPI_LAUNCH_FACTOR(M, WH, L) \
-    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, st, a)
+    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3(factor_grid((F + 64 / L - 1) / (64 / L))), dim3(64), 0, st, a)
 #define CPI_LAUNCH_FACTOR_L(M, WH) \
     do { if (lpf == 16) CPI_LAUNCH_FACTOR(M, WH, 16); else if (lpf == 8) CPI_LAUNCH_FACTOR(M, WH, 8); else CPI_LAUNCH_FACTOR(M, WH, 4); } while (0)
     if (whiten) {
@@ -86,20 +86,20 @@ void factor(int model, bool whiten, int lpf, const FactorArgs &a, hipStream_t st
 
 void factor_packed(int model, int lpf, const FactorArgs &a, double *packed, hipStream_t st) {
     const long long F = a.F;
-#define CPI_PACKED(M, L) hipLaunchKernelGGL((cpi_factor_packed_kernel<M, L>), dim3((unsigned)((F + 64 / L - 1) / (64 / L))), dim3(64), 0, st, a, packed)
+#define CPI_PACKED(M, L) hipLaunchKernelGGL((cpi_factor_packed_kernel<M, L>), dim3(factor_grid((F + 64 / L - 1) / (64 / L))), dim3(64), 0, st, a, packed)
     if (model == CPI_MODEL_V1) { if (lpf == 2) CPI_PACKED(1, 2); else if (lpf == 3) CPI_PACKED(1, 3); else if (lpf == 4) CPI_PACKED(1, 4); else if (lpf == 6) CPI_PACKED(1, 6); else CPI_PACKED(1, 8); }
     else                       { if (lpf == 2) CPI_PACKED(2, 2); else if (lpf == 3) CPI_PACKED(2, 3); else if (lpf == 4) CPI_PACKED(2, 4); else if (lpf == 6) CPI_PACKED(2, 6); else CPI_PACKED(2, 8); }
 #undef CPI_PACKED
 }
 
 void factor_hessian(int model, const FactorArgs &a, double *hess, hipStream_t st) {
-    const unsigned nb = (unsigned)((a.F + 3) / 4);
+    const unsigned nb = factor_grid((a.F + 3) / 4);
     if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_hessian_kernel<1>), dim3(nb), dim3(64), 0, st, a, hess);
     else hipLaunchKernelGGL((cpi_factor_hessian_kernel<2>), dim3(nb), dim3(64), 0, st, a, hess);
 }
 
 void sqrt_info(long long F, const double *P, double *R, hipStream_t st) {
-    hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3((unsigned)((F + 3) / 4)), dim3(64), 0, st, F, P, R);
+    hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3(factor_grid((F + 3) / 4)), dim3(64), 0, st, F, P, R);
 }
 
 void predict(int model, const PredictArgs &a, hipStream_t st) {

@@ -45,6 +45,24 @@ struct FieldFetch {
     }
 };
 
+// Workgroup -> group of factors.  CPI_FACTOR_XCD = 1: workgroup b runs on XCD b mod 8 (observed placement, for speed only), so
+// "group (b mod 8) * ceil(groups / 8) + b / 8" gives every XCD one contiguous eighth of the inputs and outputs (the launchers pad
+// the grid to a multiple of 8; surplus workgroups leave at once).  0: group = b.
+#ifndef CPI_FACTOR_XCD
+#define CPI_FACTOR_XCD 0
+#endif
+__device__ __forceinline__ long long factor_group_of_block(long long groups) {
+#if CPI_FACTOR_XCD
+    const long long per = (groups + 7) >> 3;
+    const long long g = (long long)(blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    return ((long long)(blockIdx.x >> 3) < per && g < groups) ? g : -1;
+#else
+    (void)groups;
+    return blockIdx.x;
+#endif
+}
+inline unsigned factor_grid(long long groups) { return CPI_FACTOR_XCD ? (unsigned)(((groups + 7) >> 3) << 3) : (unsigned)groups; }
+
 // Record layout of one factor in the LDS staging area (doubles)
 namespace fin {
 constexpr int O_ALPHA = 0, O_BETA = 3, O_Q = 6, O_LIN = 10, O_JQ = 16, O_JB = 25, O_JA = 34, O_HB = 43, O_HA = 52,
@@ -158,7 +176,9 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the factors' R
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = lane / LPF;
-    const long long f0 = (long long)blockIdx.x * FPW;
+    const long long grp = factor_group_of_block((A.F + FPW - 1) / FPW);
+    if (grp < 0) return;
+    const long long f0 = grp * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     constexpr bool whiten = WHITEN;
 
@@ -284,7 +304,9 @@ __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, dou
     __shared__ double sDummy[2];
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = min(lane / LPF, FPW - 1);   // 64 mod LPF spare lanes repeat the last factor's lane 0 (same values, same slots)
-    const long long f0 = (long long)blockIdx.x * FPW;
+    const long long grp = factor_group_of_block((A.F + FPW - 1) / FPW);
+    if (grp < 0) return;
+    const long long f0 = grp * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sIn, sDummy);
     __syncthreads();
@@ -396,7 +418,9 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
     constexpr int FPW = 4;
     __shared__ __attribute__((aligned(16))) double sA[FPW * 225];
     const int lane = threadIdx.x, j = lane & 15, fl = lane >> 4;
-    const long long f0 = (long long)blockIdx.x * FPW;
+    const long long grp = factor_group_of_block((F + FPW - 1) / FPW);
+    if (grp < 0) return;
+    const long long f0 = grp * FPW;
     const int nf = (int)min((long long)FPW, F - f0);
     struct __attribute__((packed, aligned(8))) d2u { double a, b; };
     {
@@ -537,7 +561,9 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
     double *sR = sAll + FPW * IN_D, *sTab = sAll + 2 * U1 - FPW * TAB_D;
     static_assert(FPW * IN_D + FPW * 225 <= 2 * U1 - FPW * TAB_D, "R sits between the records and the block tables");
     const int lane = threadIdx.x;
-    const long long f0 = (long long)blockIdx.x * FPW;
+    const long long grp = factor_group_of_block((A.F + FPW - 1) / FPW);
+    if (grp < 0) return;
+    const long long f0 = grp * FPW;
     const int nf = (int)min((long long)FPW, A.F - f0);
     const int q = lane & 15, f = min(lane >> 4, nf - 1);     // missing factors shadow the last one (same values, same slots)
     const int qr = min(q, 14);                               // lane 15 shadows row 14 in the row phase

@@ -21,6 +21,8 @@ def test_emit_keeps_the_last_line_under_6k_and_writes_the_rows(tmp_path, monkeyp
            "config": {"workload": "v1_mean: 10000 windows x 50 samples per GPU per step, CPI model 1, mean-only (BASELINE.json configs[1])",
                       "pool_batches": 12, "clock_preramp_ms": 60.0, "library_build": "0123456789abcdef", "launch_mode": "g" * 80, "parallelism": "1 GPU"},
            "roofline": bench.roofline_of("v1_mean", 10000, 50, 12.4e-6, {}, "no pmc"), "goal_40pct_hbm": False, "goal_note": "n" * 250,
+           "overlapped": {"contexts": 3, "value": 1.2e9, "unit": "windows/s", "ms_per_batch": 0.0084, "frac": 0.437, "batches": 3000,
+                          "frac_by_contexts": {"2": 0.4012, "3": 0.4371, "4": 0.4402}, "how": "h" * 170}, "goal_40pct_hbm_overlapped": True,
            "cpu_baseline": dict(_row("v1_mean", 10000)["cpu_baseline"], sample="s" * 200,
                                 sparse_port={"value": 3.2e6, "unit": "windows/s", "cores": 16, "kind": "port", "single_core_value": 2.1e5, "what": "w" * 60, "sample": "p" * 90})}
     extra = [_row(name, W) for name, W, _ in bench.EXTRA_ROWS]
@@ -37,6 +39,7 @@ def test_emit_keeps_the_last_line_under_6k_and_writes_the_rows(tmp_path, monkeyp
     assert r["configs2"]["value"] > 0 and r["configs2"]["fp64"]["useful_frac"] == 0.34 and r["configs2"]["cpu_baseline"]["kind"] == "reference"
     assert len(r["extra_rows"]) == len(extra) and r["extra_rows"]["broken@5"] == "error"
     assert r["routes_1M_x_50"]["dense_kernel_preassembled"] > 0
+    assert r["overlapped"]["frac"] == 0.437 and r["goal_40pct_hbm_overlapped"] is True
     doc = json.load(open(tmp_path / "bench_extra.json"))
     assert len(doc["rows"]) == len(extra) and doc["headline"]["value"] == 7.1e8 and "extra_rows" not in doc["headline"]
 

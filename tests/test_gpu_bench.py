@@ -57,6 +57,12 @@ def test_the_last_stdout_line_of_the_drivers_command_parses_and_is_small(driver_
     assert cb["single_core_value"] > 0 and 0 < len(cb["sample"]) <= 200 and cb["sparse_port"]["value"] > 0
     # the north-star's 40 % criterion is answered in the line itself
     assert r["goal_40pct_hbm"] == (rf["frac"] >= 0.40) and "17 k" in r["goal_note"]
+    # ... and so is the one route to it at this batch size: several batches in flight, MEASURED in the same run (round 5)
+    ov = r["overlapped"]
+    assert ov["contexts"] == 3 and ov["unit"] == "windows/s" and ov["value"] > r["value"] * 0.8 and ov["batches"] >= 1000
+    assert abs(ov["value"] * ov["ms_per_batch"] * 1e-3 / 10000 - 1.0) < 1e-9
+    assert abs(ov["frac"] - ov["value"] * rf["algorithmic_bytes_per_unit"] / 8e12) < 1e-9 and 0.1 < ov["frac"] < 1.0
+    assert set(ov["frac_by_contexts"]) == {"2", "3", "4"} and r["goal_40pct_hbm_overlapped"] == (ov["frac"] >= 0.40)
     # BASELINE configs[2] (V2 + covariance + Jacobians: the row the >= 10 M windows/s goal sits on) travels in the parsed part
     c2 = r["configs2"]
     assert "configs[2]" in c2["workload"] and c2["value"] > 1e7 and c2["goal_10M_windows_per_s"] is True and c2["launch_ms"] > 0
@@ -91,4 +97,4 @@ def test_no_extra_no_cpu_still_prints_one_contract_line():
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     r = json.loads(lines[0])
-    assert r["steps"] == 50 and "configs2" not in r and "cpu_baseline" not in r and r["roofline"]["frac"] > 0.05
+    assert r["steps"] == 50 and "configs2" not in r and "cpu_baseline" not in r and "overlapped" not in r and r["roofline"]["frac"] > 0.05

@@ -189,6 +189,45 @@ def test_cpp_host_sharding_a_batch_over_the_device_set(golden_dir):
         assert p5.stdout == p.stdout
 
 
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_gpus_4_and_8_the_drivers_first_multi_gpu_commands_rehearsed_on_one_gpu(n):
+    """The exact commands the driver issues for its scaling curve -- `bench.py --gpus N --steps 20 --warmup 5`, N = 4 and 8, all
+    defaults -- as a rehearsal on this 1-GPU box (CPI_BENCH_SINGLE_DEVICE=1: N ranks compute on cuda:0, the exchange goes through
+    gloo).  What must hold the first time real RCCL runs it holds here: the line parses, is < 6 KB, says n_gpus = N, every rank's
+    last-step slab arrives bitwise at rank 0 (CPI_BENCH_STRICT), the N pools of resident batches fit beside each other, the line
+    says how long the timed region is against the exchange (`scaling_note`), and the per-GPU share of BASELINE configs[4]
+    (`--workload cfg5_mean`: 1 M windows x 100 samples per rank) runs the pipelined schedule with N ranks' slabs verified."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["CPI_BENCH_SINGLE_DEVICE"] = "1"
+    env["CPI_BENCH_STRICT"] = "1"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    runs = [(["--gpus", str(n), "--steps", "20", "--warmup", "5"], 20, 10000, "final")]
+    if n == 8:
+        runs.append((["--gpus", str(n), "--steps", "3", "--warmup", "1", "--workload", "cfg5_mean", "--windows", "200000"], 3, 200000, "pipelined"))
+    for args, steps, W, sched in runs:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=1200, env=env, cwd=ROOT)
+        assert p.returncode == 0, "\n".join(ln for ln in p.stderr.splitlines() if "Traceback" in ln or "Error" in ln or "bench.py" in ln or "assert" in ln)[-3000:]
+        lines = [ln for ln in p.stdout.strip().splitlines() if ln.strip()]
+        line = lines[-1]
+        assert line.startswith("{") and len(line) < 6000, (len(line), line[:200])
+        d = json.loads(line)
+        assert d["n_gpus"] == n and d["steps"] == steps and d["value"] > 0 and d["scaling"] == "weak" and "REHEARSAL" in d["data"]
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (n * W) - 1.0) < 1e-6          # whole-job aggregate: N ranks x W windows per step
+        c = d["config"]
+        assert c["rccl"]["backend"] == "gloo" and c["rccl"]["world_size"] == n and sorted(r[0] for r in c["rccl"]["ranks"]) == list(range(n))
+        assert c["gather_schedule"] == sched and c["gather_verified"] is True and "bitwise" in c["gather_verified_how"]
+        assert c["value_kernel_only"] >= d["value"] and c["value_without_gather"] > 0
+        assert "timed region" in c["scaling_note"] and "exchange" in c["scaling_note"] and len(c["scaling_note"]) < 700
+        assert "roofline" in d and "cpu_baseline" not in d and "overlapped" not in d       # rank 0 at N = 1 only
+
+
 def test_cpp_host_threads_one_context_each(golden_dir):
     """tests/cpp/test_threads.cpp: four host threads, one context each, run the host-pointer preintegration (pipelined
     staging owned by the context) and the factor sweep concurrently; each must match the single-threaded run bit for bit."""

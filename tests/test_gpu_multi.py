@@ -4,7 +4,7 @@ the suite -- they VALIDATE (bitwise against the unsharded call) instead of merel
 
   * the single-process device set of the C-ABI (cpi_group_create -> ncclCommInitAll on distinct devices, cpi_group_gather:
     one ncclSend per peer straight to the root) -- tests/tools/group_real_check.py;
-  * `python bench.py --gpus 2` with no rehearsal switch: one rank per GPU over ProcessGroupNCCL, `config.rccl` says what the
+  * `python bench.py --gpus N` (N = 2, 4 and every device of the node) with no rehearsal switch: one rank per GPU over ProcessGroupNCCL, `config.rccl` says what the
     collective library saw, rank 0 recomputes every rank's last-step batch and compares the gathered blocks bitwise
     (`config.gather_verified`), and the line separates kernel time from the collective tail (`value_kernel_only`)."""
 import json
@@ -29,27 +29,32 @@ def _env():
     return env
 
 
-@pytest.mark.parametrize("n", sorted({2, NDEV}) if NDEV >= 2 else [2])
+NS = sorted(x for x in {2, 4, NDEV} if 2 <= x <= max(NDEV, 2))     # an 8-GPU node also checks the intermediate points of the curve
+
+
+@pytest.mark.parametrize("n", NS)
 def test_device_set_on_real_rccl_reproduces_the_unsharded_call_bitwise(n):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "group_real_check.py"), str(n)], env=_env(),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0 and "group_real_check ok" in p.stdout, p.stdout[-3000:]
 
 
-@pytest.mark.parametrize("extra", [[], ["--workload", "v2_full", "--windows", "20000", "--scaling", "strong"], ["--workload", "v1_full", "--windows", "30000"]])
-def test_bench_gpus_2_on_real_rccl_validates_what_it_gathers(extra):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"] + extra,
+@pytest.mark.parametrize("n", NS)
+@pytest.mark.parametrize("extra", [[], ["--workload", "v2_full", "--windows", "20000", "--scaling", "strong"], ["--workload", "v1_full", "--windows", "30000"],
+                                   ["--workload", "cfg5_mean", "--windows", "200000"]])
+def test_bench_gpus_n_on_real_rccl_validates_what_it_gathers(n, extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "20", "--warmup", "5"] + extra,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=_env(), cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [ln for ln in p.stdout.strip().splitlines() if ln.strip()][-1]
     assert len(line) < 6000
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 20 and "REHEARSAL" not in d["data"] and d["data"] == "synthetic"
+    assert d["n_gpus"] == n and d["value"] > 0 and d["steps"] == 20 and "REHEARSAL" not in d["data"] and d["data"] == "synthetic"
     c = d["config"]
     rc = c["rccl"]
-    assert rc["backend"] == "nccl" and rc["world_size"] == 2 and rc["distinct_devices"] == 2 and rc["nccl_version"]
-    assert sorted(r[0] for r in rc["ranks"]) == [0, 1] and sorted(r[1] for r in rc["ranks"]) == [0, 1]
+    assert rc["backend"] == "nccl" and rc["world_size"] == n and rc["distinct_devices"] == n and rc["nccl_version"]
+    assert sorted(r[0] for r in rc["ranks"]) == list(range(n)) and sorted(r[1] for r in rc["ranks"]) == list(range(n))
     assert c["gather_verified"] is True and "bitwise" in c["gather_verified_how"]
     assert c["value_kernel_only"] >= d["value"] and c["value_without_gather"] > 0
     assert c["kernel_ms"] > 0 and c["gather_ms"] > 0 and c["wall_ms"] >= c["kernel_ms"] * 0.99
-    assert d["scaling"] == ("strong" if "strong" in extra else "weak")
+    assert d["scaling"] == ("strong" if "strong" in extra else "weak") and "timed region" in c["scaling_note"]

@@ -60,6 +60,17 @@ __global__ __launch_bounds__(64) void k_mixed(const d2 *src, d2 *dst, long long 
     for (long long i = threadIdx.x; i < rd16; i += 64) { const d2 v = src[blk * rd16 + i]; acc += v.x + v.y; }
     for (long long i = threadIdx.x; i < wr16; i += 64) dst[blk * wr16 + i] = d2{acc, 2.0 + (double)i};
 }
+// the same copy with all loads of the wavefront in flight before the first store (the sweeps' one round trip) and non-temporal stores
+__global__ __launch_bounds__(64, 2) void k_mixed_nt(const d2 *src, d2 *dst, long long rd16, long long wr16, unsigned nblocks) {
+    const long long blk = blockIdx.x;
+    d2 v[11];
+#pragma unroll
+    for (int u = 0; u < 11; u++) { const long long i = threadIdx.x + 64 * u; v[u] = src[blk * rd16 + (i < rd16 ? i : rd16 - 1)]; }
+    double acc = 0;
+#pragma unroll
+    for (int u = 0; u < 11; u++) acc += v[u].x + v[u].y;
+    for (long long i = threadIdx.x; i < wr16; i += 64) __builtin_nontemporal_store(d2{acc, 2.0 + (double)i}, dst + blk * wr16 + i);
+}
 // grid-stride, 256-thread blocks (the classic memset shape)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_grid(d2 *dst, long long total16) {
@@ -138,6 +149,29 @@ int main() {
         };
         t2("MIXED 6.2 KB in / 29.8 KB out, consecutive", [&] { hipLaunchKernelGGL(k_mixed<0>, dim3(nb), dim3(64), 0, 0, src, p, rd16, wr16, nb); });
         t2("MIXED 6.2 KB in / 29.8 KB out, XCD-contig.", [&] { hipLaunchKernelGGL(k_mixed<1>, dim3((nb + 7) / 8 * 8), dim3(64), 0, 0, src, p, rd16, wr16, nb); });
+    }
+    // round 5: the mixes of the whitened sweep (4 factors per wavefront: 4 x (776 + 1 800) B in, 4 x 3 720 B out) and of the Hessian
+    // sweep (4 x 2 576 in, 4 x 3 968 out), 200 000 wavefronts -- is 0.57-0.62 of 8 TB/s the ceiling of a 1 : 1.5 read : write copy?
+    for (int which = 0; which < 2; which++) {
+        const long long rd16 = 10304 / 16, wr16 = (which == 0 ? 14880 : 15872) / 16;
+        const unsigned nb = 200000;                       // 200 000 x 15 872 B = 3.17 GB of the 3 600-MiB destination
+        d2 *src;
+        if (hipMalloc(&src, (size_t)nb * rd16 * 16) != hipSuccess) return 1;
+        hipMemset(src, 0, (size_t)nb * rd16 * 16);
+        const double gb = (double)nb * (rd16 + wr16) * 16;
+        auto t3 = [&](const char *name, auto launch) {
+            launch(); hipDeviceSynchronize();
+            hipEventRecord(e0);
+            for (int r = 0; r < 5; r++) launch();
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-52s %8.3f ms  %6.2f TB/s (read + write) = %.3f of 8 TB/s\n", name, ms / 5, gb / (ms / 5 * 1e-3) / 1e12, gb / (ms / 5 * 1e-3) / 8e12);
+        };
+        t3(which == 0 ? "MIXED whitened sweep 10.3 KB in / 14.9 KB out" : "MIXED Hessian sweep 10.3 KB in / 15.9 KB out",
+           [&] { hipLaunchKernelGGL(k_mixed<0>, dim3(nb), dim3(64), 0, 0, src, p, rd16, wr16, nb); });
+        t3(which == 0 ? "  the same, non-temporal stores" : "  the same, non-temporal stores",
+           [&] { hipLaunchKernelGGL(k_mixed_nt, dim3(nb), dim3(64), 0, 0, src, p, rd16, wr16, nb); });
+        hipFree(src);
     }
     timeit("hipMemsetAsync 0xff", [&] { hipMemsetAsync(p, 0xff, bytes, 0); });
     for (unsigned nb : {65536u}) {
