@@ -645,13 +645,14 @@ __global__ __launch_bounds__(256) void cpi_cut_windows_kernel(long long K, const
 //     rate), line-aligned 512-byte trips with a carry for the straddling knot, rows stored out of step (reads 1.14 x, writes
 //     + 29 %: 1.40 ms) or in step with a 320-byte carry (traffic 1.05 x in total, but 54 KB of LDS = 3 wavefronts per CU:
 //     1.34 ms).  Commit "experiment (not shipped): line-aligned assembler" holds the last of them.
+//   * round 5: the next trip's LDS-DMA issued under the current trip's row stores (4 rows per trip, two 17-KB images, the landing
+//     waited for as vmcnt(28) on exact store counts): reads 1.36 x -> 1.16 x, latency hidden, 1.13-1.16 ms -- the SAME time
+//     (profiles/r05_assembler.md; commit "experiment (not shipped): assembler with the next trip's DMA under the row stores").
+//     5.0 TB/s of algorithmic read + write is what a 1 : 1 copy of 448-byte pieces into 512-byte rows gets on this memory system.
 // The DMA route needs the wavefront's windows within 2^24 knots above the first one and K >= RB (wave-uniform test); any
 // other wavefront takes the per-lane loads of round 3.
-#ifndef CPI_ASM_PIPE
-#define CPI_ASM_PIPE 0                      // 1: the wavefront-internal pipeline measured in round 5 (RB = 4, two images)
-#endif
 #ifndef CPI_ASM_RB
-#define CPI_ASM_RB (CPI_ASM_PIPE ? 4 : 8)
+#define CPI_ASM_RB 8
 #endif
 __global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) {
     constexpr int RB = CPI_ASM_RB;              // rows per trip
@@ -660,8 +661,7 @@ __global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) 
     constexpr int NI = 64 / WPI;                // DMA instructions per trip: 32
     constexpr int IMG = (RB == 8) ? 1040 : 1072;   // bytes between instruction images: 2-way (RB = 8) / 3-way (RB = 4) read conflicts, the minima of these placements
     static_assert((RB == 8 && WPI == 2) || (RB == 4 && WPI == 4), "RB = 8: two windows per instruction; RB = 4: four");
-    constexpr int NBUF = CPI_ASM_PIPE ? 2 : 1;
-    __shared__ __attribute__((aligned(1024))) char img[NBUF * NI * IMG];
+    __shared__ __attribute__((aligned(1024))) char img[NI * IMG];
     __shared__ int srel[64];
     const int lane = threadIdx.x;
     const long long u = (long long)blockIdx.x * 64 + lane;
@@ -698,64 +698,6 @@ __global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) 
         const int dp = (lane < PPW * WPI) ? lane - dw * PPW : 0;
         const unsigned img_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)img);
         const char *mine = img + (lane / WPI) * IMG + (lane % WPI) * (PPW * 16);   // this lane's window in the image
-#if CPI_ASM_PIPE
-        // Round 5: the next trip's LDS-DMA under the current trip's row stores.  Loads and stores share ONE
-        // in-order counter on gfx9 (vmcnt), so "trip t + 1 has landed" can only be waited for as "at most S operations are
-        // younger", S = the row stores issued since -- exact only when every lane stored every row of the trip (wave-uniform
-        // test; otherwise the next wait is a full drain).  Measured: profiles/r05_assembler.md.
-        static_assert(RB == 4, "two images fit beside four wavefronts per CU only with four rows per trip");
-        constexpr int STORES = RB * 7;
-        auto issue = [&](int r0, int buf) -> long long {
-            const long long st = min(fp + (long long)min(r0, m), A.K - RB);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads of this image's previous contents have retired
-            srel[lane] = (int)(st - base);
-            wave_lds_fence();
-            unsigned so[NI];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) so[j] = (unsigned)srel[j * WPI + dw];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) glds16(so[j] * 56u + (unsigned)dp * 16u, sbase, img_base + buf * (NI * IMG) + j * IMG);
-            return st;
-        };
-        long long st_cur = issue(0, 0);
-        bool counted = false;                                         // the previous trip issued exactly STORES stores
-        int buf = 0;
-        for (int r0 = 0; r0 <= rmax; r0 += RB, buf ^= 1) {
-            if (counted) wait_vmcnt<STORES>(); else wait_vmcnt<0>();
-            wave_lds_fence();
-            long long st_next = st_cur;
-            if (r0 + RB <= rmax) st_next = issue(r0 + RB, buf ^ 1);
-            const bool full = __all(r0 + RB - 1 <= rows);
-            const char *img_mine = mine + buf * (NI * IMG);
-            double v[RB][7];
-#pragma unroll
-            for (int i = 0; i < RB; i++) {
-                const int r = r0 + i;
-                const int jj = (int)(fp + (long long)min(r, m) - st_cur);
-                const double *src = reinterpret_cast<const double *>(img_mine + min(max(jj, 0), RB - 1) * 56);
-#pragma unroll
-                for (int k = 0; k < 7; k++) v[i][k] = src[k];
-                if (r == 0) v[i][0] = start_t;
-                if (tail && r == m + 1) v[i][0] = T;
-            }
-            if (full) {                                               // wave-uniform: STORES store instructions, all lanes
-#pragma unroll
-                for (int i = 0; i < RB; i++)
-#pragma unroll
-                    for (int k = 0; k < 7; k++) __builtin_nontemporal_store(v[i][k], tb + (long long)(r0 + i) * A.ss + k * 64);
-            } else {
-#pragma unroll
-                for (int i = 0; i < RB; i++)
-                    if (r0 + i <= rows) {
-#pragma unroll
-                        for (int k = 0; k < 7; k++) __builtin_nontemporal_store(v[i][k], tb + (long long)(r0 + i) * A.ss + k * 64);
-                    }
-            }
-            counted = full;
-            st_cur = st_next;
-        }
-        return;
-#else
         for (int r0 = 0; r0 <= rmax; r0 += RB) {
             // the trip's RB knots of window i start at knot fp + min(r0, m) (rows past m repeat knot m: the tail row is knot
             // m's reading under the update time), pulled back so that the piece stays inside the stream
@@ -789,7 +731,6 @@ __global__ __launch_bounds__(64) void cpi_assemble_tiles_kernel(AssembleArgs A) 
             }
         }
         return;
-#endif
     }
     // per-lane loads (round 3): RB rows per trip, a lane consumes RB x 56 contiguous bytes of the stream while its 128-byte
     // lines are in flight / fresh in the L1

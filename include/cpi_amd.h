@@ -178,6 +178,10 @@ const int32_t *cpi_stream_counts(const void *workspace, int64_t U);   /* device 
  *                         time alone; a stream with backward stamps needs the host assembler).  count[u] receives the TRUE
  *                         number of intervals of window u; rows beyond N are not written -- a caller sizes N >= max count
  *                         (the kernels clamp count to N).
+ *                         WHEN: the copy costs 1.1-1.2 ms per 1 M x 50 windows (twice the tiled kernel it feeds), so a caller
+ *                         that preintegrates a stream ONCE uses cpi_preintegrate_stream above (windows cut in place, no copy:
+ *                         0.65-0.69 ms mean-only); tiles pay when the SAME windows are preintegrated again and again at new
+ *                         linearisation points -- from about the 8th use (profiles/r05_assembler.md).
  *   cpi_tile_windows      re-tiles windows the caller already holds in the layouts of cpi_preintegrate_batch (dense
  *                         knots[W][N+1][7] with first == NULL, or a shared stream indexed by first[W] / count[W]); rows
  *                         past a window's last knot repeat that knot.  A full extra pass: for one-off use and tests.

@@ -245,11 +245,14 @@ def test_gpu_stream_entry_reads_the_stream_in_place(mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["long", "mixed", "tiny", "end"])
 def test_gpu_device_assembler_every_pass_geometry(case):
-    """cpi_assemble_tiles copies the contiguous stream span of 16 consecutive windows through a 44-KB LDS image (804 knots) and
-    falls back to 8 / 4 / 2 / 1 windows per pass, and to row chunks of a single window, when the span does not fit.  Window
-    lengths chosen to hit every geometry -- windows of 900 and 2 000 intervals (chunked), groups of 300-interval windows (2 per
-    pass), empty windows, repeated update times, a stream shorter than 4 readings, the last window ending past the last
-    reading -- against the host assembler (the deque loop) slot for slot, and counts exactly."""
+    """cpi_assemble_tiles (cpi_mean_kernels.hpp): a wavefront owns a tile of 64 windows, lane = window; a trip moves 8 rows of every
+    window -- 32 LDS-DMA instructions, each the 448 contiguous bytes of TWO windows, into a 33-KB image, from which every lane reads
+    its window back for seven 512-byte row stores.  Window lengths chosen to exercise the trip logic -- windows of 900 and 2 000
+    intervals next to empty ones (lanes that finished long ago re-fetch their last knot), lengths 803 / 804 / 805 (= 5 mod 8 ...:
+    the partial last trip), repeated update times, the last windows running past the stream's end (the pull-back of a trip's first
+    knot to K - 8), a stream shorter than one trip (K = 3 < 8: the whole launch takes the per-lane loads) -- against the host
+    assembler (the deque loop) slot for slot, and the counts exactly.  The two other fallback predicates of the DMA route have
+    their own test below (test_gpu_device_assembler_fallback_predicates)."""
     import torch
     import cpi_amd
     eng = cpi_amd.Engine()
@@ -291,6 +294,97 @@ def test_gpu_device_assembler_every_pass_geometry(case):
         for u in range(U):
             n = min(int(count[u]), 4)
             assert np.array_equal(sd[u // 64, :n + 1, :, u % 64], knots[first[u]:first[u] + n + 1]), (case, u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["k_lt_8", "span_2_24", "unsorted"])
+def test_gpu_device_assembler_fallback_predicates(case):
+    """the DMA route of cpi_assemble_tiles is taken per wavefront when (a) K >= 8, (b) every window of the wavefront
+    starts at or behind lane 0's (`fp >= fp of lane 0`) and (c) all of them lie within 2^24 knots above it (the DMA offsets are 32-bit
+    byte offsets from a wave-uniform base); any other wavefront takes per-lane loads.  Each predicate failing, next to wavefronts
+    where it holds:
+      k_lt_8     streams of 1 ... 7 readings;
+      span_2_24  17 M readings; one tile whose last window ends 16.9 M readings behind the others (count >> N: rows beyond N are not
+                 written, the TRUE count is) between tiles of ordinary windows;
+      unsorted   update times that go BACKWARDS inside a tile (outside the contract -- the reference's deque cannot be restated for
+                 them -- but the kernel must stay inside the stream and follow its documented closed form: window u starts where the
+                 deque would stand after update u - 1 ALONE): expectation = that closed form (_torch_cut).
+    Slot for slot against the host assembler (k_lt_8, span_2_24) / the closed form, counts exactly; and the fused cut of
+    cpi_preintegrate_stream (same arithmetic in the mean kernel's prologue) gives the same counts."""
+    import torch
+    import cpi_amd
+    eng = cpi_amd.Engine()
+    rng = np.random.default_rng(11)
+    dev = eng.device
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if case == "k_lt_8":
+        for K in range(1, 8):
+            t = 50.0 + 0.005 * np.arange(K)
+            stream = np.concatenate([t[:, None], rng.standard_normal((K, 6))], axis=1)
+            ut = np.sort(np.concatenate([t[0] + 0.005 * rng.uniform(-1, K + 1, 70), [t[-1], t[0]]]))
+            knots, first, count = st.assemble_windows(stream, ut)
+            N = max(int(count.max()), 1)
+            tiles = torch.full(((len(ut) + 63) // 64, N + 1, 7, 64), float("nan"), dtype=torch.float64, device=dev)
+            _, cnt = eng.assemble_tiles(T(stream), T(ut), N, tiles=tiles)
+            torch.cuda.synchronize()
+            assert np.array_equal(cnt.cpu().numpy(), count), K
+            td = tiles.cpu().numpy()
+            for u in range(len(ut)):
+                assert np.array_equal(td[u // 64, :count[u] + 1, :, u % 64], knots[first[u]:first[u] + count[u] + 1]), (K, u)
+        return
+    if case == "span_2_24":
+        K = (1 << 24) + 300000
+        stream = torch.empty((K, 7), dtype=torch.float64, device=dev)
+        stream[:, 0] = 100.0 + torch.arange(K, dtype=torch.float64, device=dev) * 0.005
+        g = torch.Generator(device=dev); g.manual_seed(3)
+        stream[:, 1:] = torch.randn((K, 6), generator=g, dtype=torch.float64, device=dev)
+        # 3 tiles: windows of ~40 intervals; window 100 (tile 1) ends 16.9 M readings later, windows 101 ... go on from there
+        edges = np.concatenate([40 * np.arange(1, 101), (1 << 24) + 100000 + 40 * np.arange(1, 92)]).astype(np.int64)
+        ut = torch.from_numpy(100.0 + 0.005 * edges + 0.002).to(dev)
+        N = 64
+        knots, first, count = _torch_cut(stream, ut)
+        cnt_np = count.cpu().numpy()
+        assert int(cnt_np[100]) > (1 << 24) and sorted(set(cnt_np[:100])) == [40, 41] and int(cnt_np[101:].max()) <= 41
+        tiles = torch.full(((len(edges) + 63) // 64, N + 1, 7, 64), float("nan"), dtype=torch.float64, device=dev)
+        _, cnt = eng.assemble_tiles(stream, ut, N, tiles=tiles)
+        torch.cuda.synchronize()
+        assert torch.equal(cnt.to(torch.int32), count)
+        f_np = first.cpu().numpy()
+        for u in list(range(0, 191, 7)) + [63, 64, 99, 100, 101, 127, 128, 190]:
+            n = min(int(cnt_np[u]), N)
+            assert torch.equal(tiles[u // 64, :n + 1, :, u % 64], knots[int(f_np[u]):int(f_np[u]) + n + 1]), u
+        # the head of the closed form against the deque loop (host), and the fused cut's counts
+        hk, hf, hc = st.assemble_windows(stream[:5000].cpu().numpy(), ut[:100].cpu().numpy())
+        assert np.array_equal(hc, cnt_np[:100]) and np.array_equal(hk, knots[:hk.shape[0]].cpu().numpy())
+        lin = torch.zeros((len(edges), 6), dtype=torch.float64, device=dev)
+        _, c2 = eng.preintegrate_stream(stream, ut, lin, None, eng.make_params(1), want=("mean",), N=N, return_counts=True, check_counts=False)
+        torch.cuda.synchronize()
+        assert torch.equal(c2.to(torch.int32), count)
+        return
+    K = 6000
+    t = 10.0 + 0.005 * np.arange(K)
+    stream = np.concatenate([t[:, None], rng.standard_normal((K, 6))], axis=1)
+    ut = 10.0 + 0.005 * (30 * np.arange(1, 193)) + 0.0021
+    ut[5], ut[6] = ut[6], ut[5]                       # a swap inside tile 0 (lane 6's window starts before lane 0's? no: before lane 5's)
+    ut[70:80] = ut[70:80][::-1].copy()                # a reversed run inside tile 1
+    ut[128] = t[0] - 1.0                              # the first window of tile 2 ends before the stream starts: lane 1 starts at knot 0, below nothing -- and
+    ut[129] = ut[127] - 0.3                           # ... lane 1 of tile 2 ends 60 readings BEFORE where lane 0 started
+    ds, du = T(stream), T(ut)
+    knots, first, count = _torch_cut(ds, du)
+    cnt_np, f_np = count.cpu().numpy(), first.cpu().numpy()
+    N = max(int(cnt_np.max()), 1)
+    tiles = torch.full(((len(ut) + 63) // 64, N + 1, 7, 64), float("nan"), dtype=torch.float64, device=dev)
+    _, cnt = eng.assemble_tiles(ds, du, N, tiles=tiles)
+    torch.cuda.synchronize()
+    assert torch.equal(cnt.to(torch.int32), count)
+    for u in range(len(ut)):
+        n = int(cnt_np[u])
+        assert torch.equal(tiles[u // 64, :n + 1, :, u % 64], knots[int(f_np[u]):int(f_np[u]) + n + 1]), u
+    lin = torch.zeros((len(ut), 6), dtype=torch.float64, device=dev)
+    for lanes in (0, 1, 4):
+        _, c2 = eng.preintegrate_stream(ds, du, lin, None, eng.make_params(1, lanes_per_window=lanes), want=("mean",), N=N, return_counts=True, check_counts=False)
+        torch.cuda.synchronize()
+        assert torch.equal(c2.to(torch.int32), count), lanes
 
 
 @pytest.mark.gpu
