@@ -259,10 +259,10 @@ class Engine:
                                  pinned=False, return_counts=False):
         """preintegrate_stream for a caller that holds everything in HOST memory (cpi_preintegrate_stream_host): the IMU
         stream [K,7], the update times [U], one linearisation point per window -- CPU float64 tensors in, CPU tensors out;
-        synchronous.  A window longer than N intervals raises (N defaults to the stream's length: nothing can be)."""
+        synchronous.  A window longer than N intervals raises (N defaults to the longest window the stamps allow: nothing can be)."""
         params = params or self.make_params()
         K, U = stream.shape[0], update_times.shape[0]
-        N = int(N) if N is not None else min(max(K, 1), 65535)
+        N = int(N) if N is not None else self._stream_bound(stream, update_times)     # the same default as the device entry: same lane split, same bits
         for t in (stream, update_times, lin, q_k_lin):
             assert t is None or (not t.is_cuda and t.is_contiguous() and t.dtype == torch.float64), "inputs must be contiguous CPU float64 tensors"
         out = {}

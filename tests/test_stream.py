@@ -344,7 +344,7 @@ def test_gpu_device_assembler_fallback_predicates(case):
         N = 64
         knots, first, count = _torch_cut(stream, ut)
         cnt_np = count.cpu().numpy()
-        assert int(cnt_np[100]) > (1 << 24) and sorted(set(cnt_np[:100])) == [40, 41] and int(cnt_np[101:].max()) <= 41
+        assert int(cnt_np[100]) > (1 << 24) and set(cnt_np[:100].tolist()) <= {40, 41} and int(cnt_np[101:].max()) <= 41
         tiles = torch.full(((len(edges) + 63) // 64, N + 1, 7, 64), float("nan"), dtype=torch.float64, device=dev)
         _, cnt = eng.assemble_tiles(stream, ut, N, tiles=tiles)
         torch.cuda.synchronize()
