@@ -633,8 +633,40 @@ def overlapped_rate(W, N, nctxs, steps):
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / steps)
         per[nctx] = best
+    # The same round-robin as ONE HIP graph (fork from the capture stream into the contexts' streams, join at the end): no host
+    # launch cost between the batches -- what a caller that replays a fixed schedule gets, and the figure that says what the GPU
+    # itself does with overlapping launches (the eager figure above can be bound by ~3-4 us of host work per launch).
+    graph = {}
+    try:
+        nsteps = 600
+        for nctx in nctxs:
+            cap = torch.cuda.Stream(device=dev)
+            cap.wait_stream(torch.cuda.current_stream(dev))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=cap):
+                for st in pool.streams[:nctx]:
+                    st.wait_stream(cap)
+                for i in range(nsteps):
+                    kn, lin, q = batches[i % nb]
+                    pool.engines[i % nctx].preintegrate(kn, lin, q, prm, want=("mean",), out=outs[i % len(outs)])
+                for st in pool.streams[:nctx]:
+                    cap.wait_stream(st)
+            g.replay()
+            torch.cuda.synchronize()
+            best = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    g.replay()
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / (5 * nsteps))
+            graph[nctx] = best
+            del g
+    except Exception as ex:             # pragma: no cover - depends on the runtime's cross-stream capture
+        sys.stderr.write("bench.py: multi-stream graph capture failed (%r): eager figures only\n" % (ex,))
+        graph = {}
     pool.close()
-    return per
+    return per, graph
 
 
 # ------------------------------------------------------------------------------------------------ launch
@@ -769,13 +801,17 @@ def main():
         if rank == 0 and world == 1 and not a.no_extra and W == 10000:
             # the same workload issued through 2 / 3 / 4 engine contexts (HIP streams): consecutive launches overlap
             try:
-                per = overlapped_rate(W, N, (2, 3, 4), 3000)
+                per, gper = overlapped_rate(W, N, (2, 3, 4), 3000)
                 bpb = bytes_per_unit("v1_mean", N) * W
-                res["overlapped"] = {"contexts": 3, "value": W / per[3], "unit": "windows/s", "ms_per_batch": per[3] * 1e3,
-                                     "frac": bpb / per[3] / 1e9 / HBM_PEAK_GBS, "batches": 3000,
-                                     "frac_by_contexts": {str(k): round(bpb / v / 1e9 / HBM_PEAK_GBS, 4) for k, v in per.items()},
-                                     "how": "independent batches round-robin over N engine contexts (one HIP stream each, eager launches, "
-                                            "host wall clock / batches): an aggregate rate, not a launch duration"}
+                best = gper if gper else per                 # the graph replay when the runtime captured it, else the eager issue
+                res["overlapped"] = {"contexts": 3, "value": W / best[3], "unit": "windows/s", "ms_per_batch": best[3] * 1e3,
+                                     "frac": bpb / best[3] / 1e9 / HBM_PEAK_GBS, "batches": 3000,
+                                     "mode": "graph" if gper else "eager",
+                                     "frac_by_contexts": {str(k): round(bpb / v / 1e9 / HBM_PEAK_GBS, 4) for k, v in best.items()},
+                                     "frac_eager_by_contexts": {str(k): round(bpb / v / 1e9 / HBM_PEAK_GBS, 4) for k, v in per.items()},
+                                     "how": "independent batches round-robin over N engine contexts (one HIP stream each); graph: 600 batches "
+                                            "captured as ONE HIP graph (fork / join over the N streams), 5 replays; eager: 3000 launches from the "
+                                            "host; wall clock / batches: an aggregate rate, not a launch duration"}
                 res["goal_40pct_hbm_overlapped"] = bool(res["overlapped"]["frac"] >= 0.40)
             except Exception as ex:       # an additional object must never cost the line
                 res["overlapped"] = {"error": repr(ex)}
