@@ -838,9 +838,9 @@ def main():
             "timed region %.3f ms = %d steps (%.3f ms of kernels, HIP events) + %.3f ms of exposed exchange (%.0f %% of the region; %s schedule): "
             "%s  Scaling efficiency of the hot path itself: value_kernel_only / (n_gpus x the 1-GPU value); with the exchange: value." % (
                 wall * 1e3, a.steps, kern_ms, gather_ms, 100.0 * share, schedule if do_gather else "no",
-                ("the region is shorter than a collective's start-up on this fabric, so `value` measures the exchange, not the kernels -- "
-                 "the millisecond-scale rows (`--workload cfg5_mean`, `--scaling strong --workload v2_full`) are the ones a curve means something on."
-                 if wall * 1e3 < 2.0 else "the steps dominate the region.")))
+                ("the exchange is a third or more of a region of a few milliseconds, so `value` is shaped by the collective's latency, not by the "
+                 "kernels -- the millisecond-per-step rows (`--workload cfg5_mean`, `--scaling strong --workload v2_full`) are the ones a curve means something on."
+                 if share >= 0.3 else "the steps dominate the region.")))
     if do_gather and a.gather == "root":
         res["config"].update(verify_gather(eng, wl, tm, world, rank, base_seed, rehearsal))
     extra = None

@@ -224,7 +224,7 @@ def test_bench_gpus_4_and_8_the_drivers_first_multi_gpu_commands_rehearsed_on_on
         assert c["rccl"]["backend"] == "gloo" and c["rccl"]["world_size"] == n and sorted(r[0] for r in c["rccl"]["ranks"]) == list(range(n))
         assert c["gather_schedule"] == sched and c["gather_verified"] is True and "bitwise" in c["gather_verified_how"]
         assert c["value_kernel_only"] >= d["value"] and c["value_without_gather"] > 0
-        assert "timed region" in c["scaling_note"] and "exchange" in c["scaling_note"] and len(c["scaling_note"]) < 700
+        assert "timed region" in c["scaling_note"] and "exchange" in c["scaling_note"] and len(c["scaling_note"]) < 900
         assert "roofline" in d and "cpu_baseline" not in d and "overlapped" not in d       # rank 0 at N = 1 only
 
 
