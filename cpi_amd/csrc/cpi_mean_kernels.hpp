@@ -64,9 +64,6 @@ __device__ __forceinline__ long long knots_not_after_near(const double *stream, 
 #ifndef CPI_MEAN_WPS
 #define CPI_MEAN_WPS 1
 #endif
-#ifndef CPI_MEAN_UPFRONT
-#define CPI_MEAN_UPFRONT 0
-#endif
 #ifndef CPI_MEAN_C
 #define CPI_MEAN_C 2      // knots per chunk of the staged kernels with several intervals per lane (3 measured: see below)
 #endif
@@ -324,7 +321,11 @@ __global__ __launch_bounds__(64, BIG ? 2 : (((MODEL == 2 && !JAC) || (MODEL == 1
     const bool utail = cut && __all(tailseg && len == maxlen);
     const int nsteps = utail ? maxlen - 1 : maxlen;
     const int nchunks = (nsteps + C - 1) / C;
-    auto consume = [&](int it) {
+    if (nchunks > 0) issue(0);
+    for (int it = 0; it < nchunks; ++it) {
+        commit();
+        __syncthreads();
+        if (it + 1 < nchunks) issue(it + 1);
 #pragma unroll   // C <= 2: the two steps of a chunk share one basic block (no knot copy between them)
         for (int c = 0; c < C; ++c) {
             const int s = it * C + c;
@@ -350,54 +351,7 @@ __global__ __launch_bounds__(64, BIG ? 2 : (((MODEL == 2 && !JAC) || (MODEL == 1
 #pragma unroll
             for (int i = 0; i < 7; i++) pk[i] = q[i];
         }
-    };
-    // Small, latency-bound batches (several lanes per window, every wavefront with a SIMD to itself -- the 10 k-window headline):
-    // with at most NUP chunks per lane-segment ALL chunks are requested at once (NUP x 14 staged doubles; registers are free at
-    // one wavefront per SIMD), so that only the first arrival is waited for in full and the integration of chunk k runs under the
-    // arrival of chunks k + 1 ...; the unrolled trip carries static counts, i.e. partial s_waitcnt vmcnt.  Measured against one
-    // chunk ahead: profiles/r05_headline_upfront.md.
-    constexpr int NUP = 5;
-    constexpr bool UPF = (CPI_MEAN_UPFRONT != 0) && !BIG && !JAC && CUT == 0 && L >= 5 && C == 2;
-    bool upfront = false;
-    if constexpr (UPF) upfront = (nchunks > 0) && (nchunks <= NUP) && (A.N >= NUP * C);   // wave-uniform; N: the fast path over-reads NUP chunks
-    if (upfront) {
-        if constexpr (UPF) {
-            double sall[NUP][SEGD];
-            if (safe_overread) {
-#pragma unroll
-                for (int it = 0; it < NUP; ++it) {
-                    const char *cb = reinterpret_cast<const char *>(blk0) + it * (SEGD * 8);
-#pragma unroll
-                    for (int e = 0; e < SEGD; ++e) {
-                        asm volatile("" : "+v"(voff[e]));
-                        sall[it][e] = *reinterpret_cast<const double *>(cb + voff[e]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int it = 0; it < NUP; ++it)
-#pragma unroll
-                    for (int e = 0; e < SEGD; ++e) sall[it][e] = sptr[e][min(it, smax[e]) * SEGD];
-            }
-#pragma unroll
-            for (int it = 0; it < NUP; ++it) {
-                if (it >= nchunks) break;
-#pragma unroll
-                for (int e = 0; e < SEGD; ++e) tile[tofs[e]] = sall[it][e];
-                __syncthreads();
-                consume(it);
-                __syncthreads();
-            }
-        }
-    } else {
-    if (nchunks > 0) issue(0);
-    for (int it = 0; it < nchunks; ++it) {
-        commit();
         __syncthreads();
-        if (it + 1 < nchunks) issue(it + 1);
-        consume(it);
-        __syncthreads();
-    }
     }
     if constexpr (cut) {
         if (utail) {   // the peeled tail interval [stamp of the last real knot, t_end], that knot's reading held
