@@ -44,6 +44,8 @@ if [ "$PART" = cpu ]; then
   printf '%s\n' 1275.06 1275.4 1276.0 1277.5 > build/san/ut.txt
   run "cpi_host.hpp parse_imu_text + assemble_windows" build/san/test_stream_asan tests/golden/imu_gazebo200_excerpt.dat build/san/ut.txt
   run "cpi_host.hpp assemble_windows_tiled" build/san/test_stream_asan tests/golden/imu_gazebo200_excerpt.dat build/san/ut.txt tiled
+  g++ -std=c++17 -O1 $SAN tests/cpp/test_facade_lazy_cpu.cpp -o build/san/test_facade_lazy_asan -Lcpi_amd -lcpi_amd -Wl,-rpath,$R/cpi_amd -Wl,-rpath,/opt/rocm/lib || exit 2
+  run "cpi_host.hpp lazy result members (fresh / stored / copied / a read that needs the device)" build/san/test_facade_lazy_asan
 else
   CXX=/opt/rocm/lib/llvm/bin/clang++
   SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g -shared-libsan"
