@@ -23,12 +23,12 @@ __global__ __launch_bounds__(64, OCC) void k_visit(const char *src, double *sink
         const long long vb = (long long)v * B;
         if (lpw <= 64) {
             // instruction e covers windows per e .. per e + per - 1
-            for (int e0 = 0; e0 < 64 / per; e0 += 8) {
+            for (int e0 = 0; e0 * per < 64; e0 += 8) {
                 double t[8][2];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int e = e0 + u;
-                    const long long win = w0 + (long long)gap * (per * e + lane / lpw);
+                    const long long win = w0 + (long long)gap * min(per * e + lane / lpw, 63);
                     const char *p = src + win * stride + vb + (long long)(lane % lpw) * LW;
                     if (LW == 16) { const d2 x = *reinterpret_cast<const d2 *>(p); t[u][0] = x.x; t[u][1] = x.y; }
                     else { t[u][0] = *reinterpret_cast<const double *>(p); t[u][1] = 0; }
@@ -61,9 +61,11 @@ int main() {
     if (hipMalloc(&p, (size_t)W * stride + 4096) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess) return 1;
     hipMemset(p, 0, (size_t)W * stride + 4096);
     printf("64 windows of %d B per wavefront, %lld windows; B bytes per window and visit, LW bytes per lane and load\n", stride, W);
-    for (int gap : {1, 16}) for (int LW : {8, 16}) for (int B : {128, 256, 512, 1024}) {
-        if (B / LW > 64) continue;
+    for (int gap : {1, 16}) for (int LW : {8, 16}) for (int B : {112, 128, 168, 176, 224, 256, 512, 1024}) {
+        if (B / LW > 64 || B % LW != 0) continue;
         const int visits = stride / B;
+        const int lpw = B / LW, per = lpw >= 64 ? 1 : 64 / lpw;
+        (void)per;                                             // (window indices are clamped to the wavefront's 64: all of them are read)
         const double bytes = (double)W * visits * B;
         float ms2 = (LW == 8) ? run<8, 2>(p, sink, W, stride, B, gap) : run<16, 2>(p, sink, W, stride, B, gap);
         float ms3 = (LW == 8) ? run<8, 3>(p, sink, W, stride, B, gap) : run<16, 3>(p, sink, W, stride, B, gap);
