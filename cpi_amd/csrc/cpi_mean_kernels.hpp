@@ -64,10 +64,6 @@ __device__ __forceinline__ long long knots_not_after_near(const double *stream, 
 #ifndef CPI_MEAN_WPS
 #define CPI_MEAN_WPS 1
 #endif
-#ifndef CPI_MEAN_W16
-#define CPI_MEAN_W16 0
-#endif
-typedef double cpi_ld2 __attribute__((ext_vector_type(2), aligned(8)));   // 16 bytes at an 8-byte aligned address (56-byte knots)
 #ifndef CPI_MEAN_C
 #define CPI_MEAN_C 2      // knots per chunk of the staged kernels with several intervals per lane (3 measured: see below)
 #endif
@@ -282,35 +278,8 @@ __global__ __launch_bounds__(64, BIG ? 2 : (((MODEL == 2 && !JAC) || (MODEL == 1
     // per-element path below stops at the segment's end and re-reads its last, valid knot instead.)
     const bool safe_overread = cut ? fast_stream
                                    : ((A.first == nullptr) && (A.count == nullptr) && ((long long)(blockIdx.x + 1) * WPB + 2 < A.W));
-    // Fast path, two knots per chunk: a lane-segment's chunk is 112 bytes = SEVEN 16-byte pieces, fetched as such
-    // (global_load_dwordx4 at 8-byte alignment): 7 load instructions per chunk instead of 14.  A pure-load probe of the pattern
-    // (tools/exp/stride_probe.hip) streams 112-byte visits at 5.2 TB/s with 16-byte loads against 4.5 with 8-byte ones.
-    constexpr bool W16 = (CPI_MEAN_W16 != 0) && !BIG && C == 2;
-    unsigned woff[W16 ? 7 : 1];
-    int wtofs[W16 ? 7 : 1];
-    if constexpr (W16) {
-        if (safe_overread) {
-#pragma unroll
-            for (int e = 0; e < 7; ++e) {
-                const int idx = e * 64 + lane, seg = idx / 7, sub = idx - seg * 7;     // piece `sub` of lane-segment `seg`
-                const long long base = (long long)(segdesc[seg] >> 16);
-                woff[e] = (unsigned)((A.knots + base + 7 + 2 * sub - blk0) * 8);
-                wtofs[e] = seg * PITCH + 2 * sub;
-            }
-        }
-    }
     auto issue = [&](int it) {
-        if (W16 && safe_overread) {
-            if constexpr (W16) {
-                const char *cb = reinterpret_cast<const char *>(blk0) + (long long)it * (SEGD * 8);
-#pragma unroll
-                for (int e = 0; e < 7; ++e) {
-                    asm volatile("" : "+v"(woff[e]));
-                    const cpi_ld2 v = *reinterpret_cast<const cpi_ld2 *>(cb + woff[e]);
-                    stage[2 * e] = v.x; stage[2 * e + 1] = v.y;
-                }
-            }
-        } else if (safe_overread) {
+        if (safe_overread) {
             // scalar base (advanced by SALU) + constant 32-bit lane offsets: no vector arithmetic per element
             const char *cb = reinterpret_cast<const char *>(blk0) + (long long)it * (SEGD * 8);
 #pragma unroll
@@ -332,13 +301,6 @@ __global__ __launch_bounds__(64, BIG ? 2 : (((MODEL == 2 && !JAC) || (MODEL == 1
         }
     };
     auto commit = [&]() {
-        if (W16 && safe_overread) {
-            if constexpr (W16) {
-#pragma unroll
-                for (int e = 0; e < 7; ++e) { tile[wtofs[e]] = stage[2 * e]; tile[wtofs[e] + 1] = stage[2 * e + 1]; }
-            }
-            return;
-        }
 #pragma unroll
         for (int e = 0; e < SEGD; ++e) {
             if constexpr (BIG) tile[e * 64 + lane] = stage[e]; else tile[tofs[e]] = stage[e];
