@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 5, VERDICT item 1(b): cpi_mean_line_kernel (whole 128-byte lines, phase-sorted wavefronts) against the shipped staged
 # kernels.  usage (GPU box): tools/exp/r05_line_ab.sh <variant tag> [<variant tag> ...]   (cpi_amd/libcpi_amd_<tag>.so; "" = default)
+# (The kernel now lives in the experiments build: python -m cpi_amd.build --custom <tag> -DCPI_EXPERIMENTS [...], run with CPI_AMD_MEAN_LINE=1;
+# the session recorded in profiles/r05_mean_traffic.md used an earlier -DCPI_MEAN_LINE_W=<windows> switch of the default build.)
 # (i) bitwise check of the variant against the two-knot kernel + reference sample (the three-knot test runs whatever kernel the
 # library picks for a one-lane dense launch), (ii) same-box alternating launch times, (iii) FETCH_SIZE / WRITE_SIZE per launch.
 cd ${GRAFT_REPO_ROOT:-.}
