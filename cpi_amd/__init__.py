@@ -8,7 +8,8 @@ from ._lib import CpiError, LIB_PATH  # noqa: F401
 
 
 def __getattr__(name):  # lazy: importing the package must not need torch / a GPU
-    if name in ("Engine", "CpiV1", "CpiV2", "ForsterDiscrete", "ImuFactorCPIv1", "ImuFactorCPIv2", "default_engine", "unpack_factor"):
+    if name in ("Engine", "CpiV1", "CpiV2", "ForsterDiscrete", "ImuFactorCPIv1", "ImuFactorCPIv2", "default_engine", "unpack_factor",
+                "pack_sym", "pack_tri", "unpack_sym", "unpack_tri"):
         from . import engine
         return getattr(engine, name)
     if name == "EnginePool":

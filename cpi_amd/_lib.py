@@ -12,9 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CPI_AMD_LIB") or os.path.join(_HERE, "libcpi_amd.so")  # env override: kernel-variant A/B runs
 
 CPI_OK, CPI_ERR_INVALID, CPI_ERR_HIP, CPI_ERR_NO_DEVICE, CPI_ERR_RCCL = 0, 1, 2, 3, 4
-ABI_VERSION = 2   # include/cpi_amd.h CPI_ABI_VERSION
+ABI_VERSION = 3   # include/cpi_amd.h CPI_ABI_VERSION
 OUT_FIELDS = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("J_a", 9), ("J_b", 9),
-              ("H_a", 9), ("H_b", 9), ("O_a", 9), ("O_b", 9), ("P", 225)]
+              ("H_a", 9), ("H_b", 9), ("O_a", 9), ("O_b", 9), ("P", 225), ("P_sym", 120)]
+TRI_DOUBLES = 120   # include/cpi_amd.h CPI_TRI_DOUBLES: packed upper triangle of a 15 x 15 matrix, entry (i, j), i <= j, at i + j (j + 1) / 2
 
 
 class CpiParams(C.Structure):
@@ -37,21 +38,37 @@ class CpiError(RuntimeError):
 _lib = None
 
 
+def _embedded_build_id(path):
+    """cpi_build_id() of a library file WITHOUT loading it into this process (a stale copy must not stay mapped when the
+    fresh build is loaded afterwards): the id string sits in .rodata behind a fixed tag."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+        i = blob.find(b"cpi-build-id:")
+        return blob[i + 13:i + 13 + 64].split(b"\0", 1)[0].decode() if i >= 0 else None
+    except OSError:
+        return None
+
+
 def load():
     global _lib
     if _lib is not None:
         return _lib
+    import shutil
     from . import build as _build
-    hipcc_missing = None
-    if LIB_PATH == _build.LIB and _build.stale():
-        # missing, or built from other sources than the tree holds (content hash); hipcc cross-compiles without a GPU.
-        # Compile and link errors PROPAGATE (a source edit that does not build must not be hidden behind the previous
-        # library).  Only a machine without the compiler may go on with the library that is there -- and then only when that
-        # library was built from this tree's sources (cpi_build_id() == source_id(), checked below).
-        try:
+    # a machine without the compiler (detected as such, not guessed from an exception type: a missing SOURCE file is a broken
+    # tree and propagates) may go on with the library that is there -- and then only when that library was built from this
+    # tree's sources (cpi_build_id() == source_id(), checked below)
+    hipcc_missing = None if (os.path.exists(_build.HIPCC) or shutil.which(_build.HIPCC)) else "no %s on this machine" % _build.HIPCC
+    if LIB_PATH == _build.LIB and not hipcc_missing:
+        # missing, or built from other sources than the tree holds; hipcc cross-compiles without a GPU.  Compile and link
+        # errors PROPAGATE (a source edit that does not build must not be hidden behind the previous library).  Two notions
+        # of "stale": the sidecar .id file (content hash of the sources at build time) and -- for a library copied in from
+        # elsewhere beside a sidecar that says fresh -- the id compiled INTO the library, which only a forced build repairs.
+        if _build.stale():
             _build.build()
-        except FileNotFoundError as ex:            # subprocess could not start HIPCC: no compiler on this machine
-            hipcc_missing = ex
+        elif _embedded_build_id(LIB_PATH) != _build.source_id():
+            _build.build(force=True)
     if not os.path.exists(LIB_PATH):
         raise ImportError("cpi_amd: %s is missing and could not be built (%r); no CPU fallback exists" % (LIB_PATH, hipcc_missing))
     lib = C.CDLL(LIB_PATH)
@@ -61,10 +78,11 @@ def load():
     if lib.cpi_abi_version() != ABI_VERSION:
         raise ImportError("cpi_amd: %s has ABI version %d, this binding expects %d (stale build?)" % (LIB_PATH, lib.cpi_abi_version(), ABI_VERSION))
     missing = [n for n in ("cpi_preintegrate_stream", "cpi_assemble_tiles", "cpi_tile_windows", "cpi_outputs_bind_slab", "cpi_preintegrate_tiled_batch_host",
-                          "cpi_preintegrate_stream_host")
+                          "cpi_preintegrate_stream_host", "cpi_sqrt_information_packed_batch", "cpi_factor_eval_whitened_tri_batch",
+                          "cpi_factor_hessian_tri_batch", "cpi_group_gather_chunk", "cpi_shard_chunk_bounds")
                if not hasattr(lib, n)]
     if missing:
-        raise ImportError("cpi_amd: %s lacks %s (a build from before round 3: run python -m cpi_amd.build --force)" % (LIB_PATH, ", ".join(missing)))
+        raise ImportError("cpi_amd: %s lacks %s (an older build: run python -m cpi_amd.build --force)" % (LIB_PATH, ", ".join(missing)))
     lib.cpi_build_id.restype = C.c_char_p
     if LIB_PATH == _build.LIB:
         # the in-tree product library must be the build of the in-tree sources: same-ABI libraries with old kernels would
@@ -74,7 +92,7 @@ def load():
             msg = "cpi_amd: %s was built from other sources than this tree holds (build id %s, sources %s)%s" % (
                 LIB_PATH, have, want, "; hipcc is not available here (%r)" % (hipcc_missing,) if hipcc_missing else "")
             if os.environ.get("CPI_AMD_ALLOW_STALE") != "1":
-                raise ImportError(msg + " -- run python -m cpi_amd.build, or set CPI_AMD_ALLOW_STALE=1 to load it anyway")
+                raise ImportError(msg + " -- run python -m cpi_amd.build --force, or set CPI_AMD_ALLOW_STALE=1 to load it anyway")
             import warnings
             warnings.warn(msg + " (CPI_AMD_ALLOW_STALE=1: loaded anyway)")
     lib.cpi_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
@@ -88,6 +106,9 @@ def load():
     lib.cpi_shard_bounds.argtypes = [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
     lib.cpi_shard_bounds.restype = None
     lib.cpi_group_gather.argtypes = [vp, C.c_int, i64, C.POINTER(CpiOutputs), C.POINTER(CpiOutputs)]
+    lib.cpi_group_gather_chunk.argtypes = [vp, C.c_int, i64, C.c_int, C.c_int, C.POINTER(CpiOutputs), C.POINTER(CpiOutputs)]
+    lib.cpi_shard_chunk_bounds.argtypes = [i64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    lib.cpi_shard_chunk_bounds.restype = None
     lib.cpi_group_synchronize.argtypes = [vp]
     lib.cpi_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.cpi_ctx_destroy.argtypes = [vp]
@@ -121,6 +142,9 @@ def load():
     lib.cpi_factor_eval_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp]
     lib.cpi_factor_eval_packed_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp]
     lib.cpi_sqrt_information_batch.argtypes = [vp, i64, dp, dp]
+    lib.cpi_sqrt_information_packed_batch.argtypes = [vp, i64, dp, dp]
+    lib.cpi_factor_eval_whitened_tri_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp, dp]
+    lib.cpi_factor_hessian_tri_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp]
     lib.cpi_factor_eval_whitened_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp, dp, dp]
     lib.cpi_factor_hessian_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, dp, dp, i64, vp, vp, dp, dp]
     lib.cpi_predict_batch.argtypes = [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(CpiOutputs), dp, i64, vp, dp]
@@ -135,7 +159,8 @@ def load():
               lib.cpi_predict_batch, lib.cpi_preintegrate_batch_host, lib.cpi_factor_eval_batch_host, lib.cpi_factor_hessian_batch,
               lib.cpi_preintegrate_tiled_batch, lib.cpi_tile_knots, lib.cpi_group_create, lib.cpi_group_gather, lib.cpi_group_synchronize, lib.cpi_group_size, lib.cpi_ctx_set_stream,
               lib.cpi_tile_windows, lib.cpi_assemble_tiles, lib.cpi_preintegrate_tiled_batch_host, lib.cpi_outputs_bind_slab,
-              lib.cpi_group_last_gather_messages, lib.cpi_preintegrate_stream_host):
+              lib.cpi_group_last_gather_messages, lib.cpi_preintegrate_stream_host, lib.cpi_sqrt_information_packed_batch,
+              lib.cpi_factor_eval_whitened_tri_batch, lib.cpi_factor_hessian_tri_batch, lib.cpi_group_gather_chunk):
         f.restype = C.c_int
     _lib = lib
     return lib

@@ -34,6 +34,9 @@
 
 using namespace cpi;
 
+constexpr int kOutFields = 13;   // fields of cpi_outputs (ABI 3: P_sym is the 13th)
+static_assert(sizeof(cpi_outputs) == kOutFields * sizeof(double *), "cpi_outputs is a plain table of kOutFields pointers");
+
 // ============================================================================================
 // contexts
 // ============================================================================================
@@ -81,7 +84,9 @@ extern "C" int cpi_abi_version(void) { return CPI_ABI_VERSION; }
 #ifndef CPI_BUILD_ID
 #define CPI_BUILD_ID "unknown"
 #endif
-extern "C" const char *cpi_build_id(void) { return CPI_BUILD_ID; }
+// "cpi-build-id:<id>" as ONE string in .rodata: cpi_amd/_lib.py finds the id of a library file by that tag without loading it
+static const char kBuildIdTagged[] = "cpi-build-id:" CPI_BUILD_ID;
+extern "C" const char *cpi_build_id(void) { return kBuildIdTagged + 13; }
 
 extern "C" int cpi_ctx_create(int device, void *stream, cpi_ctx **out) {
     if (!out) return fail(nullptr, CPI_ERR_INVALID, "cpi_ctx_create: out is NULL");
@@ -201,10 +206,10 @@ static PreArgs shift_windows(const PreArgs &a, long long w0) {
     if (a.count) t.count = a.count + w0;
     t.lin = a.lin + w0 * 6;
     if (a.qk) t.qk = a.qk + w0 * 4;
-    static const int n[12] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225 };
-    double **f[12] = { &t.out.DT, &t.out.alpha, &t.out.beta, &t.out.q, &t.out.J_q, &t.out.J_a, &t.out.J_b, &t.out.H_a,
-                       &t.out.H_b, &t.out.O_a, &t.out.O_b, &t.out.P };
-    for (int k = 0; k < 12; k++) if (*f[k]) *f[k] += w0 * n[k];
+    static const int n[kOutFields] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225, 120 };
+    double **f[kOutFields] = { &t.out.DT, &t.out.alpha, &t.out.beta, &t.out.q, &t.out.J_q, &t.out.J_a, &t.out.J_b, &t.out.H_a,
+                               &t.out.H_b, &t.out.O_a, &t.out.O_b, &t.out.P, &t.out.P_sym };
+    for (int k = 0; k < kOutFields; k++) if (*f[k]) *f[k] += w0 * n[k];
     return t;
 }
 #endif
@@ -246,7 +251,7 @@ static int preintegrate_impl(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int
 
     const bool want_mean = out->DT || out->alpha || out->beta || out->q;
     const bool want_jac = out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b;
-    const bool want_cov = out->P != nullptr;
+    const bool want_cov = out->P != nullptr || out->P_sym != nullptr;
     const bool forster = prm->model == CPI_MODEL_FORSTER;
     const bool avg = prm->imu_avg != 0;
     const bool v2 = prm->model == CPI_MODEL_V2;
@@ -315,7 +320,6 @@ static int preintegrate_impl(cpi_ctx *ctx, const cpi_params *prm, int64_t W, int
         PreArgs c = a;
         c.write_means = want_mean ? 1 : 0;
         c.write_jac = (stj && want_jac) ? 1 : 0;
-        if (!want_cov) c.out.P = nullptr;
         launch::cov(prm->model, avg, c, ctx->stream);
     }
     if (run_mean) {
@@ -429,7 +433,7 @@ static int factor_args(cpi_ctx *ctx, const char *who, int32_t model, const doubl
 
 static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F, const cpi_outputs *meas,
                             const double *lin, const double *q_k_lin, const double *states, int64_t S, const int32_t *idx_i,
-                            const int32_t *idx_j, const double *sqrt_info, double *err, double *H1, double *H2) {
+                            const int32_t *idx_j, const double *sqrt_info, bool tri, double *err, double *H1, double *H2) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (F == 0) return CPI_OK;
     if (!err) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_batch: NULL argument");
@@ -438,7 +442,7 @@ static int factor_eval_impl(cpi_ctx *ctx, int32_t model, const double grav[3], i
     if (rc != CPI_OK) return rc;
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    a.err = err; a.H1 = H1; a.H2 = H2; a.sqrt_info = sqrt_info;
+    a.err = err; a.H1 = H1; a.H2 = H2; a.sqrt_info = sqrt_info; a.r_tri = tri ? 1 : 0;
     launch::factor(model, sqrt_info != nullptr, factor_lanes(F, sqrt_info != nullptr), a, ctx->stream);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
@@ -448,7 +452,7 @@ extern "C" int cpi_factor_eval_batch(cpi_ctx *ctx, int32_t model, const double g
                                      const cpi_outputs *meas, const double *lin, const double *q_k_lin,
                                      const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                      double *err, double *H1, double *H2) {
-    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, nullptr, err, H1, H2);
+    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, nullptr, false, err, H1, H2);
 }
 
 extern "C" int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
@@ -456,7 +460,14 @@ extern "C" int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const
                                               const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                               const double *sqrt_info, double *err, double *H1, double *H2) {
     if (ctx && !sqrt_info) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_whitened_batch: sqrt_info is NULL");
-    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, sqrt_info, err, H1, H2);
+    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, sqrt_info, false, err, H1, H2);
+}
+extern "C" int cpi_factor_eval_whitened_tri_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                                  const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                                  const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                                                  const double *R_tri, double *err, double *H1, double *H2) {
+    if (ctx && !R_tri) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_eval_whitened_tri_batch: R_tri is NULL");
+    return factor_eval_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, R_tri, true, err, H1, H2);
 }
 
 extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
@@ -484,23 +495,29 @@ extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const d
     return CPI_OK;
 }
 
-extern "C" int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double *P, double *sqrt_info) {
+static int sqrt_information_impl(cpi_ctx *ctx, int64_t F, const double *P, double *R, bool packed) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (F < 0) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: negative size");
     if (F == 0) return CPI_OK;
-    if (!P || !sqrt_info) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: NULL argument");
+    if (!P || !R) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: NULL argument");
     if (!grid_ok(F)) return fail(ctx, CPI_ERR_INVALID, "cpi_sqrt_information_batch: F exceeds 2^31 - 1 factors per call");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    launch::sqrt_info((long long)F, P, sqrt_info, ctx->stream);
+    launch::sqrt_info((long long)F, P, R, packed, ctx->stream);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
 }
+extern "C" int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double *P, double *sqrt_info) {
+    return sqrt_information_impl(ctx, F, P, sqrt_info, false);
+}
+extern "C" int cpi_sqrt_information_packed_batch(cpi_ctx *ctx, int64_t F, const double *P_sym, double *R_tri) {
+    return sqrt_information_impl(ctx, F, P_sym, R_tri, true);
+}
 
-extern "C" int cpi_factor_hessian_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
-                                        const cpi_outputs *meas, const double *lin, const double *q_k_lin,
-                                        const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
-                                        const double *sqrt_info, double *hess) {
+static int factor_hessian_impl(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                               const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                               const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                               const double *sqrt_info, bool tri, double *hess) {
     if (!ctx) return fail(nullptr, CPI_ERR_INVALID, "ctx is NULL");
     if (F == 0) return CPI_OK;
     if (!sqrt_info || !hess) return fail(ctx, CPI_ERR_INVALID, "cpi_factor_hessian_batch: NULL argument");
@@ -509,10 +526,22 @@ extern "C" int cpi_factor_hessian_batch(cpi_ctx *ctx, int32_t model, const doubl
     if (rc != CPI_OK) return rc;
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    a.sqrt_info = sqrt_info;
+    a.sqrt_info = sqrt_info; a.r_tri = tri ? 1 : 0;
     launch::factor_hessian(model, a, hess, ctx->stream);
     CPI_HIP(ctx, hipGetLastError());
     return CPI_OK;
+}
+extern "C" int cpi_factor_hessian_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                        const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                        const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                                        const double *sqrt_info, double *hess) {
+    return factor_hessian_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, sqrt_info, false, hess);
+}
+extern "C" int cpi_factor_hessian_tri_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                            const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                            const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                                            const double *R_tri, double *hess) {
+    return factor_hessian_impl(ctx, model, grav, F, meas, lin, q_k_lin, states, S, idx_i, idx_j, R_tri, true, hess);
 }
 
 extern "C" int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
@@ -538,9 +567,9 @@ extern "C" int cpi_predict_batch(cpi_ctx *ctx, int32_t model, const double grav[
     return CPI_OK;
 }
 
-static const int OUT_N[12] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225 };
+static const int OUT_N[kOutFields] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225, CPI_TRI_DOUBLES };
 static double **out_field(cpi_outputs *o, int k) {
-    double **f[12] = { &o->DT, &o->alpha, &o->beta, &o->q, &o->J_q, &o->J_a, &o->J_b, &o->H_a, &o->H_b, &o->O_a, &o->O_b, &o->P };
+    double **f[kOutFields] = { &o->DT, &o->alpha, &o->beta, &o->q, &o->J_q, &o->J_a, &o->J_b, &o->H_a, &o->H_b, &o->O_a, &o->O_b, &o->P, &o->P_sym };
     return f[k];
 }
 static double *out_field_c(const cpi_outputs *o, int k) { cpi_outputs t = *o; return *out_field(&t, k); }
@@ -548,7 +577,7 @@ static double *out_field_c(const cpi_outputs *o, int k) { cpi_outputs t = *o; re
 extern "C" size_t cpi_outputs_slab_doubles(const cpi_outputs *mask, int64_t Wb) {
     if (!mask || Wb <= 0) return 0;
     size_t n = 0;
-    for (int k = 0; k < 12; k++) if (out_field_c(mask, k)) n += (size_t)OUT_N[k] * (size_t)Wb;
+    for (int k = 0; k < kOutFields; k++) if (out_field_c(mask, k)) n += (size_t)OUT_N[k] * (size_t)Wb;
     return n;
 }
 extern "C" int cpi_outputs_bind_slab(const cpi_outputs *mask, int64_t Wb, double *slab, cpi_outputs *bound) {
@@ -556,7 +585,7 @@ extern "C" int cpi_outputs_bind_slab(const cpi_outputs *mask, int64_t Wb, double
     cpi_outputs b;
     memset(&b, 0, sizeof b);
     size_t off = 0;
-    for (int k = 0; k < 12; k++)
+    for (int k = 0; k < kOutFields; k++)
         if (out_field_c(mask, k)) { *out_field(&b, k) = slab + off; off += (size_t)OUT_N[k] * (size_t)Wb; }
     *bound = b;
     return CPI_OK;
@@ -609,7 +638,7 @@ extern "C" int cpi_preintegrate_tiled_batch(cpi_ctx *ctx, const cpi_params *prm,
     if (!tiles || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: tiles/lin is NULL");
     if (prm->model == CPI_MODEL_V2 && !q_k_lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: model 2 needs q_k_lin");
     if (!grid_ok(W)) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: W exceeds 2^31 - 1 windows per call");
-    if (out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b || out->P)
+    if (out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b || out->P || out->P_sym)
         return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch: the tiled layout serves the mean outputs (DT, alpha, beta, q) only; "
                                           "Jacobians and covariance are FP64-bound, not HBM-bound: use cpi_preintegrate_batch");
     if (prm->lanes_per_window < 0 || prm->lanes_per_window > 8)
@@ -710,6 +739,10 @@ struct cpi_group {
     size_t staging_cap = 0;             // doubles
     int staging_dev = -1;
     int last_gather_sends = 0;          // messages per peer of the last gather (1 = slab path); cpi_group_last_gather_messages
+    // cpi_group_gather_chunk: a second non-blocking stream per device for the exchange (made at the first use), and one event per
+    // device to order it behind / ahead of the compute stream
+    std::vector<hipStream_t> xstreams;  // owned; empty until the first chunked gather
+    std::vector<hipEvent_t> xev;
 };
 static thread_local std::string g_group_err;
 static int gfail(cpi_group *g, int code, const std::string &msg) { if (g) g->err = msg; else g_group_err = msg; return code; }
@@ -719,6 +752,19 @@ extern "C" void cpi_shard_bounds(int64_t W, int rank, int n, int64_t *lo, int64_
     const int64_t a = std::min<int64_t>(W, (int64_t)rank * per);
     if (lo) *lo = a;
     if (hi) *hi = std::min<int64_t>(W, a + per);
+}
+// sub-block `chunk` of `chunks` of rank's block: equal sub-block size on every rank (cper = ceil(ceil(W / n) / chunks))
+extern "C" void cpi_shard_chunk_bounds(int64_t W, int rank, int n, int chunk, int chunks, int64_t *lo, int64_t *hi) {
+    int64_t a, b;
+    cpi_shard_bounds(W, rank, n, &a, &b);
+    if (chunks > 1) {
+        const int64_t per = n > 0 ? (W + n - 1) / n : W, cper = (per + chunks - 1) / chunks;
+        const int64_t ca = std::min<int64_t>(b, a + (int64_t)chunk * cper);
+        b = std::min<int64_t>(b, ca + cper);
+        a = ca;
+    }
+    if (lo) *lo = a;
+    if (hi) *hi = b;
 }
 extern "C" const char *cpi_group_last_error(const cpi_group *g) { return g ? g->err.c_str() : g_group_err.c_str(); }
 extern "C" int cpi_group_size(const cpi_group *g) { return g ? g->n : 0; }
@@ -732,6 +778,8 @@ extern "C" void cpi_group_destroy(cpi_group *g) {
         if (r < (int)g->comms.size() && g->comms[r] && g_rccl.CommDestroy) g_rccl.CommDestroy(g->comms[r]);
         if (r < (int)g->ctx.size() && g->ctx[r]) {
             (void)hipSetDevice(g->ctx[r]->device);
+            if (r < (int)g->xstreams.size() && g->xstreams[r]) (void)hipStreamDestroy(g->xstreams[r]);
+            if (r < (int)g->xev.size() && g->xev[r]) (void)hipEventDestroy(g->xev[r]);
             if (r < (int)g->streams.size() && g->streams[r]) (void)hipStreamDestroy(g->streams[r]);
             cpi_ctx_destroy(g->ctx[r]);
         }
@@ -797,14 +845,25 @@ extern "C" int cpi_group_synchronize(cpi_group *g) {
         const int rc = cpi_ctx_synchronize(g->ctx[r]);
         if (rc != CPI_OK) return gfail(g, rc, cpi_last_error(g->ctx[r]));
     }
+    if (!g->xstreams.empty()) {   // a chunked exchange that was not joined yet (cpi_group_gather_chunk)
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        hipError_t e = hipSuccess;
+        for (int r = 0; r < g->n && e == hipSuccess; r++) {
+            e = hipSetDevice(g->ctx[r]->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(g->xstreams[r]);
+        }
+        if (prev >= 0) (void)hipSetDevice(prev);
+        if (e != hipSuccess) return gfail(g, CPI_ERR_HIP, std::string("cpi_group_synchronize (exchange streams): ") + hipGetErrorString(e));
+    }
     return CPI_OK;
 }
 
 // Is rank r's local output set ONE slab -- the wanted fields back to back, field-major over wb >= cnt windows
 // (cpi_outputs_bind_slab)?  Returns its base, wb and the doubles to send (the last field only up to cnt windows).
 static bool slab_of(const cpi_outputs &loc, const cpi_outputs &want, long long cnt, const double *&base, long long &wb, size_t &len) {
-    int ks[12], nk = 0;
-    for (int k = 0; k < 12; k++) if (out_field_c(&want, k)) ks[nk++] = k;
+    int ks[kOutFields], nk = 0;
+    for (int k = 0; k < kOutFields; k++) if (out_field_c(&want, k)) ks[nk++] = k;
     if (nk == 0) return false;
     const double *p0 = out_field_c(&loc, ks[0]);
     if (!p0) return false;
@@ -827,34 +886,53 @@ static bool slab_of(const cpi_outputs &loc, const cpi_outputs &want, long long c
     return true;
 }
 
-extern "C" int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_outputs *local, const cpi_outputs *root_out) {
+// chunk < 0: the whole blocks, on the ranks' compute streams (cpi_group_gather).  chunk >= 0: sub-block `chunk` of `chunks` of every
+// block, on the exchange streams, ordered behind the compute streams' position at this call; the last chunk joins
+// (cpi_group_gather_chunk).
+static int gather_impl(cpi_group *g, int root, int64_t W, int chunk, int chunks, const cpi_outputs *local, const cpi_outputs *root_out) {
     if (!g) return gfail(nullptr, CPI_ERR_INVALID, "group is NULL");
     if (root < 0 || root >= g->n || W < 0 || !local || !root_out) return gfail(g, CPI_ERR_INVALID, "cpi_group_gather: invalid argument");
+    const bool chunked = chunk >= 0;
+    if (chunked && (chunks < 1 || chunk >= chunks)) return gfail(g, CPI_ERR_INVALID, "cpi_group_gather_chunk: chunk must lie in [0, chunks)");
     int prev = -1;
     (void)hipGetDevice(&prev);
     struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore_{prev};
     const int n = g->n;
+    if (chunked && g->xstreams.empty()) {
+        g->xstreams.assign(n, nullptr); g->xev.assign(n, nullptr);
+        for (int r = 0; r < n; r++)
+            if (hipSetDevice(g->ctx[r]->device) != hipSuccess || hipStreamCreateWithFlags(&g->xstreams[r], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&g->xev[r], hipEventDisableTiming) != hipSuccess)
+                return gfail(g, CPI_ERR_HIP, "cpi_group_gather_chunk: creating the exchange streams failed");
+    }
+    auto stream_of = [&](int r) { return chunked ? g->xstreams[r] : g->ctx[r]->stream; };
+    if (chunked) {   // the exchange of this sub-block starts where the compute streams stand NOW
+        for (int r = 0; r < n; r++)
+            if (hipSetDevice(g->ctx[r]->device) != hipSuccess || hipEventRecord(g->xev[r], g->ctx[r]->stream) != hipSuccess ||
+                hipStreamWaitEvent(g->xstreams[r], g->xev[r], 0) != hipSuccess)
+                return gfail(g, CPI_ERR_HIP, "cpi_group_gather_chunk: ordering the exchange stream behind the compute stream failed");
+    }
     long long lo[kMaxGroup], cnt[kMaxGroup], wb[kMaxGroup];
     const double *base[kMaxGroup];
     size_t len[kMaxGroup], stride = 0;
     bool any_field = false;
-    for (int k = 0; k < 12; k++) any_field = any_field || out_field_c(root_out, k);
+    for (int k = 0; k < kOutFields; k++) any_field = any_field || out_field_c(root_out, k);
     if (!any_field) return CPI_OK;
     // every wanted field must exist in every non-empty block
     bool slabs = n > 1;
     for (int r = 0; r < n; r++) {
         int64_t a, b;
-        cpi_shard_bounds(W, r, n, &a, &b);
+        if (chunked) cpi_shard_chunk_bounds(W, r, n, chunk, chunks, &a, &b); else cpi_shard_bounds(W, r, n, &a, &b);
         lo[r] = a; cnt[r] = b - a; wb[r] = 0; base[r] = nullptr; len[r] = 0;
         if (cnt[r] == 0) continue;
-        for (int k = 0; k < 12; k++)
+        for (int k = 0; k < kOutFields; k++)
             if (out_field_c(root_out, k) && !out_field_c(&local[r], k))
                 return gfail(g, CPI_ERR_INVALID, "cpi_group_gather: a field wanted at the root is NULL in a rank's local outputs");
         if (r == root) continue;
         if (slabs && slab_of(local[r], *root_out, cnt[r], base[r], wb[r], len[r])) stride = std::max(stride, len[r]);
         else slabs = false;
     }
-    hipStream_t rs = g->ctx[root]->stream;
+    hipStream_t rs = stream_of(root);
     // the slab path needs staging for n slabs on the root's device (grow-only; a re-allocation waits for the root's stream)
     if (slabs && stride > 0) {
         stride = (stride + 1) & ~(size_t)1;   // 16-byte aligned slabs
@@ -874,7 +952,7 @@ extern "C" int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_out
     if (n > 1) { rc = g_rccl.GroupStart(); if (rc != ncclSuccess) return gfail(g, CPI_ERR_RCCL, std::string("ncclGroupStart: ") + g_rccl.GetErrorString(rc)); }
     // the root's own block: device-to-device copies on its stream (unless it was computed in place)
     if (cnt[root] > 0) {
-        for (int k = 0; k < 12 && !hip_bad; k++) {
+        for (int k = 0; k < kOutFields && !hip_bad; k++) {
             double *dst = out_field_c(root_out, k);
             if (!dst) continue;
             const double *src = out_field_c(&local[root], k);
@@ -889,16 +967,16 @@ extern "C" int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_out
         if (r == root || cnt[r] == 0) continue;
         if (slabs) {   // ONE message per peer: its whole slab into the root's staging area
             rc = g_rccl.Recv(g->staging + (size_t)r * stride, len[r], ncclFloat64, r, g->comms[root], rs);
-            if (rc == ncclSuccess) rc = g_rccl.Send(base[r], len[r], ncclFloat64, root, g->comms[r], g->ctx[r]->stream);
+            if (rc == ncclSuccess) rc = g_rccl.Send(base[r], len[r], ncclFloat64, root, g->comms[r], stream_of(r));
             msgs = 1;
         } else {       // separately allocated fields: one message per (peer, field), received in place
             int m = 0;
-            for (int k = 0; k < 12 && rc == ncclSuccess; k++) {
+            for (int k = 0; k < kOutFields && rc == ncclSuccess; k++) {
                 double *dst = out_field_c(root_out, k);
                 if (!dst) continue;
                 const size_t c = (size_t)cnt[r] * (size_t)OUT_N[k];
                 rc = g_rccl.Recv(dst + (size_t)lo[r] * OUT_N[k], c, ncclFloat64, r, g->comms[root], rs);
-                if (rc == ncclSuccess) rc = g_rccl.Send(out_field_c(&local[r], k), c, ncclFloat64, root, g->comms[r], g->ctx[r]->stream);
+                if (rc == ncclSuccess) rc = g_rccl.Send(out_field_c(&local[r], k), c, ncclFloat64, root, g->comms[r], stream_of(r));
                 m++;
             }
             msgs = std::max(msgs, m);
@@ -917,7 +995,20 @@ extern "C" int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_out
         if (hipGetLastError() != hipSuccess) return gfail(g, CPI_ERR_HIP, "cpi_group_gather: the unpack launch failed");
     }
     g->last_gather_sends = msgs;
+    if (chunked && chunk == chunks - 1) {   // join: whatever is enqueued on the contexts from here on waits for the whole exchange
+        for (int r = 0; r < n; r++)
+            if (hipSetDevice(g->ctx[r]->device) != hipSuccess || hipEventRecord(g->xev[r], g->xstreams[r]) != hipSuccess ||
+                hipStreamWaitEvent(g->ctx[r]->stream, g->xev[r], 0) != hipSuccess)
+                return gfail(g, CPI_ERR_HIP, "cpi_group_gather_chunk: joining the exchange streams failed");
+    }
     return CPI_OK;
+}
+extern "C" int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_outputs *local, const cpi_outputs *root_out) {
+    return gather_impl(g, root, W, -1, 1, local, root_out);
+}
+extern "C" int cpi_group_gather_chunk(cpi_group *g, int root, int64_t W, int chunk, int chunks, const cpi_outputs *local_chunk,
+                                      const cpi_outputs *root_out) {
+    return gather_impl(g, root, W, chunk, chunks, local_chunk, root_out);
 }
 
 // -------------------------------------------------------------------------------- test hook (include/cpi_amd_test.h)
@@ -967,14 +1058,14 @@ struct HostPipe {
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     void *in[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // knots, count, lin, q_k_lin
     size_t in_cap[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    void *out[2][12] = {};
-    size_t out_cap[2][12] = {};
+    void *out[2][kOutFields] = {};
+    size_t out_cap[2][kOutFields] = {};
 };
 static void host_pipe_destroy(HostPipe *hp) {
     if (!hp) return;
     for (int s = 0; s < 2; s++) {
         for (int k = 0; k < 4; k++) if (hp->in[s][k]) (void)hipFree(hp->in[s][k]);
-        for (int k = 0; k < 12; k++) if (hp->out[s][k]) (void)hipFree(hp->out[s][k]);
+        for (int k = 0; k < kOutFields; k++) if (hp->out[s][k]) (void)hipFree(hp->out[s][k]);
         if (hp->ev_in[s]) (void)hipEventDestroy(hp->ev_in[s]);
         if (hp->ev_done[s]) (void)hipEventDestroy(hp->ev_done[s]);
         if (hp->ev_out[s]) (void)hipEventDestroy(hp->ev_out[s]);
@@ -1026,7 +1117,7 @@ static int preintegrate_host_pipeline(cpi_ctx *ctx, const cpi_params *prm, int64
                                  q_k_lin ? (size_t)Wc * 4 * sizeof(double) : 0 };
         for (int k = 0; k < 4; k++)
             if ((rc = host_pipe_reserve(ctx, hp->in[s][k], hp->in_cap[s][k], need[k])) != CPI_OK) return rc;
-        for (int k = 0; k < 12; k++)
+        for (int k = 0; k < kOutFields; k++)
             if (*out_field(&h, k) && (rc = host_pipe_reserve(ctx, hp->out[s][k], hp->out_cap[s][k], (size_t)Wc * OUT_N[k] * sizeof(double))) != CPI_OK) return rc;
     }
     // after the first enqueue nothing may return before the three streams are idle: copies into the caller's memory are in flight
@@ -1045,7 +1136,7 @@ static int preintegrate_host_pipeline(cpi_ctx *ctx, const cpi_params *prm, int64
         if (i >= 2 && !hip_ok(hipStreamWaitEvent(ctx->stream, hp->ev_out[s], 0), "hipStreamWaitEvent")) break;   // slot's outputs downloaded
         cpi_outputs d;
         memset(&d, 0, sizeof d);
-        for (int k = 0; k < 12; k++) if (*out_field(&h, k)) *out_field(&d, k) = (double *)hp->out[s][k];
+        for (int k = 0; k < kOutFields; k++) if (*out_field(&h, k)) *out_field(&d, k) = (double *)hp->out[s][k];
         if (tiled)
             rc = cpi_preintegrate_tiled_batch(ctx, prm, wn, N, (const double *)hp->in[s][0], count ? (const int32_t *)hp->in[s][1] : nullptr,
                                               (const double *)hp->in[s][2], q_k_lin ? (const double *)hp->in[s][3] : nullptr, &d);
@@ -1055,7 +1146,7 @@ static int preintegrate_host_pipeline(cpi_ctx *ctx, const cpi_params *prm, int64
         if (rc != CPI_OK) break;
         if (!hip_ok(hipEventRecord(hp->ev_done[s], ctx->stream), "hipEventRecord")) break;
         if (!hip_ok(hipStreamWaitEvent(hp->down, hp->ev_done[s], 0), "hipStreamWaitEvent")) break;
-        for (int k = 0; k < 12; k++)
+        for (int k = 0; k < kOutFields; k++)
             if (*out_field(&h, k) && !hip_ok(hipMemcpyAsync(*out_field(&h, k) + (size_t)w0 * OUT_N[k], hp->out[s][k], (size_t)wn * OUT_N[k] * sizeof(double),
                                                             hipMemcpyDeviceToHost, hp->down), "download")) break;
         if (!err.empty()) break;
@@ -1075,7 +1166,7 @@ extern "C" int cpi_preintegrate_tiled_batch_host(cpi_ctx *ctx, const cpi_params 
     if (!prm || !out || !tiles || !lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch_host: NULL argument");
     if (W <= 0) return W == 0 ? CPI_OK : fail(ctx, CPI_ERR_INVALID, "negative size");
     if (N < 0) return fail(ctx, CPI_ERR_INVALID, "negative size");
-    if (out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b || out->P)
+    if (out->J_q || out->J_a || out->J_b || out->H_a || out->H_b || out->O_a || out->O_b || out->P || out->P_sym)
         return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_tiled_batch_host: the tiled layout serves the mean outputs (DT, alpha, beta, q) only");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
@@ -1094,14 +1185,14 @@ extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, 
     CPI_HIP(ctx, guard_.enter(ctx->device));
     if (!first) return preintegrate_host_pipeline(ctx, prm, W, N, knots, false, count, lin, q_k_lin, out);
     // ragged windows share one knot stream: staged whole (one-off calls; the stream is usually small)
-    DevBuf dk, df, dc, dl, dq, dout[12];
+    DevBuf dk, df, dc, dl, dq, dout[kOutFields];
     CPI_UP(dk, knots, (size_t)n_knots * 7 * sizeof(double));
     CPI_UP(df, first, (size_t)W * sizeof(int64_t));
     CPI_UP(dc, count, (size_t)W * sizeof(int32_t));
     CPI_UP(dl, lin, (size_t)W * 6 * sizeof(double));
     CPI_UP(dq, q_k_lin, (size_t)W * 4 * sizeof(double));
     cpi_outputs d = *out, h = *out;
-    for (int k = 0; k < 12; k++)
+    for (int k = 0; k < kOutFields; k++)
         if (*out_field(&h, k)) {
             CPI_HIP(ctx, hipMalloc(&dout[k].p, (size_t)W * OUT_N[k] * sizeof(double)));
             *out_field(&d, k) = (double *)dout[k].p;
@@ -1109,7 +1200,7 @@ extern "C" int cpi_preintegrate_batch_host(cpi_ctx *ctx, const cpi_params *prm, 
     int rc = cpi_preintegrate_batch(ctx, prm, W, N, (const double *)dk.p, (const int64_t *)df.p, (const int32_t *)dc.p,
                                     (const double *)dl.p, (const double *)dq.p, &d);
     if (rc != CPI_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-    for (int k = 0; k < 12; k++)
+    for (int k = 0; k < kOutFields; k++)
         if (*out_field(&h, k))
             CPI_HIP(ctx, hipMemcpyAsync(*out_field(&h, k), dout[k].p, (size_t)W * OUT_N[k] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CPI_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1130,14 +1221,14 @@ extern "C" int cpi_preintegrate_stream_host(cpi_ctx *ctx, const cpi_params *prm,
     if (prm->model == CPI_MODEL_V2 && !q_k_lin) return fail(ctx, CPI_ERR_INVALID, "cpi_preintegrate_stream_host: model 2 needs q_k_lin");
     DeviceGuard guard_;
     CPI_HIP(ctx, guard_.enter(ctx->device));
-    DevBuf ds, du, dl, dq, dw, dout[12];
+    DevBuf ds, du, dl, dq, dw, dout[kOutFields];
     CPI_UP(ds, stream, (size_t)K * 7 * sizeof(double));
     CPI_UP(du, update_times, (size_t)U * sizeof(double));
     CPI_UP(dl, lin, (size_t)U * 6 * sizeof(double));
     CPI_UP(dq, q_k_lin, (size_t)U * 4 * sizeof(double));
     CPI_HIP(ctx, hipMalloc(&dw.p, cpi_stream_workspace_bytes(U)));
     cpi_outputs d = *out, h = *out;
-    for (int k = 0; k < 12; k++)
+    for (int k = 0; k < kOutFields; k++)
         if (*out_field(&h, k)) {
             CPI_HIP(ctx, hipMalloc(&dout[k].p, (size_t)U * OUT_N[k] * sizeof(double)));
             *out_field(&d, k) = (double *)dout[k].p;
@@ -1145,7 +1236,7 @@ extern "C" int cpi_preintegrate_stream_host(cpi_ctx *ctx, const cpi_params *prm,
     const int rc = cpi_preintegrate_stream(ctx, prm, K, (const double *)ds.p, U, (const double *)du.p, N, (const double *)dl.p,
                                            (const double *)dq.p, dw.p, &d);
     if (rc != CPI_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-    for (int k = 0; k < 12; k++)
+    for (int k = 0; k < kOutFields; k++)
         if (*out_field(&h, k))
             CPI_HIP(ctx, hipMemcpyAsync(*out_field(&h, k), dout[k].p, (size_t)U * OUT_N[k] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (count) CPI_HIP(ctx, hipMemcpyAsync(count, cpi_stream_counts(dw.p, U), (size_t)U * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -75,6 +75,7 @@ struct FactorArgs {
     double *H1;
     double *H2;
     const double *sqrt_info;   // optional [F][225] upper-triangular R: outputs are whitened (R err, R H1, R H2)
+    int r_tri;                 // sqrt_info is the packed upper triangle [F][120] (include/cpi_amd.h: CPI_TRI_INDEX)
 };
 
 struct PredictArgs {
@@ -119,7 +120,7 @@ void forster(const PreArgs &a, hipStream_t st);
 void factor(int model, bool whiten, int lpf, const FactorArgs &a, hipStream_t st);            // lpf 16 | 8 | 4
 void factor_packed(int model, int lpf, const FactorArgs &a, double *packed, hipStream_t st);  // lpf 2 | 3 | 4 | 6 | 8
 void factor_hessian(int model, const FactorArgs &a, double *hess, hipStream_t st);
-void sqrt_info(long long F, const double *P, double *R, hipStream_t st);
+void sqrt_info(long long F, const double *P, double *R, bool packed, hipStream_t st);   // packed: P_sym [F][120] -> R_tri [F][120]
 void predict(int model, const PredictArgs &a, hipStream_t st);
 #ifdef CPI_TEST_HOOKS
 void test_quat_ops(int op, long long n, const double *in, double *out, hipStream_t st);   // libcpi_amd_test.so only

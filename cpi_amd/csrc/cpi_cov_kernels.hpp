@@ -212,6 +212,11 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
 #pragma unroll
         for (int i = 0; i < 15; i++) p[i] = Ln.P0[i];
     }
+    if (A.out.P_sym && jj < 15) {   // the same column, rows 0 .. jj only: the packed upper triangle (CPI_TRI_INDEX), 960 B per window
+        double *p = A.out.P_sym + w * CPI_TRI_DOUBLES + jj * (jj + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < 15; i++) if (i <= jj) p[i] = Ln.P0[i];
+    }
     if (A.write_means && j == 0) {
         if (A.out.DT) A.out.DT[w] = gs[GS_DT];
         if (A.out.alpha) stv3(A.out.alpha + w * 3, rec_v3(gs, GS_ALPHA));
@@ -370,6 +375,11 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
         double *p = A.out.P + w * 225 + j * 15;
 #pragma unroll
         for (int i = 0; i < 15; i++) p[i] = x[i];
+    }
+    if (A.out.P_sym && j < 15) {   // packed upper triangle of the same matrix
+        double *p = A.out.P_sym + w * CPI_TRI_DOUBLES + j * (j + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < 15; i++) if (i <= j) p[i] = x[i];
     }
     if (j == 0) {
         if (A.out.DT) A.out.DT[w] = m.dT;

@@ -26,14 +26,14 @@ struct UnpackArgs {
     cpi_outputs out;
 };
 __global__ __launch_bounds__(256) void cpi_unpack_slabs_kernel(UnpackArgs U) {
-    const int NF[12] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225 };
-    double *const dst[12] = { U.out.DT, U.out.alpha, U.out.beta, U.out.q, U.out.J_q, U.out.J_a, U.out.J_b, U.out.H_a,
-                              U.out.H_b, U.out.O_a, U.out.O_b, U.out.P };
+    const int NF[13] = { 1, 3, 3, 4, 9, 9, 9, 9, 9, 9, 9, 225, CPI_TRI_DOUBLES };
+    double *const dst[13] = { U.out.DT, U.out.alpha, U.out.beta, U.out.q, U.out.J_q, U.out.J_a, U.out.J_b, U.out.H_a,
+                              U.out.H_b, U.out.O_a, U.out.O_b, U.out.P, U.out.P_sym };
     const int r = blockIdx.y;
     if (U.cnt[r] <= 0) return;
     long long off = 0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
+    for (int k = 0; k < 13; k++) {
         if (!dst[k]) continue;
         const long long len = U.cnt[r] * NF[k];
         const double *s = U.staging + (long long)r * U.stride + off;
@@ -71,14 +71,16 @@ namespace launch {
 
 void factor(int model, bool whiten, int lpf, const FactorArgs &a, hipStream_t st) {
     const long long F = a.F;
-#define CPI_LAUNCH_FACTOR(M, WH, L) \
-    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L>), dim3(factor_grid((F + 64 / L - 1) / (64 / L))), dim3(64), 0, st, a)
-#define CPI_LAUNCH_FACTOR_L(M, WH) \
-    do { if (lpf == 16) CPI_LAUNCH_FACTOR(M, WH, 16); else if (lpf == 8) CPI_LAUNCH_FACTOR(M, WH, 8); else CPI_LAUNCH_FACTOR(M, WH, 4); } while (0)
-    if (whiten) {
-        if (model == CPI_MODEL_V1) CPI_LAUNCH_FACTOR_L(1, true); else CPI_LAUNCH_FACTOR_L(2, true);
+#define CPI_LAUNCH_FACTOR(M, WH, L, TR) \
+    hipLaunchKernelGGL((cpi_factor_kernel<M, WH, L, TR>), dim3(factor_grid((F + 64 / L - 1) / (64 / L))), dim3(64), 0, st, a)
+#define CPI_LAUNCH_FACTOR_L(M, WH, TR) \
+    do { if (lpf == 16) CPI_LAUNCH_FACTOR(M, WH, 16, TR); else if (lpf == 8) CPI_LAUNCH_FACTOR(M, WH, 8, TR); else CPI_LAUNCH_FACTOR(M, WH, 4, TR); } while (0)
+    if (whiten && a.r_tri) {
+        if (model == CPI_MODEL_V1) CPI_LAUNCH_FACTOR_L(1, true, true); else CPI_LAUNCH_FACTOR_L(2, true, true);
+    } else if (whiten) {
+        if (model == CPI_MODEL_V1) CPI_LAUNCH_FACTOR_L(1, true, false); else CPI_LAUNCH_FACTOR_L(2, true, false);
     } else {
-        if (model == CPI_MODEL_V1) CPI_LAUNCH_FACTOR_L(1, false); else CPI_LAUNCH_FACTOR_L(2, false);
+        if (model == CPI_MODEL_V1) CPI_LAUNCH_FACTOR_L(1, false, false); else CPI_LAUNCH_FACTOR_L(2, false, false);
     }
 #undef CPI_LAUNCH_FACTOR_L
 #undef CPI_LAUNCH_FACTOR
@@ -94,12 +96,18 @@ void factor_packed(int model, int lpf, const FactorArgs &a, double *packed, hipS
 
 void factor_hessian(int model, const FactorArgs &a, double *hess, hipStream_t st) {
     const unsigned nb = factor_grid((a.F + 3) / 4);
-    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_hessian_kernel<1>), dim3(nb), dim3(64), 0, st, a, hess);
-    else hipLaunchKernelGGL((cpi_factor_hessian_kernel<2>), dim3(nb), dim3(64), 0, st, a, hess);
+    if (a.r_tri) {
+        if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_hessian_kernel<1, true>), dim3(nb), dim3(64), 0, st, a, hess);
+        else hipLaunchKernelGGL((cpi_factor_hessian_kernel<2, true>), dim3(nb), dim3(64), 0, st, a, hess);
+    } else {
+        if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_factor_hessian_kernel<1, false>), dim3(nb), dim3(64), 0, st, a, hess);
+        else hipLaunchKernelGGL((cpi_factor_hessian_kernel<2, false>), dim3(nb), dim3(64), 0, st, a, hess);
+    }
 }
 
-void sqrt_info(long long F, const double *P, double *R, hipStream_t st) {
-    hipLaunchKernelGGL(cpi_sqrt_info_kernel, dim3(factor_grid((F + 3) / 4)), dim3(64), 0, st, F, P, R);
+void sqrt_info(long long F, const double *P, double *R, bool packed, hipStream_t st) {
+    if (packed) hipLaunchKernelGGL(cpi_sqrt_info_kernel<true>, dim3(factor_grid((F + 3) / 4)), dim3(64), 0, st, F, P, R);
+    else hipLaunchKernelGGL(cpi_sqrt_info_kernel<false>, dim3(factor_grid((F + 3) / 4)), dim3(64), 0, st, F, P, R);
 }
 
 void predict(int model, const PredictArgs &a, hipStream_t st) {

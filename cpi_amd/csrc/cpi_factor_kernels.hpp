@@ -68,12 +68,13 @@ namespace fin {
 constexpr int O_ALPHA = 0, O_BETA = 3, O_Q = 6, O_LIN = 10, O_JQ = 16, O_JB = 25, O_JA = 34, O_HB = 43, O_HA = 52,
               O_DT = 61, O_QK = 62, O_OB = 66, O_OA = 75, O_XI = 84, O_XJ = 100, IN_D = 116;
 }
-template <int MODEL, int FPW, bool WHITEN>
+// RD: doubles of R per factor when WHITEN -- 225 (dense column-major) or CPI_TRI_DOUBLES (the packed upper triangle)
+template <int MODEL, int FPW, bool WHITEN, int RD = 225>
 __device__ __forceinline__ void factor_fetch_inputs(const FactorArgs &A, long long f0, int nf, int lane, double *sIn,
                                                     double *sR) {
     using namespace fin;
     constexpr bool whiten = WHITEN;
-    constexpr int HB = FPW * 225;
+    constexpr int HB = FPW * RD;
     // ---- cooperative, de-duplicated input fetch: every double of the FPW factors' records is loaded from HBM
     // exactly once per wavefront (consecutive lanes = consecutive doubles of one SoA field) into LDS, from
     // where the lanes of a factor read it as broadcasts.  All loads are issued unconditionally (clamped
@@ -109,7 +110,7 @@ __device__ __forceinline__ void factor_fetch_inputs(const FactorArgs &A, long lo
         double R_[WHITEN ? (HB + 63) / 64 : 1];
         if (whiten) {
 #pragma unroll
-            for (int r = 0; r < (HB + 63) / 64; r++) R_[r] = A.sqrt_info[f0 * 225 + min(lane + 64 * r, nf * 225 - 1)];
+            for (int r = 0; r < (HB + 63) / 64; r++) R_[r] = A.sqrt_info[f0 * RD + min(lane + 64 * r, nf * RD - 1)];
         }
         f_alpha.store(sIn, IN_D, O_ALPHA, lane); f_beta.store(sIn, IN_D, O_BETA, lane); f_q.store(sIn, IN_D, O_Q, lane);
         f_lin.store(sIn, IN_D, O_LIN, lane); f_jq.store(sIn, IN_D, O_JQ, lane); f_jb.store(sIn, IN_D, O_JB, lane);
@@ -165,15 +166,20 @@ __device__ __forceinline__ void whiten_col_dpp(const double (&Rc)[15], double (&
 #ifndef CPI_FACTOR_WPS
 #define CPI_FACTOR_WPS 1
 #endif
-template <int MODEL, bool WHITEN, int LPF>
+// TRI (WHITEN only): R arrives as its packed upper triangle (cpi_factor_eval_whitened_tri_batch): 120 instead of 225 doubles per
+// factor to fetch and to park in LDS; entry (i, k), i <= k, at i + k (k + 1) / 2.  The arithmetic never touched the zeros the
+// dense form stores below the diagonal, so the outputs are the same bits.
+template <int MODEL, bool WHITEN, int LPF, bool TRI = false>
 __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
+    static_assert(WHITEN || !TRI, "TRI is a layout of the whitening matrix");
     constexpr int FPW = 64 / LPF;                // factors per wavefront
     constexpr int CPL = (15 + LPF - 1) / LPF;    // columns per lane
     constexpr int HB = FPW * 225;                // doubles of H1 (or H2) per wavefront
+    constexpr int RD = TRI ? CPI_TRI_DOUBLES : 225;   // doubles of R per factor
     constexpr int IN_D = fin::IN_D;
     __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
     __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];         // the factors' input records
-    __shared__ __attribute__((aligned(16))) double sR[WHITEN ? HB : 2];     // whitening only: the factors' R
+    __shared__ __attribute__((aligned(16))) double sR[WHITEN ? FPW * RD : 2];   // whitening only: the factors' R
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = lane / LPF;
     const long long grp = factor_group_of_block((A.F + FPW - 1) / FPW);
@@ -182,12 +188,13 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     const int nf = (int)min((long long)FPW, A.F - f0);
     constexpr bool whiten = WHITEN;
 
-    factor_fetch_inputs<MODEL, FPW, WHITEN>(A, f0, nf, lane, sIn, sR);
+    factor_fetch_inputs<MODEL, FPW, WHITEN, RD>(A, f0, nf, lane, sIn, sR);
     __syncthreads();
     const double *in = sIn + fl * IN_D;
     const FactorMeas m = factor_meas_of(in, A.grav);   // every field is read from LDS where it is used
     double *s1 = sH, *se = sH + HB;
-    const double *Rf = sR + fl * 225;
+    const double *Rf = sR + fl * RD;
+    auto r_at = [&](int i, int k) -> double { return TRI ? Rf[k * (k + 1) / 2 + i] : Rf[k * 15 + i]; };   // R[i][k], i <= k
     const int nd = nf * 225, ne = nf * 15;
 
     // ---- shared algebra; the residual goes to the staging area at once.  Lane q of a factor publishes rows
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     double Rc[(WHITEN && LPF == 16) ? 15 : 1];
     if constexpr (WHITEN && LPF == 16) {
 #pragma unroll
-        for (int i = 0; i < 15; i++) Rc[i] = Rf[min(q, 14) * 15 + i];
+        for (int i = 0; i < 15; i++) Rc[i] = r_at(TRI ? min(i, min(q, 14)) : i, min(q, 14));   // (rows below the diagonal are never used: whiten_row_dpp)
     }
     auto whiten_col = [&](double (&h)[15]) {   // in place: out[i] = sum_{k >= i} R[i][k] h[k]
         if constexpr (WHITEN && LPF == 16) whiten_col_dpp<0>(Rc, h);
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
             for (int i = 0; i < 15; i++) {
                 double acc = 0.0;
 #pragma unroll
-                for (int k = i; k < 15; k++) acc = fma(Rf[k * 15 + i], h[k], acc);
+                for (int k = i; k < 15; k++) acc = fma(r_at(i, k), h[k], acc);
                 h[i] = acc;                   // rows are finished top-down, so h[k], k > i, is still unwhitened
             }
         }
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
         for (int k = 0; k < CPL; k++) {
             const int cr = min(q + LPF * k, 14);
             acc[k] = 0.0;
-            for (int j = 0; j < 15; j++) acc[k] = fma((j >= cr) ? Rf[j * 15 + cr] : 0.0, se[fl * 15 + j], acc[k]);
+            for (int j = 0; j < 15; j++) acc[k] = fma((j >= cr) ? r_at(cr, j) : 0.0, se[fl * 15 + j], acc[k]);
         }
         wave_lds_fence();
 #pragma unroll
@@ -414,9 +421,14 @@ __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], 
         chol_inv_step<K - 1>(a, u, acc, j);
     }
 }
+// PACKED (cpi_sqrt_information_packed_batch): P arrives as its upper triangle and R leaves as its non-zero triangle, 120 doubles
+// each (CPI_TRI_INDEX).  Lane j rebuilds its full symmetric column from the triangle -- rows i <= j from column j, rows i > j
+// from row j of column i -- and stores rows 0 .. j of its column of U: the same registers enter the same arithmetic as in the
+// dense form.
+template <bool PACKED>
 __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const double *P, double *Rout) {
-    constexpr int FPW = 4;
-    __shared__ __attribute__((aligned(16))) double sA[FPW * 225];
+    constexpr int FPW = 4, MD = PACKED ? CPI_TRI_DOUBLES : 225;
+    __shared__ __attribute__((aligned(16))) double sA[FPW * MD];
     const int lane = threadIdx.x, j = lane & 15, fl = lane >> 4;
     const long long grp = factor_group_of_block((F + FPW - 1) / FPW);
     if (grp < 0) return;
@@ -424,27 +436,33 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
     const int nf = (int)min((long long)FPW, F - f0);
     struct __attribute__((packed, aligned(8))) d2u { double a, b; };
     {
-        const int n2 = (nf * 225) >> 1;
-        const d2u *src = reinterpret_cast<const d2u *>(P + f0 * 225);
+        const int n2 = (nf * MD) >> 1;
+        const d2u *src = reinterpret_cast<const d2u *>(P + f0 * MD);
         for (int i = lane; i < n2; i += 64) { const d2u v = src[i]; sA[2 * i] = v.a; sA[2 * i + 1] = v.b; }
-        if (((nf * 225) & 1) && lane == 0) sA[nf * 225 - 1] = P[f0 * 225 + nf * 225 - 1];
+        if (((nf * MD) & 1) && lane == 0) sA[nf * MD - 1] = P[f0 * MD + nf * MD - 1];
     }
     wave_lds_fence();
     const int fc = min(fl, nf - 1), jc = min(j, 14);   // idle lanes (j == 15, missing factors) redo a valid column
     double a[15], u[15], acc[15];
 #pragma unroll
-    for (int i = 0; i < 15; i++) { a[i] = sA[fc * 225 + jc * 15 + i]; acc[i] = 0.0; }
+    for (int i = 0; i < 15; i++) {
+        a[i] = PACKED ? sA[fc * MD + ((i <= jc) ? jc * (jc + 1) / 2 + i : i * (i + 1) / 2 + jc)] : sA[fc * MD + jc * 15 + i];
+        acc[i] = 0.0;
+    }
     chol_inv_step<14>(a, u, acc, j);
     wave_lds_fence();   // the column reads above are complete (in-order DS) before the staging area is reused
     if (j < 15 && fl < nf) {
 #pragma unroll
-        for (int i = 0; i < 15; i++) sA[fl * 225 + j * 15 + i] = u[i];
+        for (int i = 0; i < 15; i++) {
+            if constexpr (PACKED) { if (i <= j) sA[fl * MD + j * (j + 1) / 2 + i] = u[i]; }
+            else sA[fl * MD + j * 15 + i] = u[i];
+        }
     }
     wave_lds_fence();
     {
-        const int n2 = (nf * 225) >> 1;
-        for (int i = lane; i < n2; i += 64) st16_nt(Rout + f0 * 225 + 2 * i, sA[2 * i], sA[2 * i + 1]);
-        if (((nf * 225) & 1) && lane == 0) Rout[f0 * 225 + nf * 225 - 1] = sA[nf * 225 - 1];
+        const int n2 = (nf * MD) >> 1;
+        for (int i = lane; i < n2; i += 64) st16_nt(Rout + f0 * MD + 2 * i, sA[2 * i], sA[2 * i + 1]);
+        if (((nf * MD) & 1) && lane == 0) Rout[f0 * MD + nf * MD - 1] = sA[nf * MD - 1];
     }
 }
 
@@ -546,10 +564,12 @@ __device__ __forceinline__ void tab_h2t(const double (&w)[15], const BlkTab &T, 
     put3(t + 9, ldv(w + 9));
     put3(t + 12, tab_mulT<B_RK>(T, ldv(w + 12)));
 }
-template <int MODEL>
+// TRI: R arrives as its packed upper triangle (cpi_factor_hessian_tri_batch): 480 instead of 900 doubles per wavefront to
+// fetch; the lane's column of R is completed with the zeros the dense form stores below the diagonal -- same registers, same bits.
+template <int MODEL, bool TRI = false>
 __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
     using namespace hsn;
-    constexpr int FPW = 4, IN_D = fin::IN_D;
+    constexpr int FPW = 4, IN_D = fin::IN_D, RD = TRI ? CPI_TRI_DOUBLES : 225;
     // [input records | R] -> [zx | lam] with the block tables at the far end (dead before lam reaches them); at the end
     // everything is dead and becomes the output stage
     constexpr int U1 = FPW * MAT_D;
@@ -569,16 +589,16 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
     const int qr = min(q, 14);                               // lane 15 shadows row 14 in the row phase
 
     // ---- the input records
-    constexpr int RT = (FPW * 225 + 63) / 64;
+    constexpr int RT = (FPW * RD + 63) / 64;
     {
-        // the R matrices of the wavefront (900 doubles, coalesced) travel with the input records: ONE memory round trip
+        // the R matrices of the wavefront (900 doubles, or 480 packed; coalesced) travel with the input records: ONE memory round trip
         double rr[RT];
 #pragma unroll
-        for (int t = 0; t < RT; t++) rr[t] = A.sqrt_info[f0 * 225 + min(lane + 64 * t, nf * 225 - 1)];
+        for (int t = 0; t < RT; t++) rr[t] = A.sqrt_info[f0 * RD + min(lane + 64 * t, nf * RD - 1)];
         factor_fetch_inputs<MODEL, FPW, false>(A, f0, nf, lane, sU1, sDummy);
 #pragma unroll
         for (int t = 0; t < RT; t++)
-            if (lane + 64 * t < FPW * 225) sR[lane + 64 * t] = rr[t];
+            if (lane + 64 * t < FPW * RD) sR[lane + 64 * t] = rr[t];
     }
     __syncthreads();
 
@@ -615,7 +635,10 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
     {
         double l[15], z[15], own[15];
 #pragma unroll
-        for (int k = 0; k < 15; k++) own[k] = sR[f * 225 + qr * 15 + k];
+        for (int k = 0; k < 15; k++) {
+            if constexpr (TRI) { const double v = sR[f * RD + qr * (qr + 1) / 2 + min(k, qr)]; own[k] = (k <= qr) ? v : 0.0; }
+            else own[k] = sR[f * 225 + qr * 15 + k];
+        }
         lambda_row_dpp<0>(own, l);
         tab_h1t(l, T, z);
         double y = tmul<TB_ERR>(T, l[0]);

@@ -63,6 +63,14 @@ public:
     void bounds(int64_t W, int rank, int64_t &lo, int64_t &hi) const { cpi_shard_bounds(W, rank, size(), &lo, &hi); }
     void check(int rc) const { if (rc != CPI_OK) throw std::runtime_error(cpi_group_last_error(g_)); }
     void gather(int root, int64_t W, const cpi_outputs *local, const cpi_outputs &root_out) { check(cpi_group_gather(g_, root, W, local, &root_out)); }
+    // The exchange inside ONE batch (include/cpi_amd.h: cpi_group_gather_chunk): every block in `chunks` sub-blocks
+    // (chunk_bounds), sub-block c on the wire -- on the group's exchange streams -- while the kernels of sub-block c + 1 run.
+    //   for (c = 0; c < chunks; c++) { for every rank r: enqueue the entries for chunk_bounds(W, r, c, chunks) on ctx(r);
+    //                                  gather_chunk(root, W, c, chunks, local_c, root_out); }      // the last call joins
+    void chunk_bounds(int64_t W, int rank, int chunk, int chunks, int64_t &lo, int64_t &hi) const { cpi_shard_chunk_bounds(W, rank, size(), chunk, chunks, &lo, &hi); }
+    void gather_chunk(int root, int64_t W, int chunk, int chunks, const cpi_outputs *local_chunk, const cpi_outputs &root_out) {
+        check(cpi_group_gather_chunk(g_, root, W, chunk, chunks, local_chunk, &root_out));
+    }
     void synchronize() { check(cpi_group_synchronize(g_)); }
     int last_gather_messages() const { return cpi_group_last_gather_messages(g_); }   // per peer; 1 = slab path
 private:
@@ -78,10 +86,14 @@ struct CpiResult {
     Mat15 P_meas{};
 };
 
-// The context a lazy read runs on when the preintegrator was not bound to one (CpiBase::bind): one per process, on the
-// current device.  Calls on a context are not re-entrant: threads that read results concurrently bind their own contexts.
+// The context a lazy read runs on when the preintegrator was not bound to one (CpiBase::bind): one per THREAD, on the device
+// that is current when the thread first reads a result.  Calls on one context are not re-entrant, and the reference's result
+// members are plain per-object data that different threads may read side by side -- so reads of DIFFERENT preintegrators from
+// different threads each use their own thread's context (stream, staging) and do not race.  ONE preintegrator read from two
+// threads at once is still a data race on its members the first time (the read runs the recursion and stores the results):
+// read it once before sharing it, or guard it -- INTEGRATION.md section 3.
 inline const Context &default_context() {
-    static Context ctx;
+    static thread_local Context ctx;
     return ctx;
 }
 
@@ -93,7 +105,7 @@ class CpiBase;
 template <class T>
 class Lazy {
 public:
-    explicit Lazy(const CpiBase *owner, const T &init = T{}) : v_(init), owner_(owner) {}
+    explicit Lazy(const CpiBase *owner, const T &init = T{}, bool mean = false) : v_(init), owner_(owner), mean_(mean) {}
     Lazy(const Lazy &) = delete;                       // members of ONE preintegrator: CpiBase's copy operations re-bind them
     Lazy &operator=(const Lazy &) = delete;
     Lazy &operator=(const T &v) { v_ = v; return *this; }
@@ -109,6 +121,7 @@ private:
     inline void sync() const;
     T v_;
     const CpiBase *owner_;
+    bool mean_;            // one of DT / alpha_tau / beta_tau / q_k2tau: valid after a mean-only flush
 };
 
 class CpiBase {
@@ -120,7 +133,7 @@ public:
         if (this == &o) return *this;
         imu_avg = o.imu_avg; state_transition_jacobians = o.state_transition_jacobians;
         b_w_lin = o.b_w_lin; b_a_lin = o.b_a_lin; q_k_lin = o.q_k_lin; grav = o.grav;
-        knots_ = o.knots_; model_ = o.model_; ctx_ = o.ctx_; dirty_ = o.dirty_;
+        knots_ = o.knots_; model_ = o.model_; ctx_ = o.ctx_; dirty_ = o.dirty_; means_only_ = o.means_only_;
         for (int i = 0; i < 4; i++) sig_[i] = o.sig_[i];
         put(o.peek());
         return *this;
@@ -128,10 +141,17 @@ public:
     virtual ~CpiBase() {}
     // the context lazy reads run on (default: default_context()); the Context must outlive the reads
     void bind(const Context &ctx) { ctx_ = &ctx; }
+    // Like the reference (CpiBase.h:73-80, which only stores the values; the recursion reads them at every feed_IMU), the
+    // linearisation point belongs BEFORE the first feed_IMU.  Here the recursion runs at the first read, with the values current
+    // then; a call after results were read marks them stale, so the next read recomputes the window at the new point (the
+    // reference would keep integrating the old prefix with the old point -- a use it never makes).  Assigning the public members
+    // b_w_lin / b_a_lin / q_k_lin / grav / imu_avg directly is NOT tracked: call invalidate() afterwards.
     void setLinearizationPoints(const Vec3 &b_w_lin_, const Vec3 &b_a_lin_, const Vec4 &q_k_lin_ = Vec4{{0, 0, 0, 0}},
                                 const Vec3 &grav_ = Vec3{{0, 0, 0}}) {
         b_w_lin = b_w_lin_; b_a_lin = b_a_lin_; q_k_lin = q_k_lin_; grav = grav_;
+        if (!knots_.empty()) dirty_ = true;
     }
+    void invalidate() { if (!knots_.empty()) dirty_ = true; }
     // Records interval [t_0, t_1] with readings (w_m_0, a_m_0) at t_0 and (w_m_1, a_m_1) at t_1.
     // Differences from CpiV1::feed_IMU / CpiV2::feed_IMU (CpiV1.h:62-74):
     //  * t_1 - t_0 < 0: the reference's feed_IMU integrates the interval with the negative dt (only its caller,
@@ -177,10 +197,13 @@ public:
         set_result(r);
     }
     // the result members as plain values (runs the pending intervals first) / stored from outside (CpiBatch)
-    CpiResult result() const { ensure(); return peek(); }
-    void set_result(const CpiResult &r) { put(r); dirty_ = false; }
-    void set_means(double DT_, const Vec3 &alpha, const Vec3 &beta, const Vec4 &q) {   // CpiBatch::flush_means: the other members keep their values
-        DT.v_ = DT_; alpha_tau.v_ = alpha; beta_tau.v_ = beta; q_k2tau.v_ = q; dirty_ = false;
+    CpiResult result() const { ensure(true); return peek(); }
+    void set_result(const CpiResult &r) { put(r); dirty_ = false; means_only_ = false; }
+    // CpiBatch::flush_means: only DT / alpha_tau / beta_tau / q_k2tau were computed.  The Jacobian and covariance members are
+    // NOT valid for the recorded intervals: the first read of one of them runs the whole window (finalize), reads of the four
+    // means do not.
+    void set_means(double DT_, const Vec3 &alpha, const Vec3 &beta, const Vec4 &q) {
+        DT.v_ = DT_; alpha_tau.v_ = alpha; beta_tau.v_ = beta; q_k2tau.v_ = q; dirty_ = false; means_only_ = true;
     }
     cpi_params params() const {
         cpi_params p{};
@@ -210,9 +233,9 @@ public:
     Vec4 q_k_lin{};
     Vec3 grav{};
     // CpiBase.h:99-124 (+ CpiV2.h O_a / O_b): computed on first read after a feed_IMU
-    Lazy<double> DT{this, 0.0};
-    Lazy<Vec3> alpha_tau{this}, beta_tau{this};
-    Lazy<Vec4> q_k2tau{this, Vec4{{0, 0, 0, 1}}};
+    Lazy<double> DT{this, 0.0, true};
+    Lazy<Vec3> alpha_tau{this, Vec3{}, true}, beta_tau{this, Vec3{}, true};
+    Lazy<Vec4> q_k2tau{this, Vec4{{0, 0, 0, 1}}, true};
     Lazy<Mat3> J_q{this}, J_a{this}, J_b{this}, H_a{this}, H_b{this}, O_a{this}, O_b{this};
     Lazy<Mat15> P_meas{this};
 
@@ -227,7 +250,8 @@ protected:
     std::vector<double> knots_;
 private:
     template <class T> friend class Lazy;
-    void ensure() const { if (dirty_) const_cast<CpiBase *>(this)->finalize(ctx_ ? *ctx_ : default_context()); }
+    // full: the member being read is a Jacobian / covariance (not one of the four means)
+    void ensure(bool full = true) const { if (dirty_ || (full && means_only_)) const_cast<CpiBase *>(this)->finalize(ctx_ ? *ctx_ : default_context()); }
     CpiResult peek() const {                     // the stored values, without running anything
         CpiResult r;
         r.DT = DT.v_; r.alpha_tau = alpha_tau.v_; r.beta_tau = beta_tau.v_; r.q_k2tau = q_k2tau.v_;
@@ -244,8 +268,9 @@ private:
     double sig_[4] = {0, 0, 0, 0};
     const Context *ctx_ = nullptr;
     bool dirty_ = false;                         // intervals recorded since the result members were last computed
+    bool means_only_ = false;                    // the last computation (CpiBatch::flush_means) filled the four means only
 };
-template <class T> inline void Lazy<T>::sync() const { owner_->ensure(); }
+template <class T> inline void Lazy<T>::sync() const { owner_->ensure(!mean_); }
 
 class CpiV1 : public CpiBase {
 public:

@@ -23,8 +23,52 @@ MEAN_FIELDS = ("DT", "alpha", "beta", "q")
 JAC_FIELDS = ("J_q", "J_a", "J_b", "H_a", "H_b", "O_a", "O_b")
 
 
+def _group_of(name):
+    """want-group of an output field: "mean", "jac", "cov" (P, dense 15 x 15) or "cov_sym" (P_sym: its packed upper triangle, 120
+    doubles -- include/cpi_amd.h CPI_TRI_INDEX)."""
+    if name in MEAN_FIELDS:
+        return "mean"
+    return "cov" if name == "P" else ("cov_sym" if name == "P_sym" else "jac")
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _tri_index(device=None):
+    """(rows, cols) of the packed upper triangle in storage order: entry k of a packed matrix is (rows[k], cols[k])."""
+    cols = torch.repeat_interleave(torch.arange(15, device=device), torch.arange(1, 16, device=device))
+    start = cols * (cols + 1) // 2
+    rows = torch.arange(120, device=device) - start
+    return rows, cols
+
+
+def pack_sym(M):
+    """Dense [F, 225] (column-major 15 x 15; symmetric or upper triangular) -> packed upper triangle [F, 120]
+    (include/cpi_amd.h: entry (i, j), i <= j, at i + j (j + 1) / 2).  pack_tri is the same gather."""
+    rows, cols = _tri_index(M.device)
+    return M.reshape(-1, 225)[:, cols * 15 + rows].contiguous()
+
+
+pack_tri = pack_sym
+
+
+def unpack_sym(Ps):
+    """Packed upper triangle [F, 120] of a SYMMETRIC matrix (cpi_outputs.P_sym) -> dense [F, 225], both halves filled."""
+    rows, cols = _tri_index(Ps.device)
+    M = torch.zeros((Ps.shape[0], 225), dtype=Ps.dtype, device=Ps.device)
+    M[:, rows * 15 + cols] = Ps      # lower half (element (j, i) of the column-major matrix sits at i * 15 + j)
+    M[:, cols * 15 + rows] = Ps
+    return M
+
+
+def unpack_tri(Rt):
+    """Packed [F, 120] of an UPPER-TRIANGULAR matrix (R_tri of cpi_sqrt_information_packed_batch) -> dense [F, 225]
+    column-major with zeros below the diagonal (what cpi_sqrt_information_batch writes)."""
+    rows, cols = _tri_index(Rt.device)
+    M = torch.zeros((Rt.shape[0], 225), dtype=Rt.dtype, device=Rt.device)
+    M[:, cols * 15 + rows] = Rt
+    return M
 
 
 class _nullctx:
@@ -101,7 +145,7 @@ class Engine:
         multi-GPU gather one collective (cpi_amd.dist.gather_packed)."""
         names = []
         for name, n in OUT_FIELDS:
-            grp = "mean" if name in MEAN_FIELDS else ("cov" if name == "P" else "jac")
+            grp = _group_of(name)
             if grp not in want:
                 continue
             if model != 2 and name in ("O_a", "O_b"):
@@ -161,7 +205,7 @@ class Engine:
         if out is None:
             out = {}
             for name, n in OUT_FIELDS:
-                grp = "mean" if name in MEAN_FIELDS else ("cov" if name == "P" else "jac")
+                grp = _group_of(name)
                 if grp in want and (params.model == 2 or name not in ("O_a", "O_b")):
                     out[name] = torch.empty((W,) if n == 1 else (W, n), dtype=torch.float64, pin_memory=pinned)
         o = self._outputs_struct(out)
@@ -207,15 +251,21 @@ class Engine:
         GraphSolver_IMU.cpp:43-75 for all windows at once, zero copies of the IMU data, every model and output).
         stream [K, 7] with non-decreasing stamps, update_times [U] non-decreasing, lin [U, 6], q_k_lin [U, 4]: CUDA float64.
         N = upper bound of the intervals per window; with check_counts (one synchronisation) raises when a window holds more.
-        Default: the exact bound, computed from the stamps (one searchsorted over the K stamps + one synchronisation) -- the
-        library picks the mean kernel's lane split from N, so a loose bound (round 4's default was the whole stream) costs
-        speed on small batches; pass N to skip that pass."""
+        N=None (default): the exact bound, computed from the stamps by stream_bound() -- one searchsorted over the K stamps and ONE
+        HOST SYNCHRONISATION on first use of a (stream, update_times) pair (cached afterwards by storage and version), issued on
+        the engine's stream: that first call is NOT asynchronous and NOT graph-capturable.  Callers that need either pass an integer
+        N (e.g. stream_bound() taken once, outside the capture) or N="loose" = min(K, 65535): no pass over the stamps, no
+        synchronisation -- the library picks the mean kernel's lane split from N, so a loose bound costs speed on small batches
+        (and check_counts=False keeps the whole call free of synchronisations)."""
         params = params or self.make_params()
         K, U = stream.shape[0], update_times.shape[0]
         for t in (stream, update_times, lin, q_k_lin):
             assert t is None or (t.is_cuda and t.is_contiguous() and t.dtype == torch.float64), "inputs must be contiguous CUDA float64 tensors"
         if N is None:
-            N = self._stream_bound(stream, update_times)
+            N = self.stream_bound(stream, update_times)
+        elif isinstance(N, str):
+            assert N == "loose", 'N: an integer, None (exact bound, synchronises once per pair) or "loose"'
+            N = max(1, min(K, 65535))
         if out is None:
             out = self.alloc_outputs(U, want, params.model)
         ws = workspace if workspace is not None else self.stream_workspace(U)
@@ -238,10 +288,23 @@ class Engine:
                 raise ValueError("preintegrate_stream: a window has %d intervals, more than N = %d" % (int(counts.max().item()), N))
         return (out, counts) if return_counts else out
 
+    def stream_bound(self, stream, update_times):
+        """Longest window (whole intervals + a tail) that cutting `stream` at `update_times` can produce: the closed form of
+        the deque loop (GraphSolver_IMU.cpp:50-69; cpi_cut_windows_kernel) on the stamps, tail assumed.  Device tensors: issued
+        on the ENGINE's stream (not torch's current one) and followed by one host synchronisation (.item()); the result is cached
+        per (storage, shape, version) of the two tensors, so a loop over the same buffers pays it once."""
+        key = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in (stream, update_times))
+        hit = getattr(self, "_bound_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        pinned = stream.is_cuda and not self._follow and self.stream is not None
+        with torch.cuda.stream(self.stream) if pinned else _nullctx():
+            n = self._stream_bound(stream, update_times)
+        self._bound_cache = (key, n)
+        return n
+
     @staticmethod
     def _stream_bound(stream, update_times):
-        """Longest window (whole intervals + a tail) that cutting `stream` at `update_times` can produce: the closed form of
-        the deque loop (GraphSolver_IMU.cpp:50-69; cpi_cut_windows_kernel) on the stamps, tail assumed."""
         K, U = stream.shape[0], update_times.shape[0]
         if K == 0 or U == 0:
             return 1
@@ -267,7 +330,7 @@ class Engine:
             assert t is None or (not t.is_cuda and t.is_contiguous() and t.dtype == torch.float64), "inputs must be contiguous CPU float64 tensors"
         out = {}
         for name, n in OUT_FIELDS:
-            grp = "mean" if name in MEAN_FIELDS else ("cov" if name == "P" else "jac")
+            grp = _group_of(name)
             if grp in want and (params.model == 2 or name not in ("O_a", "O_b")):
                 out[name] = torch.empty((U,) if n == 1 else (U, n), dtype=torch.float64, pin_memory=pinned)
         cnt = torch.empty((U,), dtype=torch.int32)
@@ -349,17 +412,23 @@ class Engine:
         return call, out
 
     # ------------------------------------------------------------------ factors
-    def sqrt_information(self, P):
-        """R = chol_upper(P^-1) per factor (GTSAM noiseModel::Gaussian::Covariance); P [F,225] -> R [F,225]."""
-        F = P.shape[0]
-        R = torch.empty((F, 225), dtype=torch.float64, device=self.device)
+    def sqrt_information(self, P, out=None):
+        """R = chol_upper(P^-1) per factor (GTSAM noiseModel::Gaussian::Covariance).  P [F,225] (dense) -> R [F,225] with zeros
+        below the diagonal; P [F,120] (the packed upper triangle: outputs' P_sym) -> R_tri [F,120], the same values
+        (cpi_sqrt_information_packed_batch)."""
+        F, n = P.shape
+        assert n in (225, 120) and P.is_contiguous(), "P must be [F,225] (dense) or [F,120] (packed upper triangle)"
+        R = out if out is not None else torch.empty((F, n), dtype=torch.float64, device=self.device)
+        assert R.shape == (F, n) and R.is_contiguous()
         self._sync_stream()
-        self._check(self.lib.cpi_sqrt_information_batch(self.ctx, F, _ptr(P), _ptr(R)))
+        fn = self.lib.cpi_sqrt_information_batch if n == 225 else self.lib.cpi_sqrt_information_packed_batch
+        self._check(fn(self.ctx, F, _ptr(P), _ptr(R)))
         return R
 
     def factor_eval(self, model, meas, lin, q_k_lin, states, idx_i=None, idx_j=None, want_H=True, grav=DEFAULT_GRAV,
                     out=None, sqrt_info=None):
-        """sqrt_info [F,225] (from sqrt_information): return the WHITENED residual / Jacobians (R e, R H1, R H2)."""
+        """sqrt_info [F,225] or its packed triangle [F,120] (from sqrt_information): return the WHITENED residual / Jacobians
+        (R e, R H1, R H2); the packed form reads 840 bytes less per factor and gives the same bits."""
         F = lin.shape[0]
         if out is None:
             out = {"err": torch.empty((F, 15), dtype=torch.float64, device=self.device)}
@@ -374,10 +443,10 @@ class Engine:
                                                        _ptr(states), states.shape[0], _ptr(idx_i), _ptr(idx_j),
                                                        _ptr(out["err"]), _ptr(out.get("H1")), _ptr(out.get("H2"))))
         else:
-            self._check(self.lib.cpi_factor_eval_whitened_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin),
-                                                                _ptr(q_k_lin), _ptr(states), states.shape[0], _ptr(idx_i),
-                                                                _ptr(idx_j), _ptr(sqrt_info), _ptr(out["err"]),
-                                                                _ptr(out.get("H1")), _ptr(out.get("H2"))))
+            assert sqrt_info.shape == (F, 225) or sqrt_info.shape == (F, 120)
+            fn = self.lib.cpi_factor_eval_whitened_batch if sqrt_info.shape[1] == 225 else self.lib.cpi_factor_eval_whitened_tri_batch
+            self._check(fn(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin), _ptr(states), states.shape[0], _ptr(idx_i),
+                           _ptr(idx_j), _ptr(sqrt_info), _ptr(out["err"]), _ptr(out.get("H1")), _ptr(out.get("H2"))))
         return out
 
     def factor_eval_packed(self, model, meas, lin, q_k_lin, states, idx_i=None, idx_j=None, grav=DEFAULT_GRAV, out=None):
@@ -403,9 +472,10 @@ class Engine:
         m = self._outputs_struct(meas)
         g = (C.c_double * 3)(*grav)
         self._sync_stream()
-        self._check(self.lib.cpi_factor_hessian_batch(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin),
-                                                      _ptr(states), states.shape[0], _ptr(idx_i), _ptr(idx_j),
-                                                      _ptr(sqrt_info), _ptr(out)))
+        assert sqrt_info.shape == (F, 225) or sqrt_info.shape == (F, 120), "sqrt_info: [F,225] dense or [F,120] packed triangle"
+        fn = self.lib.cpi_factor_hessian_batch if sqrt_info.shape[1] == 225 else self.lib.cpi_factor_hessian_tri_batch
+        self._check(fn(self.ctx, int(model), g, F, C.byref(m), _ptr(lin), _ptr(q_k_lin), _ptr(states), states.shape[0], _ptr(idx_i),
+                       _ptr(idx_j), _ptr(sqrt_info), _ptr(out)))
         return out
 
     def predict(self, model, meas, states_i, idx_i=None, grav=DEFAULT_GRAV, out=None):

@@ -32,7 +32,12 @@
 extern "C" {
 #endif
 
-#define CPI_ABI_VERSION 2   /* 2: state count S in the factor / predict entries; device-set entries (cpi_group_*);
+#define CPI_ABI_VERSION 3   /* 3 (round 6): cpi_outputs gained a 13th field, P_sym (the covariance as its packed upper triangle) -- a binding
+                               built against version 2 passes a 12-field struct and must be rebuilt; new symbols
+                               cpi_sqrt_information_packed_batch, cpi_factor_eval_whitened_tri_batch, cpi_factor_hessian_tri_batch,
+                               cpi_group_gather_chunk, cpi_shard_chunk_bounds; this number also records round 4's workspace-contract
+                               change of cpi_preintegrate_stream (below), which version 2 carried only in prose.
+                               2: state count S in the factor / predict entries; device-set entries (cpi_group_*);
                                additions within 2 (new symbols only): tiled layout entries, cpi_host_alloc / _free;
                                round 3: cpi_preintegrate_stream (+ _workspace_bytes, _counts), cpi_tile_windows,
                                cpi_assemble_tiles, cpi_preintegrate_tiled_batch_host,
@@ -78,7 +83,7 @@ typedef struct {
  * Structure-of-arrays over the W windows of a batch; any pointer may be NULL = "not wanted":
  *   DT, alpha, beta, q all NULL      -> means are not written
  *   J_q ... O_b all NULL             -> bias / orientation Jacobians are not computed
- *   P NULL                           -> the covariance recursion is skipped (mean-only kernel) */
+ *   P and P_sym both NULL            -> the covariance recursion is skipped (mean-only kernel) */
 typedef struct {
     double *DT;     /* [W]       CpiBase::DT        */
     double *alpha;  /* [W][3]    alpha_tau          */
@@ -91,8 +96,22 @@ typedef struct {
     double *H_b;    /* [W][9]    beta wrt b_a       */
     double *O_a;    /* [W][9]    alpha wrt q_k_lin (model 2) */
     double *O_b;    /* [W][9]    beta wrt q_k_lin  (model 2) */
-    double *P;      /* [W][225]  P_meas             */
+    double *P;      /* [W][225]  P_meas, dense column-major (the drop-in form: Eigen::Map<Matrix<double,15,15>>) */
+    double *P_sym;  /* [W][120]  P_meas as its packed upper triangle (CPI_SYM_PACKED below; P_meas is symmetric -- the
+                                 reference itself asserts it, CpiV1.h:352-353 -- so the dense form carries 105 redundant doubles
+                                 = 840 of the 2 320 bytes a window writes).  P and P_sym are independent: either, both or
+                                 neither; the entries of P_sym are bit for bit the entries (i, j), i <= j, of P */
 } cpi_outputs;
+
+/* Packed triangles (ABI 3).  A symmetric 15 x 15 matrix (P_meas) is stored as its upper triangle, an upper-triangular one (the
+ * square-root information R) as its non-zero part, both COLUMN by column -- LAPACK's packed 'U' order, the order
+ * cpi_factor_hessian_batch already writes its 31 x 31 triangle in:
+ *     entry (i, j), i <= j, at  CPI_TRI_INDEX(i, j) = i + j (j + 1) / 2,      120 doubles = 960 bytes instead of 1 800.
+ * Column j is the run [j (j + 1) / 2, j (j + 1) / 2 + j].  INTEGRATION.md section 3b shows the Eigen one-liners
+ * (selfadjointView<Upper> / triangularView<Upper>) a GTSAM-side binding unpacks them with; cpi_amd.unpack_sym / unpack_tri /
+ * pack_sym are the Python mirrors. */
+#define CPI_TRI_DOUBLES 120
+#define CPI_TRI_INDEX(i, j) ((i) + (j) * ((j) + 1) / 2)
 
 /* device < 0: use the current HIP device.  stream: a hipStream_t (NULL = the default stream). */
 int cpi_ctx_create(int device, void *stream, cpi_ctx **out);
@@ -242,6 +261,11 @@ int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const double grav[
  * P [F][225] column-major symmetric positive definite; sqrt_info [F][225] column-major upper triangular
  * (strict lower part written as zeros).  A non-positive pivot yields NaNs in that factor's R. */
 int cpi_sqrt_information_batch(cpi_ctx *ctx, int64_t F, const double *P, double *sqrt_info);
+/* The same factorisation on packed triangles (ABI 3): P_sym [F][120] in (cpi_outputs.P_sym of the covariance kernels), R_tri
+ * [F][120] out -- 1 920 bytes per factor instead of 3 600, of which the dense form spends 840 on the mirrored half of P and
+ * 840 on zeros it writes below R's diagonal.  Entry for entry the same values as cpi_sqrt_information_batch computes from the
+ * dense form of the same P (same arithmetic, same order: bit-identical). */
+int cpi_sqrt_information_packed_batch(cpi_ctx *ctx, int64_t F, const double *P_sym, double *R_tri);
 
 /* cpi_factor_eval_batch followed by GTSAM's NoiseModelFactor::linearize whitening
  * (Gaussian::WhitenSystem): err <- R err, H1 <- R H1, H2 <- R H2 with R = sqrt_info[f]. */
@@ -249,6 +273,12 @@ int cpi_factor_eval_whitened_batch(cpi_ctx *ctx, int32_t model, const double gra
                                    const cpi_outputs *meas, const double *lin, const double *q_k_lin,
                                    const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                                    const double *sqrt_info, double *err, double *H1, double *H2);
+/* The same with R as its packed upper triangle R_tri [F][120] (cpi_sqrt_information_packed_batch): 840 bytes less to read per
+ * factor, identical outputs (the 105 entries the dense form stores below the diagonal are zeros the kernel never multiplied by). */
+int cpi_factor_eval_whitened_tri_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                       const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                       const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                                       const double *R_tri, double *err, double *H1, double *H2);
 
 /* The same evaluation carried one step further down GTSAM's pipeline: the factor's
  * contribution to the normal equations.  NoiseModelFactor::linearize turns (e, H1, H2) into the JacobianFactor
@@ -262,6 +292,11 @@ int cpi_factor_hessian_batch(cpi_ctx *ctx, int32_t model, const double grav[3], 
                              const cpi_outputs *meas, const double *lin, const double *q_k_lin,
                              const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
                              const double *sqrt_info, double *hess);
+/* ... with R as its packed upper triangle R_tri [F][120]: identical hess. */
+int cpi_factor_hessian_tri_batch(cpi_ctx *ctx, int32_t model, const double grav[3], int64_t F,
+                                 const cpi_outputs *meas, const double *lin, const double *q_k_lin,
+                                 const double *states, int64_t S, const int32_t *idx_i, const int32_t *idx_j,
+                                 const double *R_tri, double *hess);
 
 /* Replaces: GraphSolver::getpredictedstate_v1 / _v2 (GraphSolver_IMU.cpp:263-281, 289-307):
  * states_j[f] = prediction of X(k+1) from states_i[idx_i[f]] and measurement f.  states_i [S][16]; idx_i NULL: state f. */
@@ -297,7 +332,25 @@ void cpi_shard_bounds(int64_t W, int rank, int n, int64_t *lo, int64_t *hi);
  * cpi_group_last_gather_messages: messages per peer of the last gather (1 = slab path). */
 int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_outputs *local, const cpi_outputs *root_out);
 int cpi_group_last_gather_messages(const cpi_group *g);
-/* Slab layout of an output set: the fields that are non-NULL in `mask`, back to back in the order of cpi_outputs, each over
+/* The exchange INSIDE one batch (ABI 3; DESIGN.md section 7 has the wire budget that asks for it: at configs[4]'s full-V1 outputs a
+ * peer's slab is 1.5 - 2.3 GB over ONE xGMI link, about as long as the kernels that produce it -- issued after them, all of it is
+ * exposed).  Every rank's block is cut into `chunks` sub-blocks of cper = ceil(ceil(W / n) / chunks) windows
+ * (cpi_shard_chunk_bounds: sub-block c of rank r = [lo_r + c cper, min(hi_r, lo_r + (c + 1) cper)); trailing ones may be short or
+ * empty).  The host enqueues the ordinary entries for sub-block c on cpi_group_ctx(g, r) and then calls
+ * cpi_group_gather_chunk(g, root, W, c, chunks, local_c, root_out): sub-block c of every rank travels to the root on the group's
+ * EXCHANGE streams (a second non-blocking stream per device, made at the first use), behind everything that is enqueued on the
+ * ranks' compute streams at the moment of the call -- and the compute streams stay free for sub-block c + 1, whose kernels
+ * run while sub-block c is on the wire.  local_c[r] = the outputs of sub-block c of rank r, a slab of its own
+ * (cpi_outputs_bind_slab over >= the sub-block's windows: ONE message per peer and chunk) or separately allocated fields;
+ * root_out = arrays of W windows, as for cpi_group_gather.  The call with chunk == chunks - 1 JOINS: every rank's compute stream
+ * waits for its exchange stream, so whatever is enqueued later on the contexts -- and cpi_group_synchronize, which also waits
+ * for the exchange streams -- is ordered behind the whole exchange.  Buffers of sub-block c must not be rewritten before that
+ * join (or a cpi_group_synchronize).  chunks == 1: cpi_group_gather, issued on the exchange streams. */
+void cpi_shard_chunk_bounds(int64_t W, int rank, int n, int chunk, int chunks, int64_t *lo, int64_t *hi);
+int cpi_group_gather_chunk(cpi_group *g, int root, int64_t W, int chunk, int chunks, const cpi_outputs *local_chunk,
+                           const cpi_outputs *root_out);
+/* Slab layout of an output set: the fields that are non-NULL in `mask`, back to back in the order of cpi_outputs (P_sym last:
+ * a mask with P_sym instead of P makes the slab -- and the message a peer sends -- 840 bytes per window shorter), each over
  * Wb windows.  _slab_doubles: size of the slab; _bind_slab: *bound = mask's fields pointing into slab (others NULL). */
 size_t cpi_outputs_slab_doubles(const cpi_outputs *mask, int64_t Wb);
 int cpi_outputs_bind_slab(const cpi_outputs *mask, int64_t Wb, double *slab, cpi_outputs *bound);

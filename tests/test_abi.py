@@ -33,7 +33,7 @@ def test_library_builds_and_exports_exactly_the_public_header():
         assert hasattr(lib, s), "libcpi_amd.so does not export %s" % s
     exported = _exported(build.LIB)
     assert exported == public, (sorted(exported - public), sorted(public - exported))
-    assert lib.cpi_abi_version() == 2
+    assert lib.cpi_abi_version() == 3
 
 
 def test_hooks_library_adds_exactly_the_test_header():
@@ -50,7 +50,7 @@ def test_hooks_library_adds_exactly_the_test_header():
 def test_struct_layouts_match_header():
     from cpi_amd._lib import CpiOutputs, CpiParams
     assert C.sizeof(CpiParams) == 7 * 8 + 4 * 4
-    assert C.sizeof(CpiOutputs) == 12 * 8
+    assert C.sizeof(CpiOutputs) == 13 * 8   # ABI 3: P_sym
 
 
 def test_no_cpu_fallback():
@@ -90,8 +90,9 @@ def test_a_library_built_from_other_sources_is_refused():
                             "def boom(*a, **k): raise RuntimeError('hipcc failed on cpi_mean.hip')\nbuild.build = boom")
     assert r.returncode != 0 and "hipcc failed on cpi_mean.hip" in r.stderr and "LOADED" not in r.stdout
     # (ii) no compiler, and the tree's sources hash differently from what the library was built from
-    no_cc = ("build.stale = lambda *a, **k: True\n"
-             "def nocc(*a, **k): raise FileNotFoundError(2, 'No such file or directory', build.HIPCC)\nbuild.build = nocc\n")
+    # (the loader asks shutil.which / os.path.exists for the compiler; build.build must then never be reached)
+    no_cc = ("build.stale = lambda *a, **k: True\nbuild.HIPCC = '/nonexistent/bin/hipcc'\n"
+             "def nocc(*a, **k): raise AssertionError('build() reached although there is no compiler')\nbuild.build = nocc\n")
     r = _load_in_subprocess(no_cc + "build.source_id = lambda *a, **k: '0123456789abcdef'")
     assert r.returncode != 0 and "built from other sources" in r.stderr and "LOADED" not in r.stdout
     r = _load_in_subprocess(no_cc + "build.source_id = lambda *a, **k: '0123456789abcdef'", env={"CPI_AMD_ALLOW_STALE": "1"})
@@ -99,6 +100,22 @@ def test_a_library_built_from_other_sources_is_refused():
     # (iii) no compiler, sidecar lost, but the library IS this tree's build
     r = _load_in_subprocess(no_cc)
     assert r.returncode == 0 and "LOADED" in r.stdout, r.stderr
+    # (iv) ADVICE round 5: the sidecar says fresh but the id compiled INTO the library differs (a .so copied in from elsewhere):
+    # with a compiler present that is repaired by a FORCED build -- build() consults only the sidecar and would rebuild nothing
+    r = _load_in_subprocess("build.stale = lambda *a, **k: False\n_lib._embedded_build_id = lambda p: 'feedfacefeedface'\n"
+                            "real = build.build\n"
+                            "def spy(*a, **k):\n    print('BUILD force=%r' % k.get('force', a[0] if a else False)); build.build = real\nbuild.build = spy")
+    assert r.returncode == 0 and "BUILD force=True" in r.stdout and "LOADED" in r.stdout, (r.stdout, r.stderr)
+    # a missing SOURCE file is a broken tree, not "no compiler": it propagates as what it is
+    r = _load_in_subprocess("build.stale = lambda *a, **k: True\n"
+                            "def gone(*a, **k): raise FileNotFoundError(2, 'No such file or directory', 'cpi_math.hpp')\nbuild.build = gone")
+    assert r.returncode != 0 and "cpi_math.hpp" in r.stderr and "LOADED" not in r.stdout
+
+
+def test_embedded_build_id_is_readable_without_loading():
+    from cpi_amd import _lib, build
+    lib = _lib.load()
+    assert _lib._embedded_build_id(build.LIB) == lib.cpi_build_id().decode() == build.source_id()
 
 
 def test_product_never_imports_oracle():
