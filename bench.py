@@ -80,6 +80,13 @@ WORKLOADS = {
     "factor_v2_whitened": dict(kind="factor", variant="whitened", model=2, W=1000000, N=50, bytes=IN2 + 1800 + 3720, kernel="cpi_factor_kernel<2,true,16>"),
     "factor_v1_hessian": dict(kind="factor", variant="hessian", model=1, W=1000000, N=50, bytes=IN1 + 1800 + 3968, kernel="cpi_factor_hessian_kernel<1>"),
     "factor_v2_hessian": dict(kind="factor", variant="hessian", model=2, W=1000000, N=50, bytes=IN2 + 1800 + 3968, kernel="cpi_factor_hessian_kernel<2>"),
+    # ABI 3 (round 6): the same three rows on PACKED TRIANGLES -- P as its upper triangle (cpi_outputs.P_sym, 960 B), R as its
+    # non-zero triangle (960 B): the dense forms move 840 B of mirrored P and 840 B of zeros per factor (include/cpi_amd.h)
+    "sqrt_info_packed": dict(kind="sqrt_info", tri=True, model=1, W=1000000, N=50, bytes=960 + 960, kernel="cpi_sqrt_info_kernel<true>"),
+    "factor_v1_whitened_tri": dict(kind="factor", variant="whitened", tri=True, model=1, W=1000000, N=50, bytes=IN1 + 960 + 3720, kernel="cpi_factor_kernel<1,true,16,true>"),
+    "factor_v2_whitened_tri": dict(kind="factor", variant="whitened", tri=True, model=2, W=1000000, N=50, bytes=IN2 + 960 + 3720, kernel="cpi_factor_kernel<2,true,16,true>"),
+    "factor_v1_hessian_tri": dict(kind="factor", variant="hessian", tri=True, model=1, W=1000000, N=50, bytes=IN1 + 960 + 3968, kernel="cpi_factor_hessian_kernel<1,true>"),
+    "factor_v2_hessian_tri": dict(kind="factor", variant="hessian", tri=True, model=2, W=1000000, N=50, bytes=IN2 + 960 + 3968, kernel="cpi_factor_hessian_kernel<2,true>"),
     # getpredictedstate_v1 / _v2 -- reads alpha, beta, q, DT (88 B) + a state (128 B), writes a state
     "predict_v1": dict(kind="predict", model=1, W=1000000, N=50, bytes=88 + 128 + 128, kernel="cpi_predict_kernel<1>"),
     "predict_v2": dict(kind="predict", model=2, W=1000000, N=50, bytes=88 + 128 + 128, kernel="cpi_predict_kernel<2>"),
@@ -151,16 +158,18 @@ class Workload:
         if self.is_factor:
             model = self.model
             need_cov = self.kind == "sqrt_info" or self.variant in ("whitened", "hessian")
+            tri = bool(spec.get("tri"))                  # packed triangles: P_sym in, R_tri through the sweeps
+            pkey = "P_sym" if tri else "P"
             kn, lin, q = synth.make_windows(W, N, seed=seed, device=dev)
-            self.meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac", "cov") if need_cov else ("mean", "jac"))
+            self.meas = eng.preintegrate(kn, lin, q, eng.make_params(model), want=("mean", "jac", "cov_sym" if tri else "cov") if need_cov else ("mean", "jac"))
             torch.cuda.synchronize()
             del kn
             xi, xj = synth.make_states(self.meas["alpha"], self.meas["beta"], self.meas["q"], self.meas["DT"], lin, model, device=dev)
             self.states = torch.cat([xi, xj[-1:]], dim=0).contiguous()   # chained states: idx_i=f, idx_j=f+1
             self.lin, self.q = lin, (q if model == 2 else None)
-            self.R = eng.sqrt_information(self.meas["P"]) if need_cov else None
+            self.R = eng.sqrt_information(self.meas[pkey]) if need_cov else None
             if self.kind == "sqrt_info":
-                self.P = self.meas["P"]
+                self.P = self.meas[pkey]
                 self.out = self.R
             elif self.kind == "predict":
                 self.out = torch.empty((W, 16), **f64)
@@ -168,11 +177,11 @@ class Workload:
                 self.out = torch.empty((W, 72), **f64)
             elif self.variant == "hessian":
                 self.out = torch.empty((W, 496), **f64)
-                self.meas = {k: v for k, v in self.meas.items() if k != "P"}
+                self.meas = {k: v for k, v in self.meas.items() if k != pkey}
             else:
                 self.out = {"err": torch.empty((W, 15), **f64), "H1": torch.empty((W, 225), **f64), "H2": torch.empty((W, 225), **f64)}
                 if need_cov:
-                    self.meas = {k: v for k, v in self.meas.items() if k != "P"}
+                    self.meas = {k: v for k, v in self.meas.items() if k != pkey}
             torch.cuda.synchronize()
             self.nbatch = 1   # gigabytes per sweep: far beyond the Infinity Cache by itself
             return
@@ -239,8 +248,7 @@ class Workload:
         if self.is_factor:
             e = self.eng
             if self.kind == "sqrt_info":
-                e._sync_stream()
-                e._check(e.lib.cpi_sqrt_information_batch(e.ctx, self.W, self.P.data_ptr(), self.R.data_ptr()))
+                e.sqrt_information(self.P, out=self.R)
             elif self.kind == "predict":
                 e.predict(self.model, self.meas, self.states, out=self.out)
             elif self.variant == "packed":
@@ -423,7 +431,8 @@ def _cpu_factor_rows(wl, min_seconds, cores):
                           "(GraphSolver_IMU.cpp:263-307), one thread" % (done // n, n, wl.model)}
     if wl.kind == "sqrt_info":
         n = min(F, 4000)
-        P = wl.P[:n].cpu().numpy().reshape(n, 15, 15)
+        import cpi_amd
+        P = (cpi_amd.unpack_sym(wl.P[:n]) if wl.P.shape[1] == 120 else wl.P[:n]).cpu().numpy().reshape(n, 15, 15)
         t0, done = time.perf_counter(), 0
         while True:
             np.linalg.cholesky(np.linalg.inv(P))             # R^T (GTSAM: Covariance -> Information(P^-1) -> LLT)
@@ -439,7 +448,8 @@ def _cpu_factor_rows(wl, min_seconds, cores):
     extra = None
     if wl.variant in ("whitened", "hessian"):
         nR = min(F, 4000)
-        R = wl.R[:nR].cpu().numpy().reshape(nR, 15, 15).transpose(0, 2, 1)
+        import cpi_amd
+        R = (cpi_amd.unpack_tri(wl.R[:nR]) if wl.R.shape[1] == 120 else wl.R[:nR]).cpu().numpy().reshape(nR, 15, 15).transpose(0, 2, 1)
 
         def extra(e, H1, H2):
             A1, A2, b = R @ H1[:nR].reshape(nR, 15, 15).transpose(0, 2, 1), R @ H2[:nR].reshape(nR, 15, 15).transpose(0, 2, 1), -(R @ e[:nR, :, None])
