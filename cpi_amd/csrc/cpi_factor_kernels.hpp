@@ -393,24 +393,40 @@ __device__ __forceinline__ double dpp_mul(double b, double x) {   // v_mul_f64 i
     dpp_fmac<K>(r, b, x);
     return r;
 }
+// 1 / sqrt(a) for the pivots: the Newton sequence of mag_and_inverse (cpi_math.hpp) WITHOUT its clamp, so that a non-positive or
+// NaN pivot poisons the factor by itself -- v_rsq_f64 gives NaN for a < 0 and +inf for 0, and 0 x inf = NaN carries it through the
+// iteration -- where a clamp (v_max) plus a compare and two selects per step stood.  Same bits as before for a > 1e-280.
+__device__ __forceinline__ double pivot_rsqrt(double a) {
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double d = fma(-g, g, a);
+    g = fma(d, h, g);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    return 2.0 * h;
+}
+// No per-lane selects in the sweep (round 6: 763 -> see resource table; the packed form of this kernel is VALU-bound).  With
+// acc[] started at -[i == j] instead of 0, row k of column j of U is -acc[k] / b_kk for EVERY lane and row:
+//   k <  j : acc[k] = sum_m B[k][m] U[m][j], as before;
+//   k == j : acc[j] is still -1 (every contribution to it carried the factor U[m][j] = 0, m > j): -(-1) / b_jj = 1 / b_jj;
+//   k >  j : acc[k] is still 0: -0 / b_kk = -0 -- a zero (the dense store writes +0 below the diagonal explicitly), and
+//            acc[i] += B[i][k] * (-0) leaves every running sum as it is.
+// The trailing update of the working matrix needs no "finished lane" select either: a lane j >= k is never read again (the
+// broadcasts of the remaining steps come from lanes < k), so whatever its dead registers turn into is nobody's input.
 template <int K>
-__device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], double (&acc)[15], int j) {
+__device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], double (&acc)[15]) {
     if constexpr (K >= 0) {
-        // pivot: b_kk = sqrt(A[k][k]); a non-positive (or NaN) pivot poisons the factor with NaNs
-        const double akk = row_share<K>(a[K]);
-        double bkk, inv;
-        mag_and_inverse(akk, bkk, inv);
-        if (!(akk > 0.0)) inv = __builtin_nan("");
-        // row k of column j of U
-        u[K] = (K == j) ? inv : ((K < j) ? -acc[K] * inv : 0.0);
-        // lanes j < k: trailing update of column j (all rows < k) with B[j][k] = A[k][j] / b_kk (symmetry: a
-        // static register of lane j); finished lanes multiply by zero
-        const double bjk = (j < K) ? a[K] * inv : 0.0;
+        // pivot: 1 / b_kk, b_kk = sqrt(A[k][k]); a non-positive (or NaN) pivot poisons the factor with NaNs
+        const double inv = pivot_rsqrt(row_share<K>(a[K]));
+        u[K] = -acc[K] * inv;                    // row k of column j of U
+        // trailing update of column j (all rows < k) with B[j][k] = A[k][j] / b_kk (symmetry: a static register of lane j).
         // B[i][k] = A[i][k] / b_kk sits in lane k: both updates take it as the broadcast operand of a DPP multiply-add, the
         // lane's own factors folded with 1 / b_kk first (two instructions per row where a broadcast, a multiply and two
         // multiply-adds stood).  Rows descend so that the pivot of the next step (a[K-1]) is the OLDEST write of this loop,
         // and the s_nop covers K = 1 -- inline assembly is invisible to the compiler's DPP hazard check in both directions.
-        const double ca = -inv * bjk, cu = inv * u[K];
+        const double ca = -inv * (a[K] * inv), cu = inv * u[K];
 #pragma unroll
         for (int i = K - 1; i >= 0; i--) {
             dpp_fmac<K>(acc[i], a[i], cu);
@@ -418,7 +434,7 @@ __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], 
         }
         asm volatile("s_nop 1");
         __builtin_amdgcn_sched_barrier(0);   // keep the steps in order: hoisted broadcasts would cost ~200 registers
-        chol_inv_step<K - 1>(a, u, acc, j);
+        chol_inv_step<K - 1>(a, u, acc);
     }
 }
 // PACKED (cpi_sqrt_information_packed_batch): P arrives as its upper triangle and R leaves as its non-zero triangle, 120 doubles
@@ -447,15 +463,21 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
 #pragma unroll
     for (int i = 0; i < 15; i++) {
         a[i] = PACKED ? sA[fc * MD + ((i <= jc) ? jc * (jc + 1) / 2 + i : i * (i + 1) / 2 + jc)] : sA[fc * MD + jc * 15 + i];
-        acc[i] = 0.0;
+        acc[i] = (i == j) ? -1.0 : 0.0;
     }
-    chol_inv_step<14>(a, u, acc, j);
+    chol_inv_step<14>(a, u, acc);
     wave_lds_fence();   // the column reads above are complete (in-order DS) before the staging area is reused
     if (j < 15 && fl < nf) {
+        if constexpr (PACKED) {
+            // WITHOUT predicates: a lane stores all 15 rows of its column at its run's base; what lies beyond its diagonal (the -0
+            // entries) falls into a LATER column's run, whose owner stores that slot in a later instruction -- rows descend, and
+            // slot T(j) + i with i > j is T(j') + i' with j' > j, i' < i.  Nothing leaves the factor's 120 doubles (T(j) + 14 <= 119).
+            double *col = sA + fl * MD + j * (j + 1) / 2;
 #pragma unroll
-        for (int i = 0; i < 15; i++) {
-            if constexpr (PACKED) { if (i <= j) sA[fl * MD + j * (j + 1) / 2 + i] = u[i]; }
-            else sA[fl * MD + j * 15 + i] = u[i];
+            for (int i = 14; i >= 0; i--) col[i] = u[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 15; i++) sA[fl * MD + j * 15 + i] = (i <= j) ? u[i] : 0.0;
         }
     }
     wave_lds_fence();

@@ -81,7 +81,15 @@ def test_P_sym_ragged_grids_every_model(eng, model, W, N):
     torch.cuda.synchronize()
     assert torch.all(big[W:] == -7.0)
     assert torch.equal(big[:W], cpi_amd.pack_sym(dense["P"]))
-    assert torch.equal(cpi_amd.unpack_sym(big[:W]), dense["P"])
+    if model != 3:
+        # models 1 / 2: the recursion forms k = M + M^T entry by entry (the reference's P = (P + P^T) / 2, CpiV1.h:352-353), so the
+        # dense matrix IS symmetric bit for bit and unpacking reproduces all 225 entries
+        assert torch.equal(cpi_amd.unpack_sym(big[:W]), dense["P"])
+    else:
+        # the Forster comparator (GTSAM's A P A^T + B Q B^T, never symmetrised there either) is symmetric to rounding only:
+        # P_sym holds the upper triangle of the dense result, the mirrored half differs from the dense lower half by <= a few ulp
+        from tests.tol import cov_rel_err
+        assert cov_rel_err(cpi_amd.unpack_sym(big[:W]).cpu().numpy(), dense["P"].cpu().numpy()) <= 1e-13
     for k in ("DT", "alpha", "beta", "q"):
         assert torch.equal(out[k], dense[k])
 
@@ -95,7 +103,9 @@ def test_P_sym_through_the_stream_entry(eng):
         packed = eng.preintegrate_stream(stream, upd, lin, qq, prm, N=18, want=("mean", "jac", "cov_sym"))
         torch.cuda.synchronize()
         assert "P" not in packed
-        assert torch.equal(cpi_amd.unpack_sym(packed["P_sym"]), dense["P"])
+        assert torch.equal(packed["P_sym"], cpi_amd.pack_sym(dense["P"]))
+        if model != 3:
+            assert torch.equal(cpi_amd.unpack_sym(packed["P_sym"]), dense["P"])
         assert torch.equal(packed["alpha"], dense["alpha"])
 
 
