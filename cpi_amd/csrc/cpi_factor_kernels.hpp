@@ -169,8 +169,15 @@ __device__ __forceinline__ void whiten_col_dpp(const double (&Rc)[15], double (&
 // TRI (WHITEN only): R arrives as its packed upper triangle (cpi_factor_eval_whitened_tri_batch): 120 instead of 225 doubles per
 // factor to fetch and to park in LDS; entry (i, k), i <= k, at i + k (k + 1) / 2.  The arithmetic never touched the zeros the
 // dense form stores below the diagonal, so the outputs are the same bits.
+// The whitened 16-lane instantiations run THREE wavefronts per SIMD (round 6): with the pinned core (cpi_math.hpp: CPI_CORE_PIN) they
+// need 144 / 151 registers, and with R parked inside the H stage (below) 11.4 KB of LDS -- 14 wavefronts per CU by LDS, 12 by
+// registers.  Measured per 1 M factors, same box, alternating: dense R 1.26 -> 1.17 ms (model 2: 1.35 -> 1.26), packed R 1.22 -> 1.10
+// (1.30 -> 1.19).  Without the pins the same bound spills 116 / 292 bytes per lane and LOSES (1.49 / 2.69 ms).  0 = two per SIMD, as before.
+#ifndef CPI_FACTOR_W3
+#define CPI_FACTOR_W3 1
+#endif
 template <int MODEL, bool WHITEN, int LPF, bool TRI = false>
-__global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
+__global__ __launch_bounds__(64, (CPI_FACTOR_W3 && WHITEN && LPF == 16) ? 3 : CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
     static_assert(WHITEN || !TRI, "TRI is a layout of the whitening matrix");
     constexpr int FPW = 64 / LPF;                // factors per wavefront
     constexpr int CPL = (15 + LPF - 1) / LPF;    // columns per lane
@@ -179,7 +186,11 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
     constexpr int IN_D = fin::IN_D;
     __shared__ __attribute__((aligned(16))) double sH[HB + FPW * 15 + 4];   // one 15x15 set at a time: H1, then H2
     __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];         // the factors' input records
-    __shared__ __attribute__((aligned(16))) double sR[WHITEN ? FPW * RD : 2];   // whitening only: the factors' R
+    // whitening only: the factors' R.  It is dead once the lanes hold their column of it (Rc) and R err is formed -- both happen
+    // before the first column is written to the stage -- so it lives IN the stage (CPI_FACTOR_W3: 11.4 KB of LDS per wavefront)
+    constexpr bool R_IN_STAGE = CPI_FACTOR_W3 && WHITEN && LPF == 16;
+    __shared__ __attribute__((aligned(16))) double sR_own[(WHITEN && !R_IN_STAGE) ? FPW * RD : 2];
+    double *sR = R_IN_STAGE ? sH : sR_own;
     const int lane = threadIdx.x;
     const int q = lane % LPF, fl = lane / LPF;
     const long long grp = factor_group_of_block((A.F + FPW - 1) / FPW);
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(64, CPI_FACTOR_WPS) void cpi_factor_kernel(FactorAr
         if ((n & 1) && lane == 0) dst[n - 1] = src[n - 1];
     };
     const Q4 qi = ldq(m.xi);
+    if constexpr (R_IN_STAGE) wave_lds_fence();   // every read of R (Rc, R err) is issued before the first column lands on it
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         double *H = pass == 0 ? A.H1 : A.H2;
@@ -472,9 +484,11 @@ __global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const
             // WITHOUT predicates: a lane stores all 15 rows of its column at its run's base; what lies beyond its diagonal (the -0
             // entries) falls into a LATER column's run, whose owner stores that slot in a later instruction -- rows descend, and
             // slot T(j) + i with i > j is T(j') + i' with j' > j, i' < i.  Nothing leaves the factor's 120 doubles (T(j) + 14 <= 119).
+            // (one ds_write_b64 per row, kept apart: merged into a ds_write2_b64, rows 1 and 0 would put lane 0's trespass and lane 1's
+            //  own entry -- the same slot -- into ONE instruction, whose lane order is not defined)
             double *col = sA + fl * MD + j * (j + 1) / 2;
 #pragma unroll
-            for (int i = 14; i >= 0; i--) col[i] = u[i];
+            for (int i = 14; i >= 0; i--) { col[i] = u[i]; wave_lds_fence(); }
         } else {
 #pragma unroll
             for (int i = 0; i < 15; i++) sA[fl * MD + j * 15 + i] = (i <= j) ? u[i] : 0.0;

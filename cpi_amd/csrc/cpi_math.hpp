@@ -24,7 +24,14 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 // Scheduling fence: keeps hipcc from hoisting every operand load of a long straight-line block to its top
 // (which maximises registers, i.e. minimises co-resident wavefronts, in kernels that are latency-bound).
+#ifndef CPI_FENCE_MEM
+#define CPI_FENCE_MEM 0   // experiment: the fence also orders MEMORY operations (loads are formed late, where they are used)
+#endif
+#if CPI_FENCE_MEM
+#define CPI_SCHED_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
 #define CPI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #else
 #define CPI_SCHED_FENCE() ((void)0)
 #endif
@@ -1076,12 +1083,32 @@ struct FactorShared {
 };
 // Column-independent part: the five quaternions, R_k (p_j - p_i - ...), R_k (v_j - v_i ...) and the five
 // 3-vector residual blocks e[0..4] = [2 q_r,vec ; b_g,K+1 - b_g,K ; betahat - beta ; b_a,K+1 - b_a,K ; alphahat - alpha].
+// Round 6: every step's results are PINNED before the next step's loads are formed (CPI_PIN3 above tells why: the scheduling
+// fences order the record's LDS loads but the arithmetic floats below the last of them, so the whole record -- ~100 doubles -- sat in
+// registers at once).  Same arithmetic, same bits; registers of the sweeps that inline this function: dense 188 -> 90-96 (model 2:
+// 232 -> 120-128), packed 188 -> 96, whitened 194 / 238 -> 144 / 151, Hessian 190 / 238 -> 128.  What that buys is occupancy where
+// LDS allows it -- the whitened sweep runs three wavefronts per SIMD now (cpi_factor_kernels.hpp: CPI_FACTOR_W3; 1.26 -> 1.17 ms
+// per 1 M factors, with R packed 1.10) -- and nothing where LDS (packed sweep: 5 wavefronts per CU, Hessian: 9) or HBM (dense sweep)
+// is the limit: profiles/r06_packed.md.  -DCPI_CORE_PIN=0 restores the unpinned core for A/B runs.
+#ifndef CPI_CORE_PIN
+#define CPI_CORE_PIN 1
+#endif
+#if CPI_CORE_PIN && defined(__HIP_DEVICE_COMPILE__)
+#define CPI_CORE_PINV(v) CPI_PIN3((v).x, (v).y, (v).z)
+#define CPI_CORE_PINQ(q) do { asm volatile("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CPI_CORE_PINV(v) ((void)0)
+#define CPI_CORE_PINQ(q) ((void)0)
+#endif
 template <int MODEL>
 CPI_HD void factor_shared_core(const FactorMeas &f, FactorShared &S, V3 e[5]) {
-    const V3 dbg = ldv(f.xi + 4) - ldv(f.lin), dba = ldv(f.xi + 10) - ldv(f.lin + 3);
+    V3 dbg = ldv(f.xi + 4) - ldv(f.lin), dba = ldv(f.xi + 10) - ldv(f.lin + 3);
+    CPI_CORE_PINV(dbg); CPI_CORE_PINV(dba);
     V3 ja = mulcm(f.J_alpha, dbg) + mulcm(f.H_alpha, dba);      // alpha corrections
+    CPI_CORE_PINV(ja);
     CPI_SCHED_FENCE();
     V3 jb = mulcm(f.J_beta, dbg) + mulcm(f.H_beta, dba);        // beta corrections
+    CPI_CORE_PINV(jb);
     CPI_SCHED_FENCE();
     const Q4 qi = ldq(f.xi);
     S.q_kR.x = 0; S.q_kR.y = 0; S.q_kR.z = 0; S.q_kR.w = 1;
@@ -1090,6 +1117,7 @@ CPI_HD void factor_shared_core(const FactorMeas &f, FactorShared &S, V3 e[5]) {
         const V3 dthk = mk(2 * S.q_kR.x, 2 * S.q_kR.y, 2 * S.q_kR.z);
         ja = ja + mulcm(f.O_alpha, dthk);
         jb = jb + mulcm(f.O_beta, dthk);
+        CPI_CORE_PINV(ja); CPI_CORE_PINV(jb); CPI_CORE_PINQ(S.q_kR);
         CPI_SCHED_FENCE();
     }
     const double dt = f.dt[0];
@@ -1099,12 +1127,15 @@ CPI_HD void factor_shared_core(const FactorMeas &f, FactorShared &S, V3 e[5]) {
         V3 pb = ldv(f.xj + 7) - vi;
         if (MODEL == 1) { pa = pa + (0.5 * dt * dt) * f.grav; pb = pb + dt * f.grav; }
         S.Ra = qrot(qi, pa); S.Rb = qrot(qi, pb);
+        CPI_CORE_PINV(S.Ra); CPI_CORE_PINV(S.Rb);
     }
     e[4] = (S.Ra - ja) - ldv(f.alpha);   // alphahat - alpha
     e[2] = (S.Rb - jb) - ldv(f.beta);    // betahat - beta
+    CPI_CORE_PINV(e[4]); CPI_CORE_PINV(e[2]);
     CPI_SCHED_FENCE();
     const Q4 q_meas = ldq(f.q_KtoK1);
-    const Q4 q_b = rot_2_quat(Exp_so3(-(mulcm(f.J_q, dbg))));
+    Q4 q_b = rot_2_quat(Exp_so3(-(mulcm(f.J_q, dbg))));
+    CPI_CORE_PINQ(q_b);
     S.q_n = quat_multiply(ldq(f.xj), quat_inv(qi));
     S.q_rminus = quat_multiply(S.q_n, quat_inv(q_meas));
     S.q_r = quat_multiply(S.q_rminus, q_b);
