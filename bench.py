@@ -52,7 +52,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 FP64_PEAK_TFLOPS = 78.6         # vector FP64 (datasheet); the covariance kernels are VALU / LDS-bound
 MALL_BYTES = 256 << 20
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc.json")
+# xGMI: AMD quotes 153.6 GB/s per Infinity Fabric link BIDIRECTIONAL (the "7 links x ~153 GB/s" of the MI355X platform); a gather
+# moves data ONE way, each peer over its own link into the root: 76.8 GB/s per peer is the wire's ceiling, before protocol overhead
+XGMI_LINK_GBS_ONE_WAY = 76.8
 
 # name -> kind, model, default units per step, samples, algorithmic HBM bytes per unit at 50 samples (SURVEY.md 8(d):
 # read + write, f64, compulsory traffic only), dominant kernel.  kinds: "pre" preintegration (dense layout), "tiled" the
@@ -108,6 +111,14 @@ WORKLOADS = {
     "cfg5_mean": dict(kind="pre", model=1, want=("mean",), W=1000000, N=100, bytes=2856 + 88, kernel="cpi_mean_kernel<1,false,false,1>"),
     "cfg5_full": dict(kind="pre", model=1, want=("mean", "jac", "cov"), W=1000000, N=100, bytes=2856 + 2320, kernel="cpi_cov_kernel<1,false>",
                       useful_lanes=(15, 16)),
+    # the same with the covariance as its packed upper triangle (cpi_outputs.P_sym, ABI 3): 1 480 instead of 2 320 bytes out per
+    # window -- on one GPU nothing (the row is FP64-bound), at N > 1 the slab a peer sends to the root shrinks by 36 %
+    "cfg5_full_sym": dict(kind="pre", model=1, want=("mean", "jac", "cov_sym"), W=1000000, N=100, bytes=2856 + 1480, kernel="cpi_cov_kernel<1,false>",
+                          useful_lanes=(15, 16)),
+    "v1_full_sym": dict(kind="pre", model=1, want=("mean", "jac", "cov_sym"), W=100000, N=50, bytes=2856 + 1480, kernel="cpi_cov_kernel<1,false>",
+                        useful_lanes=(15, 16)),
+    "v2_full_sym": dict(kind="pre", model=2, want=("mean", "jac", "cov_sym"), W=100000, N=50, bytes=2888 + 1552, kernel="cpi_cov_kernel<2,false>",
+                        useful_lanes=(27, 32)),
 }
 # sparse-minimal FP64 flop per 50-sample window (0.35-0.5 M and 0.65-0.8 M; midpoints) -- an ESTIMATE, used
 # only when no counter-derived figure is available for the loaded library
@@ -133,9 +144,12 @@ def parse(argv=None):
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="N > 1: weak = every rank runs the per-GPU workload; strong = the workload's windows are split N ways")
     ap.add_argument("--gather", default="root", choices=("root", "all", "none"), help="N > 1: the exchange step")
-    ap.add_argument("--gather-schedule", default="auto", choices=("auto", "final", "pipelined"),
+    ap.add_argument("--gather-schedule", default="auto", choices=("auto", "final", "pipelined", "chunked"),
                     help="N > 1: final = one gather after the K steps; pipelined = every step's slab, overlapped with the next step "
-                         "(auto: pipelined when a step lasts about a millisecond or more)")
+                         "(auto: pipelined when a step lasts about a millisecond or more); chunked = the exchange INSIDE a step: the "
+                         "batch in --gather-chunks sub-blocks, sub-block c on the wire while c + 1 computes (the torch.distributed twin of "
+                         "cpi_group_gather_chunk)")
+    ap.add_argument("--gather-chunks", type=int, default=8, help="sub-blocks per step of the chunked schedule")
     ap.add_argument("--eager", action="store_true", help="issue the K timed steps as K launches instead of replaying one HIP graph")
     ap.add_argument("--no-extra", action="store_true", help="skip the additional BASELINE configs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
@@ -240,6 +254,37 @@ class Workload:
             call, _ = eng.bind_preintegrate(kn, lin, q if self.model != 3 else None, self.prm, want=self.want, out=self.outs[i % nsets])
             self.calls.append(call)
 
+    def make_chunks(self, k):
+        """The chunked schedule: every batch in k sub-blocks of cper = ceil(W / k) windows (cpi_shard_chunk_bounds' rule applied to
+        this rank's block), each with a packed output slab of its own per output set -- sub-block c is computed by its own launch and
+        its slab travels while sub-block c + 1 computes.  Dense-layout preintegration workloads only."""
+        assert self.kind == "pre", "the chunked schedule shards the dense layout"
+        self.k, self.cper = k, -(-self.W // k)
+        self.chunk_outs, self.chunk_calls = [], []
+        nsets = len(self.outs)
+        for s_ in range(nsets):
+            self.chunk_outs.append([self.eng.alloc_outputs(max(1, min(self.cper, self.W - c * self.cper)) if c * self.cper < self.W else 1,
+                                                           self.want, self.model, packed=True) for c in range(k)])
+        for i in range(len(self.calls)):
+            kn, lin, q = self.batches[i % self.nbatch]
+            row = []
+            for c in range(k):
+                lo, hi = min(self.W, c * self.cper), min(self.W, (c + 1) * self.cper)
+                if hi <= lo:
+                    row.append(None)
+                    continue
+                call, _ = self.eng.bind_preintegrate(kn[lo:hi], lin[lo:hi], q[lo:hi] if self.model != 3 else None, self.prm, want=self.want,
+                                                     out=self.chunk_outs[i % nsets][c])
+                row.append(call)
+            self.chunk_calls.append(row)
+
+    def chunk_step(self, c):
+        """Launch sub-block c of the current step; returns its output set (advance self.i after the last sub-block)."""
+        call = self.chunk_calls[self.i % len(self.chunk_calls)][c]
+        if call is not None:
+            call()
+        return self.chunk_outs[self.i % len(self.outs)][c]
+
     def out_of(self, i):
         """The outputs step number i writes."""
         return self.out if self.is_factor else self.outs[i % len(self.outs)]
@@ -318,7 +363,8 @@ def time_steps(wl, steps, warmup, dist_on=False, gather="root", schedule="final"
     torch.cuda.synchronize()
     do_gather = dist_on and gather != "none" and not wl.is_factor
     pipelined = do_gather and schedule == "pipelined" and len(wl.outs) >= 2
-    g = wl.capture(steps) if (graph and not pipelined) else None
+    chunked = do_gather and schedule == "chunked" and getattr(wl, "k", 0) >= 1 and gather == "root"
+    g = wl.capture(steps) if (graph and not pipelined and not chunked) else None
     if g is not None:
         g.replay()                                           # untimed: the first replay of a graph uploads it
         torch.cuda.synchronize()
@@ -328,22 +374,64 @@ def time_steps(wl, steps, warmup, dist_on=False, gather="root", schedule="final"
             if out is None:
                 out = wl.step()
             # untimed: first use of the collective (RCCL channel set-up), and the root's receive buffers
-            if gather == "root" and dist.get_rank() == 0:
-                shape = (dist.get_world_size(), out["_flat"].numel())
-                recv = [torch.empty(shape, dtype=torch.float64, device=out["_flat"].device) for _ in range(2 if pipelined else 1)]
-                if not pipelined:
-                    recv = recv * 2
-            final_gather(out, wl.W, gather, recv=recv[0])
-            torch.cuda.synchronize()
-            if pipelined:
+            if chunked:
+                # one receive buffer per (output set, sub-block): a sub-block's slab is overwritten only by the same sub-block two steps later
+                nsets = len(wl.outs)
+                crecv = [[None] * wl.k for _ in range(nsets)]
+                if dist.get_rank() == 0:
+                    for s_ in range(nsets):
+                        for c in range(wl.k):
+                            crecv[s_][c] = torch.empty((dist.get_world_size(), wl.chunk_outs[s_][c]["_flat"].numel()), dtype=torch.float64,
+                                                       device=out["_flat"].device)
+                co = wl.chunk_outs[0][0]
+                final_gather(co, co["_flat"].numel() // sum(n for _, n in co["_fields"]), gather, recv=crecv[0][0])
+                torch.cuda.synchronize()
                 side = torch.cuda.Stream()
+            else:
+                if gather == "root" and dist.get_rank() == 0:
+                    shape = (dist.get_world_size(), out["_flat"].numel())
+                    recv = [torch.empty(shape, dtype=torch.float64, device=out["_flat"].device) for _ in range(2 if pipelined else 1)]
+                    if not pipelined:
+                        recv = recv * 2
+                final_gather(out, wl.W, gather, recv=recv[0])
+                torch.cuda.synchronize()
+                if pipelined:
+                    side = torch.cuda.Stream()
         dist.barrier()
         torch.cuda.synchronize()
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     i0 = wl.i
     t0 = time.perf_counter()
     e0.record()
-    if pipelined:
+    if chunked:
+        # the exchange INSIDE a step: sub-block c's slab travels on the side stream while sub-block c + 1 (or the next step's first
+        # one) computes; a sub-block's slab and receive buffer are rewritten only after their previous gather has drained
+        cur = torch.cuda.current_stream()
+        nsets = len(wl.outs)
+        ev_done = [[None] * wl.k for _ in range(nsets)]
+        parts = None
+        for kstep in range(steps):
+            s_ = wl.i % nsets
+            parts = []
+            for c in range(wl.k):
+                if ev_done[s_][c] is not None:
+                    cur.wait_event(ev_done[s_][c])
+                co = wl.chunk_step(c)
+                ready = torch.cuda.Event(); ready.record(cur)
+                if kstep == steps - 1 and c == wl.k - 1:
+                    e1.record(cur)
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    wc = co["_flat"].numel() // sum(n for _, n in co["_fields"])
+                    parts.append(final_gather(co, wc, gather, recv=crecv[s_][c]))
+                    done = torch.cuda.Event(); done.record(side)
+                ev_done[s_][c] = done
+            wl.i += 1
+        cur.wait_stream(side)
+        e2.record(cur)
+        if parts and parts[0] is not None:     # the root: sub-blocks back together, [world, W, n] per field
+            gathered = {name: torch.cat([p_[name] for p_ in parts], dim=1)[:, :wl.W] for name in parts[0]}
+    elif pipelined:
         # step k's slab travels on the side stream while step k + 1 computes into the other output set; a set is rewritten
         # only after its gather has drained (ev_done), the root's receive buffers alternate likewise
         cur = torch.cuda.current_stream()
@@ -378,7 +466,7 @@ def time_steps(wl, steps, warmup, dist_on=False, gather="root", schedule="final"
         dist.barrier()                               # closing barrier: outside the timed region
         torch.cuda.synchronize()
     return {"wall": wall, "kernel_ms": e0.elapsed_time(e1), "gather_ms": e1.elapsed_time(e2) if do_gather else 0.0,
-            "mode": ("pipelined-eager" if pipelined else ("graph" if g is not None else "eager")),
+            "mode": ("chunked-eager" if chunked else ("pipelined-eager" if pipelined else ("graph" if g is not None else "eager"))),
             "gathered": gathered, "last_step": i0 + steps - 1}
 
 
@@ -625,14 +713,18 @@ def overlapped_rate(W, N, nctxs, steps):
     pool = cpi_amd.EnginePool(nmax, device=dev)
     nb = max(nmax, -(-(MALL_BYTES * 5 // 4) // (W * (N + 1) * 56)))
     batches = [synth.make_windows(W, N, seed=977 + b, device=dev) for b in range(nb)]
-    outs = [pool.engines[0].alloc_outputs(W, ("mean",), 1) for _ in range(2 * nmax)]
+    # every context (stream) writes into a ring of output sets of its OWN: launches on one stream are ordered, so a set is only ever
+    # rewritten behind its previous writer -- a schedule a correct caller can run (round 5 shared one ring across the streams:
+    # unordered launches on different streams could be handed the same set)
+    RING = 3
+    outs = [[pool.engines[0].alloc_outputs(W, ("mean",), 1) for _ in range(RING)] for _ in range(nmax)]
     prm = pool.engines[0].make_params(1)
     per = {}
     for nctx in nctxs:
         def go(k):
             for i in range(k):
                 kn, lin, q = batches[i % nb]
-                pool.engines[i % nctx].preintegrate(kn, lin, q, prm, want=("mean",), out=outs[i % len(outs)])
+                pool.engines[i % nctx].preintegrate(kn, lin, q, prm, want=("mean",), out=outs[i % nctx][(i // nctx) % RING])
         torch.cuda.synchronize()
         go(max(50, steps // 10))
         torch.cuda.synchronize()
@@ -658,7 +750,7 @@ def overlapped_rate(W, N, nctxs, steps):
                     st.wait_stream(cap)
                 for i in range(nsteps):
                     kn, lin, q = batches[i % nb]
-                    pool.engines[i % nctx].preintegrate(kn, lin, q, prm, want=("mean",), out=outs[i % len(outs)])
+                    pool.engines[i % nctx].preintegrate(kn, lin, q, prm, want=("mean",), out=outs[i % nctx][(i // nctx) % RING])
                 for st in pool.streams[:nctx]:
                     cap.wait_stream(st)
             g.replay()
@@ -709,7 +801,16 @@ EXTRA_ROWS = (("v1_mean", 30000, 1000), ("v1_mean", 100000, 300), ("v1_mean", 10
               ("predict_v1", 1000000, 40), ("predict_v2", 1000000, 40),
               ("cfg5_mean", 1000000, 10), ("cfg5_full", 1000000, 3),
               ("v1_mean_tiled", 1000000, 40), ("v2_mean_tiled", 1000000, 40), ("v1_mean_tiled", 10000, 1000),
-              ("v1_mean_stream", 1000000, 40), ("v1_full_stream", 100000, 30), ("v2_full_stream", 100000, 30))
+              ("v1_mean_stream", 1000000, 40), ("v1_full_stream", 100000, 30), ("v2_full_stream", 100000, 30),
+              # round 6, ABI 3: the SURVEY 8(f1) rows on packed triangles (P_sym in, R_tri through the sweeps) and the packed covariance output
+              ("sqrt_info_packed", 1000000, 20), ("factor_v1_whitened_tri", 1000000, 20), ("factor_v2_whitened_tri", 1000000, 20),
+              ("factor_v1_hessian_tri", 1000000, 20), ("factor_v2_hessian_tri", 1000000, 20),
+              ("v1_full_sym", 100000, 30), ("v2_full_sym", 100000, 30),
+              # round 6: the window lengths the reference itself runs -- imurate / camrate = 10 (100 Hz IMU) and 20 (200 Hz):
+              # cpi_compare/launch/synthetic_test.launch:27-28; (name, windows, steps, samples)
+              ("v1_mean", 1000000, 40, 10), ("v1_mean", 1000000, 40, 20), ("v1_mean", 10000, 1000, 10), ("v1_mean", 10000, 1000, 20),
+              ("v1_full", 1000000, 5, 10), ("v1_full", 1000000, 3, 20), ("v2_full", 1000000, 3, 10), ("v2_full", 1000000, 3, 20),
+              ("v1_mean_tiled", 1000000, 40, 10), ("v1_mean_tiled", 1000000, 40, 20), ("v1_mean_stream", 1000000, 40, 20))
 
 
 def main():
@@ -762,7 +863,11 @@ def main():
     if schedule == "auto":
         schedule = "pipelined" if (do_gather and a.gather == "root" and ("cov" in spec.get("want", ()) or step_bytes > (256 << 20))) else "final"
     base_seed = lambda r: 20190101 + 7919 * r
-    wl = Workload(eng, a.workload, W, N, seed=base_seed(rank), lanes=a.lanes, min_out_sets=2 if (do_gather and schedule == "pipelined") else 1)
+    if schedule == "chunked" and not (do_gather and a.gather == "root" and spec["kind"] == "pre"):
+        schedule = "final"                            # nothing to chunk: one rank, no exchange, or not the dense layout
+    wl = Workload(eng, a.workload, W, N, seed=base_seed(rank), lanes=a.lanes, min_out_sets=2 if (do_gather and schedule in ("pipelined", "chunked")) else 1)
+    if schedule == "chunked":
+        wl.make_chunks(max(1, a.gather_chunks))
     PRERAMP_MS = 60.0
     preramp(wl, PRERAMP_MS)
     wl.i = 0     # the pre-ramp runs for a TIME, i.e. a rank-dependent number of steps: every rank walks the batch pool from the same index
@@ -787,6 +892,9 @@ def main():
     res = {
         "metric": "evaluateError factors/sec" if is_factor else "preintegration windows/sec (%d-sample windows)" % N,
         "value": value, "unit": unit + "/s",
+        # filled below when this run measures them: `value` is the LIGHTEST configuration (mean-only); the full integrator's rate
+        # (configs[2]: CPI-v2 + covariance + Jacobians) and the overlapped rate of the same headline workload stand beside it
+        "value_full_integrator": None, "value_overlapped": None,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps,
         "higher_is_better": True, "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo exchange -- not a measurement)",
@@ -794,7 +902,9 @@ def main():
                    "pool_batches": wl.nbatch, "clock_preramp_ms": PRERAMP_MS, "library_build": build_id,
                    "launch_mode": {"graph": "%d timed steps replayed as ONE HIP graph (one kernel node per step)" % a.steps,
                                    "eager": "%d eager launches" % a.steps,
-                                   "pipelined-eager": "%d eager launches, each followed by its gather on a side stream" % a.steps}[tm["mode"]],
+                                   "pipelined-eager": "%d eager launches, each followed by its gather on a side stream" % a.steps,
+                                   "chunked-eager": "%d steps of %d sub-block launches, each sub-block's slab gathered on a side stream while the next "
+                                                    "one computes" % (a.steps, getattr(wl, "k", 1))}[tm["mode"]],
                    "parallelism": ("1 GPU" if world == 1 else
                                    "%s scaling: %d %s per step on each of %d GPUs, no data-path collective; exchange = %s (%s schedule); "
                                    "value = MAX over ranks of each rank's own wall time, closing barrier outside the timed region" % (
@@ -813,7 +923,7 @@ def main():
             try:
                 per, gper = overlapped_rate(W, N, (2, 3, 4), 3000)
                 bpb = bytes_per_unit("v1_mean", N) * W
-                best = gper if gper else per                 # the graph replay when the runtime captured it, else the eager issue
+                best = gper if gper else per                 # the graph replay when the runtime captured it, else the eager issue (`mode` says which; both are kept)
                 res["overlapped"] = {"contexts": 3, "value": W / best[3], "unit": "windows/s", "ms_per_batch": best[3] * 1e3,
                                      "frac": bpb / best[3] / 1e9 / HBM_PEAK_GBS, "batches": 3000,
                                      "mode": "graph" if gper else "eager",
@@ -823,6 +933,7 @@ def main():
                                             "captured as ONE HIP graph (fork / join over the N streams), 5 replays; eager: 3000 launches from the "
                                             "host; wall clock / batches: an aggregate rate, not a launch duration"}
                 res["goal_40pct_hbm_overlapped"] = bool(res["overlapped"]["frac"] >= 0.40)
+                res["value_overlapped"] = res["overlapped"]["value"]
             except Exception as ex:       # an additional object must never cost the line
                 res["overlapped"] = {"error": repr(ex)}
     if dist_on:
@@ -841,6 +952,8 @@ def main():
     if wall_ng is not None:
         res["config"]["value_without_gather"] = total_units * a.steps / wall_ng
         res["config"]["ms_final_gather"] = max(0.0, (wall - wall_ng) * 1e3)
+    if dist_on and do_gather:
+        res["config"]["predicted"] = predicted_exchange(wl, world, a.steps, schedule, kern_ms, total_units, getattr(wl, "k", 1))
     if world > 1:
         # a collective-latency-shaped `value` explains itself: how long the timed region is, and how much of it is the exchange
         share = (gather_ms / (wall * 1e3)) if (do_gather and wall > 0) else 0.0
@@ -860,9 +973,9 @@ def main():
         extra = []
         del wl
         torch.cuda.empty_cache()
-        for name, Wx, steps in EXTRA_ROWS:
+        for name, Wx, steps, *rest in EXTRA_ROWS:
             try:
-                Nx = WORKLOADS[name]["N"]
+                Nx = rest[0] if rest else WORKLOADS[name]["N"]
                 w2 = Workload(eng, name, Wx, Nx, seed=4242)
                 t2 = time_steps(w2, steps, max(2, steps // 10), graph=not a.eager)
                 ls = t2["kernel_ms"] * 1e-3 / steps
@@ -873,14 +986,15 @@ def main():
                     asm = dict(w2.assembly)
                     asm["share_of_step"] = asm["ms_per_batch"] / (ls * 1e3)
                     row["assembly"] = asm
-                skip_cpu = name.endswith("_packed") or name.endswith("_stream") or (name == "v1_mean" and Wx != 1000000) or (name.endswith("_tiled") and Wx != 1000000)
+                skip_cpu = (name.endswith("_packed") and name != "sqrt_info_packed") or name.endswith("_stream") or name.endswith("_tri") or name.endswith("_sym") or \
+                    (name == "v1_mean" and Wx != 1000000) or (name.endswith("_tiled") and (Wx != 1000000 or Nx != 50))
                 if not a.no_cpu and not skip_cpu:
                     row["cpu_baseline"] = cpu_baseline(w2, 2.5)     # bounded: ~2.5 s of CPU work per row
                 extra.append(row)
                 del w2
                 torch.cuda.empty_cache()
             except Exception as ex:  # an extra config must never take the headline down
-                extra.append({"workload": name, "units_per_step": Wx, "error": repr(ex)})
+                extra.append({"workload": name, "units_per_step": Wx, "samples": rest[0] if rest else WORKLOADS[name]["N"], "error": repr(ex)})
         ov = res.get("overlapped", {})
         if "value" in ov:
             extra.append({"workload": "v1_mean_3ctx", "units_per_step": 10000, "value": ov["value"], "unit": "windows/s", "contexts": 3,
@@ -891,6 +1005,35 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         emit(res, extra)
+
+
+def predicted_exchange(wl, world, steps, schedule, kern_ms, total_units, chunks=1):
+    """What the exchange SHOULD cost on xGMI, stated before anyone measures it: every peer sends its slab over
+    its OWN link straight to the root, so the wire time of a gather is one slab / one link's one-way rate, whatever N is.  From
+    that and the kernel time measured in THIS run the expected wall time of the timed region under the schedule in use:
+      final      K steps of kernels, then one slab                               K k + e
+      pipelined  step i's slab under step i + 1's kernels                        k + (K - 1) max(k, e) + e
+      chunked    c sub-blocks per step, sub-block j's slab under sub-block j + 1 K max(k, e) + min(k, e) / c
+    A prediction to judge the first real-RCCL run against (and the rehearsals' gloo exchange says nothing about it)."""
+    fields = wl.outs[0]["_fields"]
+    slab = wl.W * sum(n for _, n in fields) * 8
+    e = slab / (XGMI_LINK_GBS_ONE_WAY * 1e9) * 1e3            # ms per slab
+    k = kern_ms / steps                                        # ms of kernels per step, measured
+    if schedule == "pipelined":
+        region = k + (steps - 1) * max(k, e) + e
+    elif schedule == "chunked":
+        region = steps * max(k, e) + min(k, e) / max(1, chunks)
+    else:
+        region = steps * k + e
+    return {"slab_bytes_per_peer": slab, "slab_doubles_per_window": sum(n for _, n in fields), "peers": max(0, world - 1),
+            "link_GBs_one_way": XGMI_LINK_GBS_ONE_WAY,
+            "link_source": "AMD: 153.6 GB/s per Infinity Fabric link, bidirectional; one direction = 76.8 GB/s; one link per peer into the root",
+            "root_ingress_GBs": XGMI_LINK_GBS_ONE_WAY * max(0, world - 1),
+            "exchange_ms_per_slab": e, "kernel_ms_per_step_measured": k, "schedule": schedule, "chunks": chunks if schedule == "chunked" else None,
+            "expected_region_ms": region, "expected_value": total_units * steps / (region * 1e-3),
+            "expected_value_without_gather": total_units * steps / (steps * k * 1e-3),
+            "exchange_bound": bool(e > k) if schedule != "final" else None,
+            "note": "wire ceiling only: no protocol / launch overhead (RCCL's small-message latency is tens of microseconds)"}
 
 
 def rccl_info(rehearsal, eng):
@@ -966,10 +1109,13 @@ def emit(res, extra):
     1 M x 50 batch and one [launch_ms, roofline frac] pair per extra row.  The full rows (each with roofline, counters and CPU
     leg) go to bench_extra.json beside this file (and a copy under gpurun_out/ when that directory exists)."""
     if extra is not None:
-        rows = {"%s@%d" % (r["workload"], r["units_per_step"]): r for r in extra}
+        # key: workload@units, "xN" appended for the short-window rows (samples != the workload's own)
+        rows = {"%s@%d%s" % (r["workload"], r["units_per_step"],
+                             "" if r.get("samples") in (None, WORKLOADS.get(r["workload"], {}).get("N")) else "x%d" % r["samples"]): r for r in extra}
         c2 = rows.get("v2_full@100000")
         if c2 and "error" not in c2:
             fp, cb = c2["roofline"].get("fp64", {}), c2.get("cpu_baseline", {})
+            res["value_full_integrator"] = c2["value"]
             res["configs2"] = {"workload": "v2_full: 100000 windows x 50 samples, CPI-v2 + 15x15 covariance + bias Jacobians (BASELINE configs[2])",
                                "value": c2["value"], "unit": "windows/s", "goal_10M_windows_per_s": bool(c2["value"] >= 1e7),
                                "launch_ms": c2["launch_ms"], "kernel": c2["roofline"]["kernel"], "bound": "fp64 valu / lds",

@@ -111,9 +111,9 @@ void sqrt_info(long long F, const double *P, double *R, bool packed, hipStream_t
 }
 
 void predict(int model, const PredictArgs &a, hipStream_t st) {
-    const long long nb = (a.F + 255) / 256;
-    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_predict_kernel<1>), dim3((unsigned)nb), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((cpi_predict_kernel<2>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    const long long nb = (a.F + 63) / 64;
+    if (model == CPI_MODEL_V1) hipLaunchKernelGGL((cpi_predict_kernel<1>), dim3((unsigned)nb), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((cpi_predict_kernel<2>), dim3((unsigned)nb), dim3(64), 0, st, a);
 }
 
 #ifdef CPI_TEST_HOOKS

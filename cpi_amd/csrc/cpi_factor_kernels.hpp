@@ -734,17 +734,70 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
     }
 }
 
+// getpredictedstate_v1 / _v2 (GraphSolver_IMU.cpp:263-307): 344 bytes per factor in and out, ~130 FP64 instructions -- a copy with a
+// little arithmetic in it.  One wavefront per 64 factors, one lane per factor for the arithmetic, but NOT for the memory traffic:
+// until round 5 every lane fetched its own 128-byte state, its 24 / 24 / 32-byte measurement fields and stored its 128-byte result
+// with 8- and 16-byte accesses strided by the record size (0.072 / 0.089 ms per 1 M factors = 0.60 / 0.48 of 8 TB/s, where a plain
+// copy of the same mix reaches 0.88: tools/exp/mix_probe.hip, profiles/r06_small_sweeps.md).  Now the wavefront moves its 64 records
+// as ONE burst of fully coalesced pieces -- the states (gathered through idx_i or chained) as 16-byte pieces, eight lanes per
+// state; the SoA measurement fields as consecutive doubles -- all requested before the first is used, parked in LDS record-major
+// (pitch 27 doubles: odd, so the per-lane record reads hit 32 distinct banks), and the 64 results leave through the same area as 512
+// consecutive 16-byte non-temporal stores.
+constexpr int PRED_IN_D = 27, PRED_OUT_D = 17;   // LDS pitches (doubles): state 16 + alpha 3 + beta 3 + q 4 + DT 1; result 16 (+1: odd)
 template <int MODEL>
-__global__ __launch_bounds__(256) void cpi_predict_kernel(PredictArgs A) {
-    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= A.F) return;
-    const long long ii = min(max(A.idx_i ? (long long)A.idx_i[f] : f, 0ll), A.S - 1);
-    const NavState xi = ld_state(A.states_i + ii * 16);
-    const NavState o = predict_state<MODEL>(xi, ldv3(A.meas.alpha + f * 3), ldv3(A.meas.beta + f * 3),
-                                            ldq4(A.meas.q + f * 4), A.meas.DT[f], mk(A.grav[0], A.grav[1], A.grav[2]));
-    double *d = A.states_j + f * 16;
-    d[0] = o.q.x; d[1] = o.q.y; d[2] = o.q.z; d[3] = o.q.w;
-    stv3(d + 4, o.bg); stv3(d + 7, o.v); stv3(d + 10, o.ba); stv3(d + 13, o.p);
+__global__ __launch_bounds__(64) void cpi_predict_kernel(PredictArgs A) {
+    constexpr int FPW = 64;
+    __shared__ __attribute__((aligned(16))) double sRec[FPW * PRED_IN_D];
+    static_assert(FPW * PRED_OUT_D <= FPW * PRED_IN_D, "the results re-use the record area");
+    const int lane = threadIdx.x;
+    const long long f0 = (long long)blockIdx.x * FPW;
+    const int nf = (int)min((long long)FPW, A.F - f0);
+    struct __attribute__((packed, aligned(8))) d2u { double a, b; };
+    // ---- one burst: 8 x 16-byte state pieces per lane (piece p = lane + 64 r: part p & 7 of the state of factor p >> 3), then the fields
+    d2u st[8];
+    {
+        long long si[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const long long ff = f0 + min((lane >> 3) + 8 * r, nf - 1);
+            // branch-free NULL handling (a valid dummy address is read and discarded) keeps all loads in one block
+            const int vi = (A.idx_i ? A.idx_i : reinterpret_cast<const int *>(A.states_i))[ff];
+            si[r] = min(max(A.idx_i ? (long long)vi : ff, 0ll), A.S - 1);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) st[r] = *reinterpret_cast<const d2u *>(A.states_i + si[r] * 16 + 2 * (lane & 7));
+    }
+    FieldFetch<FPW, 3> f_alpha, f_beta; FieldFetch<FPW, 4> f_q; FieldFetch<FPW, 1> f_dt;
+    f_alpha.load(A.meas.alpha, f0, nf, lane); f_beta.load(A.meas.beta, f0, nf, lane); f_q.load(A.meas.q, f0, nf, lane);
+    f_dt.load(A.meas.DT, f0, nf, lane);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        double *d = sRec + ((lane >> 3) + 8 * r) * PRED_IN_D + 2 * (lane & 7);
+        d[0] = st[r].a; d[1] = st[r].b;
+    }
+    f_alpha.store(sRec, PRED_IN_D, 16, lane); f_beta.store(sRec, PRED_IN_D, 19, lane); f_q.store(sRec, PRED_IN_D, 22, lane);
+    f_dt.store(sRec, PRED_IN_D, 26, lane);
+    wave_lds_fence();
+    // ---- lane = factor (lanes past the last factor redo it: same values, and they do not store)
+    NavState o;
+    {
+        const double *rec = sRec + min(lane, nf - 1) * PRED_IN_D;
+        const NavState xi = ld_state(rec);
+        o = predict_state<MODEL>(xi, ldv3(rec + 16), ldv3(rec + 19), ldq4(rec + 22), rec[26], mk(A.grav[0], A.grav[1], A.grav[2]));
+    }
+    wave_lds_fence();   // every record is read (in-order DS) before the area becomes the output stage
+    {
+        double *d = sRec + lane * PRED_OUT_D;
+        d[0] = o.q.x; d[1] = o.q.y; d[2] = o.q.z; d[3] = o.q.w;
+        stv3(d + 4, o.bg); stv3(d + 7, o.v); stv3(d + 10, o.ba); stv3(d + 13, o.p);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int fl = (lane >> 3) + 8 * r;
+        const double *src = sRec + fl * PRED_OUT_D + 2 * (lane & 7);
+        if (fl < nf) st16_nt(A.states_j + (f0 + fl) * 16 + 2 * (lane & 7), src[0], src[1]);
+    }
 }
 
 

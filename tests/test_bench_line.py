@@ -6,9 +6,10 @@ import json
 import bench
 
 
-def _row(name, W, with_cpu=True):
-    r = {"workload": name, "units_per_step": W, "samples": 50, "value": 1.234567891234e8, "unit": "windows/s", "launch_ms": 1.23456789,
-         "launch_mode": "graph", "roofline": bench.roofline_of(name, W, 50, 1.2e-3, {}, "no profiles/r04_pmc.json")}
+def _row(name, W, with_cpu=True, N=None):
+    N = N or bench.WORKLOADS[name]["N"]
+    r = {"workload": name, "units_per_step": W, "samples": N, "value": 1.234567891234e8, "unit": "windows/s", "launch_ms": 1.23456789,
+         "launch_mode": "graph", "roofline": bench.roofline_of(name, W, N, 1.2e-3, {}, "no profiles/r04_pmc.json")}
     if with_cpu:
         r["cpu_baseline"] = {"value": 4.0e4, "unit": "windows/s", "cores": 16, "kind": "reference", "single_core_value": 2.6e3, "sample": "x" * 300}
     return r
@@ -25,7 +26,7 @@ def test_emit_keeps_the_last_line_under_6k_and_writes_the_rows(tmp_path, monkeyp
                           "frac_by_contexts": {"2": 0.4012, "3": 0.4371, "4": 0.4402}, "how": "h" * 170}, "goal_40pct_hbm_overlapped": True,
            "cpu_baseline": dict(_row("v1_mean", 10000)["cpu_baseline"], sample="s" * 200,
                                 sparse_port={"value": 3.2e6, "unit": "windows/s", "cores": 16, "kind": "port", "single_core_value": 2.1e5, "what": "w" * 60, "sample": "p" * 90})}
-    extra = [_row(name, W) for name, W, _ in bench.EXTRA_ROWS]
+    extra = [_row(name, W, N=(rest[0] if rest else None)) for name, W, _, *rest in bench.EXTRA_ROWS]
     extra[4]["roofline"]["fp64"] = {"TFLOPs": 31.6, "peak": 78.6, "frac": 0.40, "source": "counters", "useful_frac": 0.34}
     extra.append({"workload": "v1_mean_3ctx", "units_per_step": 10000, "value": 1.2e9, "unit": "windows/s", "contexts": 3, "us_per_batch": 8.4,
                   "hbm_GBs": 3500.0, "hbm_frac": 0.437, "note": "n" * 120})
@@ -38,6 +39,9 @@ def test_emit_keeps_the_last_line_under_6k_and_writes_the_rows(tmp_path, monkeyp
     assert r["value"] == 7.1e8 and r["roofline"]["frac"] > 0 and r["cpu_baseline"]["cores"] == 16
     assert r["configs2"]["value"] > 0 and r["configs2"]["fp64"]["useful_frac"] == 0.34 and r["configs2"]["cpu_baseline"]["kind"] == "reference"
     assert len(r["extra_rows"]) == len(extra) and r["extra_rows"]["broken@5"] == "error"
+    # the short-window rows (the reference's own window lengths) are keyed apart from the 50-sample rows of the same workload
+    assert "v1_mean@1000000" in r["extra_rows"] and "v1_mean@1000000x10" in r["extra_rows"] and "v1_mean@1000000x20" in r["extra_rows"]
+    assert r["value_full_integrator"] == r["configs2"]["value"]
     assert r["routes_1M_x_50"]["dense_kernel_preassembled"] > 0
     assert r["overlapped"]["frac"] == 0.437 and r["goal_40pct_hbm_overlapped"] is True
     doc = json.load(open(tmp_path / "bench_extra.json"))

@@ -68,6 +68,8 @@ def test_the_last_stdout_line_of_the_drivers_command_parses_and_is_small(driver_
     assert "configs[2]" in c2["workload"] and c2["value"] > 1e7 and c2["goal_10M_windows_per_s"] is True and c2["launch_ms"] > 0
     assert c2["cpu_baseline"]["value"] > 0 and c2["cpu_baseline"]["cores"] >= 1 and c2["cpu_baseline"]["kind"] in ("reference", "port")
     assert set(c2["fp64"]) >= {"frac", "useful_frac"}
+    # `value` is the lightest configuration: the full integrator's rate and the overlapped rate stand beside it at the top level
+    assert r["value_full_integrator"] == c2["value"] and r["value_overlapped"] == ov["value"]
     rt = r["routes_1M_x_50"]
     assert rt["stream_in_place"] > 0 and rt["assemble_tiles"] > 0 and rt["tiled_kernel"] > 0 and rt["dense_kernel_preassembled"] > 0
     assert "bench_extra.json" in r["extra_file"]
@@ -78,16 +80,26 @@ def test_the_full_extra_rows_land_in_bench_extra_json(driver_run):
     r = json.loads([ln for ln in stdout.splitlines() if ln.strip()][-1])
     doc = json.load(open(extra_path))
     rows = doc["rows"]
-    assert len(rows) >= 26
+    assert len(rows) >= 44
     assert not [x for x in rows if "error" in x], [x for x in rows if "error" in x]
     with_roof = [x for x in rows if "roofline" in x]
-    assert len(with_roof) >= 25
+    assert len(with_roof) >= 43
     for x in with_roof:
         rf = x["roofline"]
         assert rf["achieved"] > 0 and rf["kernel"] and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert doc["headline"]["value"] == r["value"] and doc["headline"]["config"]["library_build"] == r["config"]["library_build"]
     # the compact per-row summary of the line agrees with the file
-    assert set(r["extra_rows"]) == {"%s@%d" % (x["workload"], x["units_per_step"]) for x in rows}
+    import bench
+    key = lambda x: "%s@%d%s" % (x["workload"], x["units_per_step"], "" if x.get("samples") in (None, bench.WORKLOADS.get(x["workload"], {}).get("N")) else "x%d" % x["samples"])
+    assert set(r["extra_rows"]) == {key(x) for x in rows}
+    by = {key(x): x for x in rows}
+    # round 6: the reference's own window lengths (10 / 20 samples) with roofline AND the reference's CPU leg at that length
+    for k in ("v1_mean@1000000x10", "v1_mean@1000000x20", "v1_full@1000000x10", "v2_full@1000000x20"):
+        assert by[k]["roofline"]["frac"] > 0 and by[k]["cpu_baseline"]["value"] > 0 and "%d-sample" % by[k]["samples"] in by[k]["cpu_baseline"]["sample"], k
+    assert by["v1_mean@1000000x20"]["roofline"]["frac"] >= 0.50
+    # ... and the packed-triangle rows of ABI 3 beside their dense twins
+    assert by["sqrt_info_packed@1000000"]["launch_ms"] < 0.70 * by["sqrt_info@1000000"]["launch_ms"]
+    assert by["factor_v1_whitened_tri@1000000"]["launch_ms"] < by["factor_v1_whitened@1000000"]["launch_ms"]
 
 
 def test_no_extra_no_cpu_still_prints_one_contract_line():
