@@ -172,7 +172,10 @@ static int pick_lanes(const cpi_params *prm, int64_t W, int N, bool jac) {
     // model 2 with analytic Jacobians: sequential per window (the O_a / O_b recursion is not composed); model 2
     // mean-only composes through the gravity response matrices at roughly twice the arithmetic per interval
     if (prm->model == CPI_MODEL_V2 && jac) return 1;
-    const double t_int = (prm->model == CPI_MODEL_V2) ? 1.2 : 0.55, t_lvl = (prm->model == CPI_MODEL_V2) ? 0.6 : 0.3;
+    // (model 2's level cost re-fitted in round 6 on windows of 10 and 20 intervals -- 10 k windows: 4 lanes 8.8 / 10.9 us, the 5 the old
+    //  0.6 picked 9.3 / 11.5; the choices at N = 50 do not move.  Model 1's automatic choice is within 0-3 % of the best lane count for
+    //  N = 10 / 20 at 5 k ... 50 k windows: profiles/r06_short_windows.md)
+    const double t_int = (prm->model == CPI_MODEL_V2) ? 1.2 : 0.55, t_lvl = (prm->model == CPI_MODEL_V2) ? 1.3 : 0.3;
     int L = prm->lanes_per_window;
     if (L <= 0) {
         // Small batches are latency-bound: as long as every wavefront gets a SIMD of its own (<= 1024 wavefronts
@@ -486,7 +489,11 @@ extern "C" int cpi_factor_eval_packed_batch(cpi_ctx *ctx, int32_t model, const d
     // but more LDS per wavefront (a factor's staged record + packed output = 1.5 KB).  Measured (MI355X, 1 M factors, model 1 /
     // model 2, us): 8 lanes 383 / 435 (VALU 53 % busy at 2 wavefronts per SIMD), 6: 335 / 389, 4: 290 / 324, 3: 281 / 314,
     // 2: 328 / 361 (48 KB of LDS: one wavefront per SIMD); 100 k factors: 4 lanes 31.5, 3 lanes 32.5.
-    int lpf = (F >= 300000) ? 3 : 4;
+    // Round 6 (the result overlays the record: 928 B of LDS per factor, 8 wavefronts per CU at 3 lanes): 2 / 3 / 4 / 6 lanes
+    // 252-254 / 249-255 / 256-258 / 315-317 (model 2: 276-282 / 269-272 / 282-283 / 334-337); 100 k factors 31.7 / 27.3 / 26.9-27.4 /
+    // 31.0; 20 k 8.7 / 7.9-8.0 / 8.5 / 8.4: three at every size.
+    int lpf = 3;
+    (void)F;
 #ifdef CPI_EXPERIMENTS
     if (expsw::packed_lpf()) lpf = expsw::packed_lpf();
 #endif

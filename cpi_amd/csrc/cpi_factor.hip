@@ -106,8 +106,10 @@ void factor_hessian(int model, const FactorArgs &a, double *hess, hipStream_t st
 }
 
 void sqrt_info(long long F, const double *P, double *R, bool packed, hipStream_t st) {
-    if (packed) hipLaunchKernelGGL(cpi_sqrt_info_kernel<true>, dim3(factor_grid((F + 3) / 4)), dim3(64), 0, st, F, P, R);
-    else hipLaunchKernelGGL(cpi_sqrt_info_kernel<false>, dim3(factor_grid((F + 3) / 4)), dim3(64), 0, st, F, P, R);
+    const long long groups = (F + 3) / 4;
+    const unsigned nb = CPI_SQRT_WPB > 1 ? (unsigned)((groups + CPI_SQRT_WPB - 1) / CPI_SQRT_WPB) : factor_grid(groups);
+    if (packed) hipLaunchKernelGGL(cpi_sqrt_info_kernel<true>, dim3(nb), dim3(64 * CPI_SQRT_WPB), 0, st, F, P, R);
+    else hipLaunchKernelGGL(cpi_sqrt_info_kernel<false>, dim3(nb), dim3(64 * CPI_SQRT_WPB), 0, st, F, P, R);
 }
 
 void predict(int model, const PredictArgs &a, hipStream_t st) {

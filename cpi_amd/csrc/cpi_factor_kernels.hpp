@@ -63,10 +63,13 @@ __device__ __forceinline__ long long factor_group_of_block(long long groups) {
 }
 inline unsigned factor_grid(long long groups) { return CPI_FACTOR_XCD ? (unsigned)(((groups + 7) >> 3) << 3) : (unsigned)groups; }
 
-// Record layout of one factor in the LDS staging area (doubles)
+// Record layout of one factor in the LDS staging area (doubles).  Round 6: the fields only the column-independent core reads
+// (factor_shared_core) come FIRST -- 73 doubles that are dead once the core is done -- and the fields the column phase still
+// needs (J_q, O_beta, O_alpha, state_i) last: the packed sweep writes its 72-double result over the dead part of the factor's
+// own record instead of into a stage of its own (LDS per factor 1 504 -> 928 bytes: 8 instead of 5 wavefronts per CU).
 namespace fin {
-constexpr int O_ALPHA = 0, O_BETA = 3, O_Q = 6, O_LIN = 10, O_JQ = 16, O_JB = 25, O_JA = 34, O_HB = 43, O_HA = 52,
-              O_DT = 61, O_QK = 62, O_OB = 66, O_OA = 75, O_XI = 84, O_XJ = 100, IN_D = 116;
+constexpr int O_ALPHA = 0, O_BETA = 3, O_Q = 6, O_LIN = 10, O_JB = 16, O_JA = 25, O_HB = 34, O_HA = 43, O_DT = 52, O_QK = 53,
+              O_XJ = 57, DEAD_AFTER_CORE = 73, O_JQ = 73, O_OB = 82, O_OA = 91, O_XI = 100, IN_D = 116;
 }
 // RD: doubles of R per factor when WHITEN -- 225 (dense column-major) or CPI_TRI_DOUBLES (the packed upper triangle)
 template <int MODEL, int FPW, bool WHITEN, int RD = 225>
@@ -315,10 +318,27 @@ __global__ __launch_bounds__(64, (CPI_FACTOR_W3 && WHITEN && LPF == 16) ? 3 : CP
 // LPF lanes per factor: lane q owns the columns q, q + LPF, ... < 6 of H1 (column c < 3: blocks (0,0), (6,0), (12,0), plus
 // column c of H2(0,0) and of R(q_GtoK); 3 <= c < 6: block (0,3)) and the residual rows q, q + LPF, ... < 15.
 constexpr int FACTOR_PACKED_DOUBLES = 72;
+static_assert(FACTOR_PACKED_DOUBLES <= fin::DEAD_AFTER_CORE, "the packed result overlays the part of the record that only the core reads");
+// What the column phase of the packed sweep needs of H1's column c: rows 0-2 (blocks (0,0) / (0,3)) and, for c < 3, rows 6-8 and 12-14
+// (blocks (6,0), (12,0)) -- the terms of factor_H1_column without the rows the packed form derives from the measurement, so that
+// nothing of the record's dead part (J_beta, H_beta, J_alpha, H_alpha, dt) is read after the result has begun to overwrite it.
+template <int MODEL>
+__device__ __forceinline__ void packed_H1_column(const FactorShared &S, const FactorMeas &f, V3 &top, V3 &vt, V3 &pt) {
+    const V3 u = S.u;
+    const V3 qnv = mk(S.q_n.x, S.q_n.y, S.q_n.z), qmv = mk(S.q_m.x, S.q_m.y, S.q_m.z);
+    const V3 tt = -(qLmul(S.q_n, -1.0, qLmul(S.q_m, -1.0, u)) + dot(qmv, u) * qnv);         // (0,0)
+    const V3 tg = qLmul(S.q_rminus, -1.0, colcm(f.J_q, S.cc));                               // (0,3)
+    top = (S.bc == 0) ? tt : tg;
+    vt = cross(S.Rb, u); pt = cross(S.Ra, u);                                                // (6,0) (12,0)
+    if (MODEL == 2) {
+        const V3 Lu = qLmul(S.q_kR, +1.0, u);
+        vt = vt - mulcm(f.O_beta, Lu);
+        pt = pt - mulcm(f.O_alpha, Lu);
+    }
+}
 template <int MODEL, int LPF>
 __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, double *packed) {
     constexpr int FPW = 64 / LPF, PD = FACTOR_PACKED_DOUBLES, IN_D = fin::IN_D;
-    __shared__ __attribute__((aligned(16))) double sP[FPW * PD];
     __shared__ __attribute__((aligned(16))) double sIn[FPW * IN_D];
     __shared__ double sDummy[2];
     const int lane = threadIdx.x;
@@ -331,11 +351,13 @@ __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, dou
     __syncthreads();
     const double *in = sIn + fl * IN_D;
     const FactorMeas m = factor_meas_of(in, A.grav);
-    double *out = sP + fl * PD;
+    double *out = sIn + fl * IN_D;                             // the result overlays the record's dead part (fin::DEAD_AFTER_CORE)
     FactorShared S;
     {
         V3 e5[5];
         factor_shared_core<MODEL>(m, S, e5);
+        wave_lds_fence();                                      // the core's reads of every factor of the wavefront are issued: from here on the
+                                                               // first 73 doubles of a record are result space
 #pragma unroll
         for (int k = 0; k < (15 + LPF - 1) / LPF; k++) {
             const int c = q + LPF * k;
@@ -350,30 +372,34 @@ __global__ __launch_bounds__(64) void cpi_factor_packed_kernel(FactorArgs A, dou
     for (int k = 0; k < (6 + LPF - 1) / LPF; k++) {
         const int c = q + LPF * k;               // column c of H1: 0..2 -> blocks (0,0), (6,0), (12,0) (+ H2(0,0), R(q_GtoK)); 3..5 -> block (0,3)
         if (c < 6) {
-            double h[15];
             S.bc = c / 3; S.cc = c - 3 * S.bc;
             S.u = unit(S.cc);
             S.rku = qrot(qi, S.u);
-            factor_H1_column<MODEL>(S, m, h);
+            V3 top, vt, pt;
+            packed_H1_column<MODEL>(S, m, top, vt, pt);
             if (c < 3) {
                 double *b = out + 15 + 3 * c;                    // H1(0,0), H1(6,0), H1(12,0): column c of each
-                b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
-                b[9] = h[6]; b[10] = h[7]; b[11] = h[8];
-                b[18] = h[12]; b[19] = h[13]; b[20] = h[14];
-                double h2[15];
-                factor_H2_column(S, h2);
+                b[0] = top.x; b[1] = top.y; b[2] = top.z;
+                b[9] = vt.x; b[10] = vt.y; b[11] = vt.z;
+                b[18] = pt.x; b[19] = pt.y; b[20] = pt.z;
+                const V3 h2 = qLmul(S.q_r, +1.0, S.u);           // H2(0,0) column c (factor_H2_column)
                 double *r = out + 51 + 3 * c;                    // R(q_GtoK) column c, then H2(0,0) column c
                 r[0] = S.rku.x; r[1] = S.rku.y; r[2] = S.rku.z;
-                r[9] = h2[0]; r[10] = h2[1]; r[11] = h2[2];
+                r[9] = h2.x; r[10] = h2.y; r[11] = h2.z;
             } else {
                 double *b = out + 42 + 3 * (c - 3);              // H1(0,3) column c - 3
-                b[0] = h[0]; b[1] = h[1]; b[2] = h[2];
+                b[0] = top.x; b[1] = top.y; b[2] = top.z;
             }
         }
     }
     if (q == LPF - 1) { out[69] = 0.0; out[70] = 0.0; out[71] = 0.0; }
     wave_lds_fence();
-    for (int i = lane; i < nf * (PD / 2); i += 64) st16_nt(packed + f0 * PD + 2 * i, sP[2 * i], sP[2 * i + 1]);
+    // 36 pieces of 16 bytes per factor, consecutive lanes = consecutive pieces of the OUTPUT; piece i sits in record i / 36
+    for (int i = lane; i < nf * (PD / 2); i += 64) {
+        const int g = i / (PD / 2), r = i - g * (PD / 2);
+        const double *src = sIn + g * IN_D + 2 * r;
+        st16_nt(packed + f0 * PD + 2 * i, src[0], src[1]);
+    }
 }
 
 // R = chol_upper(P^-1) = B^-1 with P = B B^T, B upper triangular ("reverse" Cholesky, from the last pivot up).
@@ -453,13 +479,19 @@ __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], 
 // each (CPI_TRI_INDEX).  Lane j rebuilds its full symmetric column from the triangle -- rows i <= j from column j, rows i > j
 // from row j of column i -- and stores rows 0 .. j of its column of U: the same registers enter the same arithmetic as in the
 // dense form.
+// WPB wavefronts per workgroup, each on four factors of its own (no barrier between them: the kernel never leaves its wavefront).
+#ifndef CPI_SQRT_WPB
+#define CPI_SQRT_WPB 1
+#endif
 template <bool PACKED>
-__global__ __launch_bounds__(64, 3) void cpi_sqrt_info_kernel(long long F, const double *P, double *Rout) {
-    constexpr int FPW = 4, MD = PACKED ? CPI_TRI_DOUBLES : 225;
-    __shared__ __attribute__((aligned(16))) double sA[FPW * MD];
-    const int lane = threadIdx.x, j = lane & 15, fl = lane >> 4;
-    const long long grp = factor_group_of_block((F + FPW - 1) / FPW);
-    if (grp < 0) return;
+__global__ __launch_bounds__(64 * CPI_SQRT_WPB, 3) void cpi_sqrt_info_kernel(long long F, const double *P, double *Rout) {
+    constexpr int FPW = 4, MD = PACKED ? CPI_TRI_DOUBLES : 225, WPB = CPI_SQRT_WPB;
+    __shared__ __attribute__((aligned(16))) double sAll[WPB * FPW * MD];
+    double *sA = sAll + (WPB > 1 ? (threadIdx.x >> 6) * (FPW * MD) : 0);
+    const int lane = threadIdx.x & 63, j = lane & 15, fl = lane >> 4;
+    const long long groups = (F + FPW - 1) / FPW;
+    const long long grp = (WPB > 1) ? (long long)blockIdx.x * WPB + (threadIdx.x >> 6) : factor_group_of_block(groups);
+    if (grp < 0 || grp >= groups) return;
     const long long f0 = grp * FPW;
     const int nf = (int)min((long long)FPW, F - f0);
     struct __attribute__((packed, aligned(8))) d2u { double a, b; };

@@ -52,6 +52,14 @@ bool mean_lanes_supported(int L) {
 #ifndef CPI_MEAN_BIG_LDS_PAD
 #define CPI_MEAN_BIG_LDS_PAD 0
 #endif
+// Round 6, the reference's own window lengths (imurate / camrate = 10 and 20, synthetic_test.launch:27-28): at N = 10 three knots per
+// chunk is 3 1/3 chunks with a padded step, and the two-knot kernel (5 chunks exactly) is 4-5 % faster on the dense layout (1 M x 10:
+// 158-159 vs 164-167 us; model 2 164 vs 170) and on stream windows (197 vs 206-208); at N = 20 the two are equal within the run-to-run
+// noise (268-285 vs 280; stream 315-317 vs 308-311).  Five knots per chunk (256 registers + 32 B of scratch) wins only the N = 10
+// stream (191 us) and is not instantiated.  Hence: BIG from 16 intervals per window (profiles/r06_short_windows.md).
+#ifndef CPI_MEAN_BIG_NMIN
+#define CPI_MEAN_BIG_NMIN 16
+#endif
 template <int MODEL, bool JAC, bool AVG>
 static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
     // 0: plain knots; 1: windows cut by cpi_cut_windows_kernel (workspace route); 2: the wavefront cuts its own windows
@@ -60,7 +68,7 @@ static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
     if constexpr (!JAC) {
         const long long wmin = MODEL == 2 ? (long long)CPI_MEAN_BIG_W_M2 : (cut != 0 ? (long long)CPI_MEAN_BIG_W : (long long)CPI_MEAN_BIG_W_DENSE);
         const bool admitted = cut != 0 ? (a.K > 0 && a.K < (1ll << 26)) : (a.first == nullptr && a.count == nullptr);
-        if (L == 1 && admitted && a.W >= wmin) {
+        if (L == 1 && admitted && a.W >= wmin && a.N >= CPI_MEAN_BIG_NMIN) {
             const unsigned nb = (unsigned)((a.W + 63) / 64);
             const size_t pad = CPI_MEAN_BIG_LDS_PAD;   // unused dynamic LDS: caps the wavefronts per CU (see above)
             if (cut == 2) hipLaunchKernelGGL((cpi_mean_kernel<MODEL, false, AVG, 1, 2, true>), dim3(nb), dim3(64), pad, st, a);

@@ -67,6 +67,9 @@ __device__ __forceinline__ long long knots_not_after_near(const double *stream, 
 #ifndef CPI_MEAN_C
 #define CPI_MEAN_C 2      // knots per chunk of the staged kernels with several intervals per lane (3 measured: see below)
 #endif
+#ifndef CPI_MEAN_BIG_C
+#define CPI_MEAN_BIG_C 3  // knots per chunk of the BIG instantiations (round 6, short windows: 2 and 5 measured at N = 10 / 20, profiles/r06_short_windows.md)
+#endif
 
 // CUT: the windows are cut out of one stream in flight (cpi_preintegrate_stream) -- a template parameter, so that the
 // plain-knot instantiations carry none of it (the 10 k-window headline launch is issue-bound: a few extra live registers
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(64, BIG ? 2 : (((MODEL == 2 && !JAC) || (MODEL == 1
     // L = 3: 19.7 -> 18.4 us, 30 k with L = 2: 27.4 -> 24.8 us, 15 k with L = 4: 16.0 -> 15.3 us, 10 k with L = 6:
     // 12.5 -> 11.8 us once the padded second step of an odd last chunk is skipped), 1 when a wave is latency-bound
     // with few intervals per lane (L >= 12: 5 k windows 9.55 vs 9.65 us, 2.5 k 7.7 vs 8.0 us); 3 for BIG (above)
-    constexpr int C = BIG ? 3 : ((L <= 8 && !JAC) ? CPI_MEAN_C : 1);
+    constexpr int C = BIG ? CPI_MEAN_BIG_C : ((L <= 8 && !JAC) ? CPI_MEAN_C : 1);
     constexpr int SEGD = 7 * C;       // doubles per lane per chunk
     constexpr int PITCH = (SEGD & 1) ? SEGD : SEGD + 1;   // odd pitch (15, 21 doubles): a half-wave's ds_read_b64 hit 32 distinct even banks
     __shared__ double tile[64 * PITCH];
