@@ -430,7 +430,8 @@ def time_steps(wl, steps, warmup, dist_on=False, gather="root", schedule="final"
         cur.wait_stream(side)
         e2.record(cur)
         if parts and parts[0] is not None:     # the root: sub-blocks back together, [world, W, n] per field
-            gathered = {name: torch.cat([p_[name] for p_ in parts], dim=1)[:, :wl.W] for name in parts[0]}
+            from cpi_amd.dist import assemble_chunks
+            gathered = assemble_chunks(parts, wl.W)
     elif pipelined:
         # step k's slab travels on the side stream while step k + 1 computes into the other output set; a set is rewritten
         # only after its gather has drained (ev_done), the root's receive buffers alternate likewise
@@ -1050,7 +1051,26 @@ def rccl_info(rehearsal, eng):
     except Exception:
         ver = None
     return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": every,
-            "distinct_devices": len({(e[1], e[2]) for e in every}), "nccl_version": ver if not rehearsal else None}
+            "distinct_devices": len({(e[1], e[2]) for e in every}), "nccl_version": ver if not rehearsal else None,
+            "link_types": link_types() if dist.get_rank() == 0 else None}
+
+
+def link_types():
+    """What connects the GPUs of this node (`rocm-smi --showtopotype`: XGMI / PCIE per pair), so that the first scaling record says
+    whether the gather really went over xGMI.  {"GPU0": {"GPU1": "XGMI", ...}, ...}, or a short error string; never raises."""
+    import subprocess
+    try:
+        p = subprocess.run(["rocm-smi", "--showtopotype", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+        d = json.loads(p.stdout[p.stdout.index("{"):])
+        out = {}
+        for k, v in (d.get("system", d) or {}).items():            # "Link Type between DRM devices 0 and 1": "XGMI" (one key per pair)
+            words = k.replace(":", " ").split()
+            ids = [w for w in words if w.isdigit()]
+            if len(ids) >= 2 and isinstance(v, str):
+                out.setdefault("GPU" + ids[0], {})["GPU" + ids[1]] = v
+        return out or {"raw": p.stdout.strip()[:300]}
+    except Exception as ex:
+        return "unavailable: %r" % (ex,)
 
 
 def verify_gather(eng, wl, tm, world, rank, base_seed, rehearsal):
@@ -1069,9 +1089,23 @@ def verify_gather(eng, wl, tm, world, rank, base_seed, rehearsal):
             b = tm["last_step"] % wl.nbatch
             ok, maxdiff = g is not None, 0.0
             parts = []
+            k = getattr(wl, "k", 1) if tm.get("mode") == "chunked-eager" else 1
+
+            def recompute(kn, lin, q):
+                """with the launch geometry the owning rank used: the chunked schedule launches W / k windows at a time (the mean
+                kernel's automatic lane split depends on the launch size)"""
+                if k <= 1:
+                    return eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
+                from cpi_amd.dist import chunk_bounds
+                pieces = []
+                for c in range(k):
+                    lo, hi, _ = chunk_bounds(wl.W, c, k)
+                    if hi > lo:
+                        pieces.append(eng.preintegrate(kn[lo:hi], lin[lo:hi], q[lo:hi] if wl.model != 3 else None, wl.prm, want=wl.want))
+                return {name: torch.cat([p_[name] for p_ in pieces], dim=0) for name in pieces[0]}
             for r in range(world if g is not None else 0):
                 kn, lin, q = synth.make_windows(wl.W, wl.N, seed=base_seed(r) + 101 * b, device=eng.device)
-                out = eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
+                out = recompute(kn, lin, q)
                 torch.cuda.synchronize()
                 for name, n in wl.outs[0]["_fields"]:
                     ok = ok and torch.equal(g[name][r].reshape(out[name].shape), out[name])

@@ -7,7 +7,9 @@ issues one ncclSend per peer and the matching ncclRecvs on the root inside one g
 travels its own xGMI link; "gloo" in the CPU tests).  gather_packed / gather_outputs(dst=None) are the
 all-gather forms for callers that need the results on every rank (n times the received bytes and memory).
 Nothing like this exists in the reference (single-threaded CPU program); SURVEY.md section 8(e).  The
-single-process C-ABI equivalent is cpi_group_gather (include/cpi_amd.h).
+single-process C-ABI equivalent is cpi_group_gather (include/cpi_amd.h); chunk_bounds / assemble_chunks serve the exchange
+INSIDE one batch (cpi_group_gather_chunk there).  Asking for the covariance as its packed upper triangle ("cov_sym": the field
+P_sym, 120 instead of 225 doubles per window) shortens a full-V1 slab from 2 320 to 1 480 bytes per window.
 """
 import torch
 import torch.distributed as dist
@@ -105,6 +107,21 @@ def gather_to_root(flat, fields, W_local, dst=0, group=None, out=None):
         return {name: full[:, off:off + n * W_local].view(world, W_local, n) for name, (off, n) in lay.items()}
     dist.gather(src, None, dst=dst, group=group)
     return None
+
+
+def chunk_bounds(W_local, chunk, chunks):
+    """Sub-block `chunk` of `chunks` of a rank's block of W_local windows, relative to the block: (lo, hi, cper) with the equal
+    sub-block size cper = ceil(W_local / chunks) -- the rule of cpi_shard_chunk_bounds (include/cpi_amd.h) for equal padded blocks.
+    The exchange INSIDE one batch (bench.py --gather-schedule chunked; cpi_group_gather_chunk for single-process hosts): sub-block c's
+    packed slab is gathered while sub-block c + 1 computes."""
+    cper = -(-W_local // max(1, chunks))
+    lo = min(W_local, chunk * cper)
+    return lo, min(W_local, lo + cper), cper
+
+
+def assemble_chunks(parts, W_local):
+    """parts[c] = what gather_to_root returned for sub-block c (name -> [world, w_c, n]) -> name -> [world, W_local, n]."""
+    return {name: torch.cat([p[name] for p in parts], dim=1)[:, :W_local] for name in parts[0]}
 
 
 def unshard(gathered, W_total):

@@ -3,6 +3,7 @@
 // (tests/test_gpu_cpp_facade.py) to compare with the golden vectors.  GPU only.
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "../../cpi_amd/csrc/cpi_host.hpp"
@@ -119,6 +120,23 @@ int main(int argc, char **argv) {
                 for (double v : c.q_k2tau) printf(" %.17g", v);
                 printf("\n");
             }
+            // after a mean-only flush the Jacobian / covariance members are NOT valid for the recorded intervals -- a
+            // read of one runs the whole window (the means read above did not); poisoned here so that a stale read would show.
+            // And two threads reading DIFFERENT preintegrators lazily use their own (thread-local) default contexts.
+            CpiBase &c0 = *wins[0], &c1 = *wins[W > 2 ? 2 : 0];
+            CpiResult poisoned = c0.result();                      // full results (finalize)
+            {
+                CpiBatch again;
+                again.add(&c0); again.add(&c1);
+                again.flush_means(ctx);                            // means only: the full members are stale from here on
+            }
+            double tr[2] = {0, 0}, jq0[2] = {0, 0};
+            std::thread t0([&] { for (int i = 0; i < 15; i++) tr[0] += c0.P_meas[i * 16]; jq0[0] = c0.J_q[0]; });
+            std::thread t1([&] { for (int i = 0; i < 15; i++) tr[1] += c1.P_meas[i * 16]; jq0[1] = c1.J_q[0]; });
+            t0.join(); t1.join();
+            double want = 0;
+            for (int i = 0; i < 15; i++) want += poisoned.P_meas[i * 16];
+            printf("AFTERMEANS %s %.17g %.17g %.17g %.17g\n", (tr[0] == want && jq0[0] == poisoned.J_q[0] && tr[1] > 0) ? "ok" : "STALE", tr[0], want, tr[1], jq0[1]);
         }
     } catch (const std::exception &e) {
         fprintf(stderr, "cpi_host error: %s\n", e.what());

@@ -2,6 +2,9 @@
 // the shape INTEGRATION.md shows for a C++ caller that shards a batch of windows over the GPUs of a node and gathers
 // the outputs on GPU 0.  usage: test_group <input.bin> <model> [ngpus]   -- input: {W, N} then knots[W][N+1][7], lin[W][6],
 // q_k_lin[W][4] (doubles).  Prints one line per window: DT alpha(3) beta(3) q(4) P(225), gathered on the root.
+// A 5th argument k > 0 runs the exchange INSIDE the batch (DeviceGroup::gather_chunk, ABI 3): every rank's block in k sub-blocks, each
+// computed into a slab of its own that carries the covariance as its packed upper triangle (cpi_outputs.P_sym); the host unpacks it
+// (CPI_TRI_INDEX) before printing, so the text equals the dense run's.
 // Compiled with g++ (no hipcc): only the HIP runtime API for memory is needed.
 #include <hip/hip_runtime_api.h>
 
@@ -46,6 +49,63 @@ int main(int argc, char **argv) {
     cpi_params prm{};
     prm.sigma_w = 0.005; prm.sigma_wb = 4e-6; prm.sigma_a = 0.01; prm.sigma_ab = 2e-4;
     prm.grav[2] = 9.8; prm.model = model; prm.state_transition_jacobians = 1;
+
+    const int chunks = argc > 5 ? std::atoi(argv[5]) : 0;
+    if (chunks > 0) {
+        HIP_OK(hipSetDevice(0));
+        cpi_outputs root{};
+        HIP_OK(hipMalloc((void **)&root.DT, (size_t)W * 8)); HIP_OK(hipMalloc((void **)&root.alpha, (size_t)W * 24));
+        HIP_OK(hipMalloc((void **)&root.beta, (size_t)W * 24)); HIP_OK(hipMalloc((void **)&root.q, (size_t)W * 32));
+        HIP_OK(hipMalloc((void **)&root.P_sym, (size_t)W * CPI_TRI_DOUBLES * 8));
+        double dummy = 0;
+        cpi_outputs mask{};
+        mask.DT = mask.alpha = mask.beta = mask.q = mask.P_sym = &dummy;
+        int messages = 0;
+        for (int c = 0; c < chunks; c++) {
+            std::vector<cpi_outputs> loc(n);
+            int64_t cper = 0;
+            { int64_t a, b; grp.chunk_bounds(W, 0, 0, chunks, a, b); cper = b - a; }      // the common sub-block size (rank 0, chunk 0 is never short unless W is tiny)
+            for (int r = 0; r < n; r++) {
+                int64_t lo, hi;
+                grp.chunk_bounds(W, r, c, chunks, lo, hi);
+                const int64_t w = hi - lo;
+                if (w <= 0) continue;
+                HIP_OK(hipSetDevice(shared ? 0 : r));
+                double *dk, *dl, *dq, *slab;
+                HIP_OK(hipMalloc((void **)&dk, (size_t)w * (N + 1) * 56)); HIP_OK(hipMalloc((void **)&dl, (size_t)w * 48)); HIP_OK(hipMalloc((void **)&dq, (size_t)w * 32));
+                HIP_OK(hipMemcpy(dk, kn.data() + (size_t)lo * (N + 1) * 7, (size_t)w * (N + 1) * 56, hipMemcpyHostToDevice));
+                HIP_OK(hipMemcpy(dl, lin.data() + (size_t)lo * 6, (size_t)w * 48, hipMemcpyHostToDevice));
+                HIP_OK(hipMemcpy(dq, qk.data() + (size_t)lo * 4, (size_t)w * 32, hipMemcpyHostToDevice));
+                const int64_t wb = cper > w ? cper : w;
+                HIP_OK(hipMalloc((void **)&slab, cpi_outputs_slab_doubles(&mask, wb) * 8));
+                if (cpi_outputs_bind_slab(&mask, wb, slab, &loc[r]) != CPI_OK) return 5;
+                if (cpi_preintegrate_batch(grp.ctx(r), &prm, w, N, dk, nullptr, nullptr, dl, dq, &loc[r]) != CPI_OK) {
+                    std::fprintf(stderr, "rank %d: %s\n", r, cpi_last_error(grp.ctx(r)));
+                    return 3;
+                }
+            }
+            grp.gather_chunk(0, W, c, chunks, loc.data(), root);      // sub-block c on the exchange streams; the kernels of c + 1 follow at once
+            messages += grp.last_gather_messages();
+        }
+        grp.synchronize();
+        HIP_OK(hipSetDevice(0));
+        std::vector<double> DT(W), al(W * 3), be(W * 3), q(W * 4), Ps((size_t)W * CPI_TRI_DOUBLES);
+        HIP_OK(hipMemcpy(DT.data(), root.DT, W * 8, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(al.data(), root.alpha, W * 24, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(be.data(), root.beta, W * 24, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(q.data(), root.q, W * 32, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(Ps.data(), root.P_sym, (size_t)W * CPI_TRI_DOUBLES * 8, hipMemcpyDeviceToHost));
+        for (int64_t w = 0; w < W; w++) {
+            std::printf("%.17g", DT[w]);
+            for (int i = 0; i < 3; i++) std::printf(" %.17g", al[w * 3 + i]);
+            for (int i = 0; i < 3; i++) std::printf(" %.17g", be[w * 3 + i]);
+            for (int i = 0; i < 4; i++) std::printf(" %.17g", q[w * 4 + i]);
+            for (int j = 0; j < 15; j++)                                  // dense column-major from the packed upper triangle
+                for (int i = 0; i < 15; i++) std::printf(" %.17g", Ps[(size_t)w * CPI_TRI_DOUBLES + (i <= j ? CPI_TRI_INDEX(i, j) : CPI_TRI_INDEX(j, i))]);
+            std::printf("\n");
+        }
+        std::fprintf(stderr, "group of %d %s, %lld windows gathered on rank 0 in %d sub-blocks, %d message(s) per peer in all\n", n,
+                     shared ? "rank(s) on one device" : "device(s)", (long long)W, chunks, messages);
+        return 0;
+    }
 
     static const int FN[5] = { 1, 3, 3, 4, 225 };                 // DT alpha beta q P
     std::vector<cpi_outputs> local(n);

@@ -29,6 +29,6 @@ def test_the_gpu_facade_program_compiles_here():
     link on the CPU box every round."""
     exe = os.path.join(tempfile.mkdtemp(), "test_facade")
     libdir = os.path.join(ROOT, "cpi_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "cpp", "test_facade.cpp"), "-o", exe,
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_facade.cpp"), "-o", exe,
                            "-L" + libdir, "-lcpi_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     assert os.path.exists(exe)

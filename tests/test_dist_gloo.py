@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -132,6 +133,100 @@ def test_bench_partition_and_gather_to_root_bitwise_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _worker_chunked(rank, world, port, W, N, k, q):
+    """The exchange INSIDE one batch (bench.py --gather-schedule chunked; cpi_group_gather_chunk in the C-ABI): every rank's block in k
+    sub-blocks (cpi_amd.dist.chunk_bounds), each with a packed slab of its own that carries the covariance as its packed upper
+    triangle (P_sym), gathered to rank 0 one sub-block at a time and put back together (assemble_chunks / unshard).  The oracle stands
+    in for the kernels; rank 0 checks the result BITWISE against the unsharded run."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from cpi_amd import synth
+        from cpi_amd.dist import alloc_packed, assemble_chunks, chunk_bounds, unshard
+        from oracle import oracle_py as op
+        kn, lin, qk = synth.make_windows(W, N, seed=707)
+        kn, lin, qk = kn.numpy(), lin.numpy(), qk.numpy()
+        cols = np.repeat(np.arange(15), np.arange(1, 16))
+        rows = np.arange(120) - cols * (cols + 1) // 2
+        pack = lambda P: np.ascontiguousarray(np.asarray(P).reshape(-1, 225)[:, cols * 15 + rows])   # CPI_TRI_INDEX
+        fields = [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4), ("J_q", 9), ("H_a", 9), ("P_sym", 120)]
+        lo, hi, per = shard_bounds(W, rank, world)
+        prm = op.make_params(1, 0, 1)
+        parts, ok, nmsg = [], True, 0
+        for c in range(k):
+            clo, chi, cper = chunk_bounds(per, c, k)
+            a, b = min(hi, lo + clo), min(hi, lo + chi)          # a short last block: trailing sub-blocks may be short or empty
+            flat, views = alloc_packed(fields, max(1, chi - clo))
+            flat.zero_()
+            if b > a:
+                loc = op.oracle().run(prm, kn[a:b], lin[a:b], qk[a:b])
+                loc["P_sym"] = pack(loc["P"])
+                for name, _ in fields:
+                    views[name][: b - a] = torch.from_numpy(np.ascontiguousarray(loc[name]).reshape(views[name][: b - a].shape))
+            out = dict(views); out["_flat"], out["_fields"] = flat, fields
+            g = bench.final_gather(out, max(1, chi - clo), "root", dst=0)
+            nmsg += 1
+            ok = ok and ((g is None) == (rank != 0))
+            parts.append(g)
+        if rank == 0:
+            full = unshard(assemble_chunks(parts, per), W)
+            ref = op.oracle().run(prm, kn, lin, qk)
+            ref["P_sym"] = pack(ref["P"])
+            for name, n in fields:
+                ok = ok and np.array_equal(full[name].numpy().reshape(W, -1), np.asarray(ref[name]).reshape(W, -1))
+        ok = ok and nmsg == k
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,k", [(77, 1), (77, 3), (80, 8), (5, 4)])
+def test_chunked_gather_inside_one_batch_world2_gloo(W, k):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_chunked, args=(r, 2, port, W, 12, k, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_predicted_exchange_is_the_wire_budget_of_design_section_7():
+    """bench.py's `predicted` object at N > 1: slab bytes per peer over ONE xGMI link at its one-way rate, and the expected wall time of
+    the timed region under each schedule -- the numbers DESIGN.md section 7 states for configs[4] (1 M windows x full V1 per GPU)."""
+    import bench
+
+    class WL:
+        W = 1000000
+    for name, bytes_per_window in (("dense", 2248), ("sym", 1408), ("mean", 88)):
+        wl = WL()
+        fields = {"dense": [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4)] + [(n, 9) for n in ("J_q", "J_a", "J_b", "H_a", "H_b")] + [("P", 225)],
+                  "sym": [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4)] + [(n, 9) for n in ("J_q", "J_a", "J_b", "H_a", "H_b")] + [("P_sym", 120)],
+                  "mean": [("DT", 1), ("alpha", 3), ("beta", 3), ("q", 4)]}[name]
+        wl.outs = [{"_fields": fields}]
+        steps, k_ms = 3, 25.9
+        for sched in ("final", "pipelined", "chunked"):
+            p = bench.predicted_exchange(wl, 8, steps, sched, k_ms * steps, 8 * wl.W, chunks=8)
+            assert p["slab_bytes_per_peer"] == wl.W * bytes_per_window and p["peers"] == 7 and p["link_GBs_one_way"] == 76.8
+            e = wl.W * bytes_per_window / 76.8e9 * 1e3
+            assert abs(p["exchange_ms_per_slab"] - e) < 1e-9 and abs(p["kernel_ms_per_step_measured"] - k_ms) < 1e-9
+            want = {"final": steps * k_ms + e, "pipelined": k_ms + (steps - 1) * max(k_ms, e) + e,
+                    "chunked": steps * max(k_ms, e) + min(k_ms, e) / 8}[sched]
+            assert abs(p["expected_region_ms"] - want) < 1e-9
+            assert abs(p["expected_value"] - 8 * wl.W * steps / (want * 1e-3)) < 1e-3
+        # the statement of DESIGN 7 (model 1 writes 281 doubles per window, 176 with the packed covariance): dense P makes the 8-GPU
+        # point root-ingress bound (29.3 ms of wire > 25.9 ms of kernels), packed P does not (18.3 ms)
+        if name == "dense":
+            assert 29.0 < e < 29.6 and p["exchange_bound"] is True
+        if name == "sym":
+            assert 18.0 < e < 18.6 and p["exchange_bound"] is False
 
 
 def test_bench_gpus_flag_spawns_the_ranks_itself(monkeypatch):

@@ -20,7 +20,7 @@ def exe():
     _lib.load()
     out = os.path.join(tempfile.mkdtemp(), "test_facade")
     libdir = os.path.join(ROOT, "cpi_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_facade.cpp"), "-o", out,
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_facade.cpp"), "-o", out,
                            "-L" + libdir, "-lcpi_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     return out
 
@@ -59,6 +59,10 @@ def test_cpp_facade_vs_golden(exe, golden_dir, model):
     assert mrows.shape == (W, 11) and all(ln.startswith("MEAN") for ln in lines[W + 1:W + 1 + W])
     means = {"DT": mrows[:, 0], "alpha": mrows[:, 1:4], "beta": mrows[:, 4:7], "q": mrows[:, 7:11]}
     check_pre(means, ref, what=("mean",), v2=(model == 2), regression=True, label="c++ flush_means m%d" % model)
+    # a Jacobian / covariance member read after a mean-only flush recomputes the window (never the stale value), and
+    # two threads reading different preintegrators lazily run on their own thread-local default contexts
+    after = [ln for ln in lines if ln.startswith("AFTERMEANS")]
+    assert len(after) == 1 and after[0].split()[1] == "ok", after
 
 
 def test_cpp_forster_facade_vs_restatement(exe, golden_dir):

@@ -187,6 +187,14 @@ def test_cpp_host_sharding_a_batch_over_the_device_set(golden_dir):
         assert p5.returncode == 0, p5.stderr
         assert "group of 5 rank(s) on one device" in p5.stderr and "1 message(s) per peer" in p5.stderr, p5.stderr
         assert p5.stdout == p.stdout
+        # round 6: the exchange INSIDE the batch through cpi_host::DeviceGroup::gather_chunk -- 3 sub-blocks per rank, the slabs carry
+        # the packed covariance (P_sym), the host unpacks it: identical text again; one device, and 5 ranks over the stand-in
+        pc = subprocess.run([exe, path, str(model), "1", "native", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert pc.returncode == 0 and pc.stdout == p.stdout and "in 3 sub-blocks" in pc.stderr, pc.stderr
+        pc5 = subprocess.run([exe_hooks, path, str(model), "5", "shared", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                             env=dict(os.environ, CPI_AMD_RCCL_LIB=fake_rccl_py.lib_path()))
+        assert pc5.returncode == 0 and pc5.stdout == p.stdout, pc5.stderr
+        assert "group of 5 rank(s) on one device" in pc5.stderr and "in 3 sub-blocks, 3 message(s) per peer in all" in pc5.stderr, pc5.stderr
 
 
 @pytest.mark.parametrize("n", [4, 8])
@@ -210,6 +218,13 @@ def test_bench_gpus_4_and_8_the_drivers_first_multi_gpu_commands_rehearsed_on_on
     runs = [(["--gpus", str(n), "--steps", "20", "--warmup", "5"], 20, 10000, "final")]
     if n == 8:
         runs.append((["--gpus", str(n), "--steps", "3", "--warmup", "1", "--workload", "cfg5_mean", "--windows", "200000"], 3, 200000, "pipelined"))
+    if n == 4:
+        # round 6: the exchange INSIDE one batch (the torch.distributed twin of cpi_group_gather_chunk) on the full-V1 share of
+        # configs[4], with the covariance as its packed upper triangle in the slab, 1 and 8 sub-blocks per step
+        for k in (1, 8):
+            runs.append((["--gpus", str(n), "--steps", "2", "--warmup", "1", "--workload", "cfg5_full_sym", "--windows", "60000",
+                          "--gather-schedule", "chunked", "--gather-chunks", str(k)], 2, 60000, "chunked"))
+    exposed = {}
     for args, steps, W, sched in runs:
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                            timeout=1200, env=env, cwd=ROOT)
@@ -226,6 +241,20 @@ def test_bench_gpus_4_and_8_the_drivers_first_multi_gpu_commands_rehearsed_on_on
         assert c["value_kernel_only"] >= d["value"] and c["value_without_gather"] > 0
         assert "timed region" in c["scaling_note"] and "exchange" in c["scaling_note"] and len(c["scaling_note"]) < 900
         assert "roofline" in d and "cpu_baseline" not in d and "overlapped" not in d       # rank 0 at N = 1 only
+        # round 6: the line states what the exchange SHOULD cost on xGMI before anyone measures it
+        pr = c["predicted"]
+        fields_doubles = {"final": 11, "pipelined": 11, "chunked": 176}[sched]           # mean-only slab / full V1 with packed P
+        assert pr["slab_doubles_per_window"] == fields_doubles and pr["slab_bytes_per_peer"] == W * fields_doubles * 8 and pr["peers"] == n - 1
+        assert pr["link_GBs_one_way"] == 76.8 and abs(pr["exchange_ms_per_slab"] - pr["slab_bytes_per_peer"] / 76.8e9 * 1e3) < 1e-9
+        assert pr["schedule"] == sched and pr["expected_value"] > 0 and pr["expected_value"] <= pr["expected_value_without_gather"] * (1 + 1e-9)
+        assert abs(pr["kernel_ms_per_step_measured"] * steps - c["kernel_ms"]) < 1e-6 * c["kernel_ms"]
+        if sched == "chunked":
+            assert "sub-block" in c["launch_mode"] and pr["chunks"] == int(args[-1])
+            exposed[int(args[-1])] = c["gather_ms"]
+    if n == 4:
+        # both sub-block counts ran, were verified bitwise, and reported their exposed exchange tail (gloo through host memory: the
+        # numbers say nothing about xGMI -- the schedule and its verification are what this exercises)
+        assert set(exposed) == {1, 8} and all(v > 0 for v in exposed.values())
 
 
 def test_cpp_host_threads_one_context_each(golden_dir):

@@ -26,6 +26,7 @@ def _env():
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["CPI_BENCH_STRICT"] = "1"          # a gathered block that differs from rank 0's recomputation is a failure, not a field
+    env["NCCL_DEBUG"] = "VERSION"          # the collective library says which build it is (one line at communicator creation)
     return env
 
 
@@ -41,7 +42,11 @@ def test_device_set_on_real_rccl_reproduces_the_unsharded_call_bitwise(n):
 
 @pytest.mark.parametrize("n", NS)
 @pytest.mark.parametrize("extra", [[], ["--workload", "v2_full", "--windows", "20000", "--scaling", "strong"], ["--workload", "v1_full", "--windows", "30000"],
-                                   ["--workload", "cfg5_mean", "--windows", "200000"]])
+                                   ["--workload", "cfg5_mean", "--windows", "200000"],
+                                   # round 6: the slab with the packed covariance (ABI 3), and the exchange inside one batch
+                                   ["--workload", "v1_full_sym", "--windows", "30000"],
+                                   ["--workload", "cfg5_full_sym", "--windows", "100000", "--gather-schedule", "chunked", "--gather-chunks", "8"],
+                                   ["--workload", "cfg5_full", "--windows", "100000", "--gather-schedule", "chunked", "--gather-chunks", "1"]])
 def test_bench_gpus_n_on_real_rccl_validates_what_it_gathers(n, extra):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "20", "--warmup", "5"] + extra,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=_env(), cwd=ROOT)
@@ -58,3 +63,10 @@ def test_bench_gpus_n_on_real_rccl_validates_what_it_gathers(n, extra):
     assert c["value_kernel_only"] >= d["value"] and c["value_without_gather"] > 0
     assert c["kernel_ms"] > 0 and c["gather_ms"] > 0 and c["wall_ms"] >= c["kernel_ms"] * 0.99
     assert d["scaling"] == ("strong" if "strong" in extra else "weak") and "timed region" in c["scaling_note"]
+    # round 6: the library's banner and the node's link types travel with the record; the prediction stands beside the measurement
+    assert "version" in (p.stdout + p.stderr).lower()
+    assert isinstance(rc["link_types"], (dict, str)) and rc["link_types"]
+    pr = c["predicted"]
+    assert pr["peers"] == n - 1 and pr["exchange_ms_per_slab"] > 0 and pr["expected_value"] > 0
+    if "chunked" in extra:
+        assert c["gather_schedule"] == "chunked" and "sub-block" in c["launch_mode"]

@@ -37,7 +37,9 @@ def main():
         for W, root, model, want, packed in [
                 (n * 4096, 0, 1, ("mean",), True), (n * 1000 + 3, n - 1, 2, ("mean", "jac", "cov"), True),
                 (n * 500 - 1, 0, 1, ("mean", "cov"), False), (n * 2000 + 1, n - 1, 1, ("mean", "jac", "cov"), True),
-                (n + 1, 0, 2, ("mean", "jac"), False)]:
+                (n + 1, 0, 2, ("mean", "jac"), False),
+                # ABI 3: the slab carries the covariance as its packed upper triangle (120 doubles per window instead of 225)
+                (n * 1500 + 7, 0, 1, ("mean", "jac", "cov_sym"), True), (n * 700 + 1, n - 1, 2, ("mean", "jac", "cov_sym"), True)]:
             rdev = torch.device("cuda", root)
             eng = cpi_amd.Engine(device=root)
             kn, lin, q = synth.make_windows(W, N, seed=300 + n + W)           # host copies: every rank uploads its block
@@ -86,6 +88,40 @@ def main():
                 assert torch.equal(root_out[k], ref[k]), ("second gather", n, W, root, k)
             ncase += 1
             del keep
+            # ---- the exchange INSIDE one batch (cpi_group_gather_chunk): k sub-blocks per rank, each with a slab of its own, sub-block
+            # c on the wire (the group's exchange streams) while c + 1 computes; the last call joins
+            if packed:
+                for k in (1, 3, 8):
+                    for v in root_out.values():
+                        v.fill_(float("nan"))
+                    keepc = []
+                    cper = (per + k - 1) // k
+                    for c in range(k):
+                        locs = (CpiOutputs * n)()
+                        for r in range(n):
+                            lo, hi = C.c_int64(), C.c_int64()
+                            lib.cpi_shard_chunk_bounds(W, r, n, c, k, C.byref(lo), C.byref(hi))
+                            lo, hi = lo.value, hi.value
+                            if hi <= lo:
+                                continue
+                            dev = torch.device("cuda", r)
+                            dk, dl, dq = kn[lo:hi].to(dev), lin[lo:hi].to(dev), q[lo:hi].to(dev)
+                            slab = torch.empty((lib.cpi_outputs_slab_doubles(C.byref(ro), cper),), dtype=torch.float64, device=dev)
+                            o = CpiOutputs()
+                            assert lib.cpi_outputs_bind_slab(C.byref(ro), cper, slab.data_ptr(), C.byref(o)) == 0
+                            keepc.append((slab, dk, dl, dq))
+                            locs[r] = o
+                            torch.cuda.synchronize(dev)
+                            ctx = lib.cpi_group_ctx(g, r)
+                            assert lib.cpi_preintegrate_batch(ctx, C.byref(prm), hi - lo, N, dk.data_ptr(), None, None, dl.data_ptr(), dq.data_ptr(),
+                                                              C.byref(o)) == 0, lib.cpi_last_error(ctx)
+                        assert lib.cpi_group_gather_chunk(g, root, W, c, k, locs, C.byref(ro)) == 0, lib.cpi_group_last_error(g)
+                        assert lib.cpi_group_last_gather_messages(g) in (0, 1)
+                    assert lib.cpi_group_synchronize(g) == 0
+                    for kk in ref:
+                        assert torch.equal(root_out[kk], ref[kk]), ("chunked", n, W, root, model, k, kk)
+                    ncase += 1
+                    del keepc
     finally:
         lib.cpi_group_destroy(g)
     print("group_real_check ok: %d cases on %d devices over real RCCL" % (ncase, n))
