@@ -25,15 +25,15 @@ for row in $ROWS; do
     v1_full_stream) K="cpi_cov_kernel<1;cpi_mean_kernel<1, true;cpi_cut_windows_kernel";;
     v2_full_stream) K="cpi_cov_kernel<2;cpi_cut_windows_kernel";;
     v2_mean_tiled) K="cpi_mean_tiled_kernel<2";;
-    sqrt_info) K="cpi_sqrt_info_kernel";;
-    factor_v1_whitened) K="cpi_factor_kernel<1, true";;
-    factor_v2_whitened) K="cpi_factor_kernel<2, true";;
-    factor_v1_hessian) K="cpi_factor_hessian_kernel<1";;
-    factor_v2_hessian) K="cpi_factor_hessian_kernel<2";;
+    sqrt_info|sqrt_info_packed) K="cpi_sqrt_info_kernel";;
+    factor_v1_whitened|factor_v1_whitened_tri) K="cpi_factor_kernel<1, true";;
+    factor_v2_whitened|factor_v2_whitened_tri) K="cpi_factor_kernel<2, true";;
+    factor_v1_hessian|factor_v1_hessian_tri) K="cpi_factor_hessian_kernel<1";;
+    factor_v2_hessian|factor_v2_hessian_tri) K="cpi_factor_hessian_kernel<2";;
     predict_v1) K="cpi_predict_kernel<1";;
     predict_v2) K="cpi_predict_kernel<2";;
-    v1_full|cfg5_full) K="cpi_cov_kernel<1;cpi_mean_kernel<1, true";;
-    v2_full) K="cpi_cov_kernel<2";;
+    v1_full|cfg5_full|v1_full_sym|cfg5_full_sym) K="cpi_cov_kernel<1;cpi_mean_kernel<1, true";;
+    v2_full|v2_full_sym) K="cpi_cov_kernel<2";;
     forster_full) K="cpi_forster_kernel";;
     factor_v1_packed|factor_v2_packed) K="cpi_factor_packed_kernel";;
     factor_v1) K="cpi_factor_kernel<1, false";;

@@ -6,7 +6,7 @@
 # row's measurements, torch's generators) appear in its table too; the row's own kernels are the ones launched `steps` x 4
 # times (3 timed repetitions + warm-up).
 R=$PWD; OUT=$1; shift
-ROWS=${@:-"v1_mean:10000:50:2000 v1_mean:30000:50:500 v1_mean:100000:50:200 v1_mean:1000000:50:20 v1_full:100000:50:20 v2_full:100000:50:20 forster_full:100000:50:20 factor_v1:1000000:50:20 factor_v2:1000000:50:20 factor_v1_packed:1000000:50:20 factor_v2_packed:1000000:50:20 sqrt_info:1000000:50:10 factor_v1_whitened:1000000:50:10 factor_v2_whitened:1000000:50:10 factor_v1_hessian:1000000:50:10 factor_v2_hessian:1000000:50:10 predict_v1:1000000:50:20 predict_v2:1000000:50:20 cfg5_mean:1000000:100:10 cfg5_full:1000000:100:3 v1_mean_tiled:1000000:50:20 v2_mean_tiled:1000000:50:20 v1_mean_tiled:10000:50:1000 v1_mean_stream:1000000:50:20 v1_full_stream:100000:50:20 v2_full_stream:100000:50:20"}
+ROWS=${@:-"v1_mean:10000:50:2000 v1_mean:30000:50:500 v1_mean:100000:50:200 v1_mean:1000000:50:20 v1_full:100000:50:20 v2_full:100000:50:20 forster_full:100000:50:20 factor_v1:1000000:50:20 factor_v2:1000000:50:20 factor_v1_packed:1000000:50:20 factor_v2_packed:1000000:50:20 sqrt_info:1000000:50:10 factor_v1_whitened:1000000:50:10 factor_v2_whitened:1000000:50:10 factor_v1_hessian:1000000:50:10 factor_v2_hessian:1000000:50:10 predict_v1:1000000:50:20 predict_v2:1000000:50:20 cfg5_mean:1000000:100:10 cfg5_full:1000000:100:3 v1_mean_tiled:1000000:50:20 v2_mean_tiled:1000000:50:20 v1_mean_tiled:10000:50:1000 v1_mean_stream:1000000:50:20 v1_full_stream:100000:50:20 v2_full_stream:100000:50:20 sqrt_info_packed:1000000:50:10 factor_v1_whitened_tri:1000000:50:10 factor_v2_whitened_tri:1000000:50:10 factor_v1_hessian_tri:1000000:50:10 factor_v2_hessian_tri:1000000:50:10 v1_full_sym:100000:50:20 v2_full_sym:100000:50:20 v1_mean:1000000:10:20 v1_mean:1000000:20:20 v1_mean:10000:10:2000 v1_mean:10000:20:2000 v1_full:1000000:10:3 v2_full:1000000:20:3 v1_mean_tiled:1000000:10:20 v1_mean_stream:1000000:20:20"}
 export TMPDIR=/tmp
 : > $R/$OUT
 for row in $ROWS; do
