@@ -676,7 +676,7 @@ def roofline_of(name, W, N, launch_s, pmc_rows, pmc_note):
     row = pmc_rows.get("%s:%d:%d" % (name, W, N))
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": row.get("traffic_bytes") if row else None,
-         "traffic_unit": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate rocprofv3 --pmc passes; " + pmc_note,
+         "traffic_unit": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 --pmc; " + pmc_note,
          "algorithmic_bytes_per_launch": bpu * W, "algorithmic_bytes_per_unit": bpu,
          "kernel": WORKLOADS[name]["kernel"], "launch_us": launch_s * 1e6}
     ul = WORKLOADS[name].get("useful_lanes")
@@ -917,8 +917,8 @@ def main():
         # north_star: >= 40 % of the HBM-read roofline.  One launch of 10 000 windows cannot reach it on this chip (reading the
         # batch alone takes 8.2 us = 0.45); said here, in the line, not only in prose
         res["goal_40pct_hbm"] = bool(res["roofline"]["frac"] >= 0.40)
-        res["goal_note"] = ("north_star asks >= 0.40 of 8 TB/s: reached from ~17 k windows per launch (30 k: 0.46-0.48, 1 M: 0.55-0.64) or "
-                            "with several batches in flight (`overlapped`, measured in this run); one 10 k-window launch is launch / first-burst bound")
+        res["goal_note"] = ("north_star asks >= 0.40 of 8 TB/s: reached from ~17 k windows per launch (30 k: 0.47, 1 M: 0.57) or with several "
+                            "batches in flight (`overlapped`, this run); one 10 k-window launch is launch / first-burst bound")
         if rank == 0 and world == 1 and not a.no_extra and W == 10000:
             # the same workload issued through 2 / 3 / 4 engine contexts (HIP streams): consecutive launches overlap
             try:
@@ -930,9 +930,8 @@ def main():
                                      "mode": "graph" if gper else "eager",
                                      "frac_by_contexts": {str(k): round(bpb / v / 1e9 / HBM_PEAK_GBS, 4) for k, v in best.items()},
                                      "frac_eager_by_contexts": {str(k): round(bpb / v / 1e9 / HBM_PEAK_GBS, 4) for k, v in per.items()},
-                                     "how": "independent batches round-robin over N engine contexts (one HIP stream each); graph: 600 batches "
-                                            "captured as ONE HIP graph (fork / join over the N streams), 5 replays; eager: 3000 launches from the "
-                                            "host; wall clock / batches: an aggregate rate, not a launch duration"}
+                                     "how": "independent batches round-robin over N contexts (one HIP stream + own output ring each); graph: 600 batches "
+                                            "as ONE HIP graph, 5 replays; eager: 3000 host launches; wall / batches = an aggregate rate"}
                 res["goal_40pct_hbm_overlapped"] = bool(res["overlapped"]["frac"] >= 0.40)
                 res["value_overlapped"] = res["overlapped"]["value"]
             except Exception as ex:       # an additional object must never cost the line
@@ -954,7 +953,10 @@ def main():
         res["config"]["value_without_gather"] = total_units * a.steps / wall_ng
         res["config"]["ms_final_gather"] = max(0.0, (wall - wall_ng) * 1e3)
     if dist_on and do_gather:
-        res["config"]["predicted"] = predicted_exchange(wl, world, a.steps, schedule, kern_ms, total_units, getattr(wl, "k", 1))
+        # kernel time per step for the prediction: the same K steps WITHOUT the exchange (`wall_ng`) -- in the chunked / pipelined
+        # schedules the HIP-event time around the K steps includes the waits for a slab's previous gather
+        k_ms = wall_ng * 1e3 if wall_ng else kern_ms
+        res["config"]["predicted"] = predicted_exchange(wl, world, a.steps, schedule, k_ms, total_units, getattr(wl, "k", 1))
     if world > 1:
         # a collective-latency-shaped `value` explains itself: how long the timed region is, and how much of it is the exchange
         share = (gather_ms / (wall * 1e3)) if (do_gather and wall > 0) else 0.0
@@ -1137,16 +1139,23 @@ def verify_gather(eng, wl, tm, world, rank, base_seed, rehearsal):
     return {"gather_verified": (bool(ok) if ok is not None else None) if rank == 0 else None, "gather_verified_how": how}
 
 
+def row_key(r):
+    """Key of an extra row in the line's compact `extra_rows`: workload@units ("1M", "100k" ... for round counts), "xN" appended for the
+    short-window rows (samples != the workload's own N)."""
+    u = r["units_per_step"]
+    us = "%dM" % (u // 1000000) if u % 1000000 == 0 and u else ("%dk" % (u // 1000) if u % 1000 == 0 and u else "%d" % u)
+    own = WORKLOADS.get(r["workload"], {}).get("N")
+    return "%s@%s%s" % (r["workload"], us, "" if r.get("samples") in (None, own) else "x%d" % r["samples"])
+
+
 def emit(res, extra):
     """Rank 0.  The LAST stdout line is ONE JSON object of < 6 KB: the headline with its roofline and cpu_baseline, a compact
     `configs2` object (BASELINE configs[2]: the row the >= 10 M windows/s goal sits on), the end-to-end route table of a
     1 M x 50 batch and one [launch_ms, roofline frac] pair per extra row.  The full rows (each with roofline, counters and CPU
     leg) go to bench_extra.json beside this file (and a copy under gpurun_out/ when that directory exists)."""
     if extra is not None:
-        # key: workload@units, "xN" appended for the short-window rows (samples != the workload's own)
-        rows = {"%s@%d%s" % (r["workload"], r["units_per_step"],
-                             "" if r.get("samples") in (None, WORKLOADS.get(r["workload"], {}).get("N")) else "x%d" % r["samples"]): r for r in extra}
-        c2 = rows.get("v2_full@100000")
+        rows = {row_key(r): r for r in extra}
+        c2 = rows.get("v2_full@100k")
         if c2 and "error" not in c2:
             fp, cb = c2["roofline"].get("fp64", {}), c2.get("cpu_baseline", {})
             res["value_full_integrator"] = c2["value"]
@@ -1158,14 +1167,15 @@ def emit(res, extra):
                                "hbm_frac": c2["roofline"]["frac"], "traffic": c2["roofline"]["traffic"],
                                "cpu_baseline": {k: cb.get(k) for k in ("value", "cores", "kind", "single_core_value")}}
         ms = lambda k: (rows[k]["launch_ms"] if k in rows and "error" not in rows[k] else None)
-        asm = (rows.get("v1_mean_tiled@1000000") or {}).get("assembly", {}).get("ms_per_batch")
+        asm = (rows.get("v1_mean_tiled@1M") or {}).get("assembly", {}).get("ms_per_batch")
         res["routes_1M_x_50"] = {"what": "ms per batch of 1 M windows x 50 samples held as ONE IMU stream + update times (GraphSolver_IMU.cpp:50-69), means out",
-                                 "stream_in_place": ms("v1_mean_stream@1000000"),
-                                 "assemble_tiles": asm, "tiled_kernel": ms("v1_mean_tiled@1000000"),
-                                 "assemble_plus_tiled_first_use": (asm + ms("v1_mean_tiled@1000000")) if asm and ms("v1_mean_tiled@1000000") else None,
-                                 "dense_kernel_preassembled": ms("v1_mean@1000000")}
-        res["extra_rows"] = {k: ([round(r["launch_ms"], 5), round(r["roofline"]["frac"], 4)] if "roofline" in r else
-                                 ([round(r["us_per_batch"] * 1e-3, 5), round(r["hbm_frac"], 4)] if "hbm_frac" in r else "error"))
+                                 "stream_in_place": ms("v1_mean_stream@1M"),
+                                 "assemble_tiles": asm, "tiled_kernel": ms("v1_mean_tiled@1M"),
+                                 "assemble_plus_tiled_first_use": (asm + ms("v1_mean_tiled@1M")) if asm and ms("v1_mean_tiled@1M") else None,
+                                 "dense_kernel_preassembled": ms("v1_mean@1M")}
+        sig = lambda x: float("%.4g" % x)
+        res["extra_rows"] = {k: ([sig(r["launch_ms"]), round(r["roofline"]["frac"], 3)] if "roofline" in r else
+                                 ([sig(r["us_per_batch"] * 1e-3), round(r["hbm_frac"], 3)] if "hbm_frac" in r else "error"))
                              for k, r in rows.items()}
         res["extra_rows_key"] = "[launch ms, algorithmic bytes / launch / 8 TB/s]"
         doc = {"headline": {k: v for k, v in res.items() if k not in ("extra_rows", "extra_rows_key")}, "rows": extra}

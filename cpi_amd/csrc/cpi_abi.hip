@@ -9,10 +9,12 @@
 //   cpi_cov_kernel<MODEL,AVG>          covariance (model 2: + compounded state transition -> Jacobians) and means;
 //                                      column-lane RK4 recursion.  CpiV1.h:266-353 / CpiV2.h:314-464.
 //   cpi_forster_kernel                 GTSAM's discrete comparator.  GraphSolver_IMU.cpp:141-232.
-//   cpi_factor_kernel<MODEL,WHITEN,LPF> / cpi_factor_packed_kernel / cpi_factor_hessian_kernel
+//   cpi_factor_kernel<MODEL,WHITEN,LPF,TRI> / cpi_factor_packed_kernel / cpi_factor_hessian_kernel<MODEL,TRI>
 //                                      evaluateError residual + Jacobian blocks.  ImuFactorCPIv1.cpp:37-208 / v2.cpp:38-212.
-//   cpi_sqrt_info_kernel               R = chol_upper(P^-1) per factor (ImuFactorCPIv1.h:82).
+//                                      TRI: the square-root information arrives as its packed upper triangle (ABI 3).
+//   cpi_sqrt_info_kernel<PACKED>       R = chol_upper(P^-1) per factor (ImuFactorCPIv1.h:82); PACKED: triangles in and out.
 //   cpi_predict_kernel<MODEL>          GraphSolver_IMU.cpp:263-307.
+// The covariance / Forster kernels write cpi_outputs.P (dense) and / or P_sym (packed upper triangle, ABI 3).
 //   cpi_tile_knots_kernel / cpi_assemble_tiles_kernel   producers of the tiled layout (GraphSolver_IMU.cpp:50-69).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // prototypes and enums only: the library is bound lazily with dlopen (never linked)

@@ -634,20 +634,27 @@ __device__ __forceinline__ void tab_h2t(const double (&w)[15], const BlkTab &T, 
 }
 // TRI: R arrives as its packed upper triangle (cpi_factor_hessian_tri_batch): 480 instead of 900 doubles per wavefront to
 // fetch; the lane's column of R is completed with the zeros the dense form stores below the diagonal -- same registers, same bits.
+// Round 6: LDS is what capped this kernel's occupancy once the pinned core (cpi_math.hpp: CPI_CORE_PIN) had taken its registers from
+// 190 / 238 to 128: the two exchange arrays (Lam, Z: 2 x 8.6 KB) and the four-factor output stage (16.4 KB) allowed 9 wavefronts per CU.
+// They now TIME-SHARE one array -- Lam rows (with y in their spare 16th column) are written, combined into the G22 / g2 runs (t), and
+// only then do the Z rows take their place -- and the stage is filled and flushed two factors at a time: [records | R | tables] is
+// the largest tenant, 11.1 KB with R packed (14.5 KB dense): 12 (11) wavefronts per CU at three per SIMD.  Same arithmetic in the
+// same order as before (tests/hostsim's lane emulation and the whitened sweep still pin it).
+#ifndef CPI_HESS_WPS
+#define CPI_HESS_WPS 3
+#endif
 template <int MODEL, bool TRI = false>
-__global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
+__global__ __launch_bounds__(64, CPI_HESS_WPS) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
     using namespace hsn;
     constexpr int FPW = 4, IN_D = fin::IN_D, RD = TRI ? CPI_TRI_DOUBLES : 225;
-    // [input records | R] -> [zx | lam] with the block tables at the far end (dead before lam reaches them); at the end
-    // everything is dead and becomes the output stage
-    constexpr int U1 = FPW * MAT_D;
-    static_assert(FPW * IN_D <= U1 && FPW * 225 <= U1 && TB_END <= TAB_D, "the areas are re-used");
-    __shared__ __attribute__((aligned(16))) double sAll[2 * U1];
+    // [input records | R | block tables] -> ONE exchange array (Lam, then Z) -> the output stage of two factors (+ 64 trash slots)
+    constexpr int U1 = FPW * MAT_D, HEAD = FPW * IN_D + FPW * RD + FPW * TAB_D, STAGE = 2 * HESS_PACKED + 64;
+    constexpr int LDS_D = (HEAD > U1 ? HEAD : U1) > STAGE ? (HEAD > U1 ? HEAD : U1) : STAGE;
+    static_assert(TB_END <= TAB_D && MAT_D >= 15 * ROWP && ROWP >= 16, "table / exchange geometry");
+    __shared__ __attribute__((aligned(16))) double sAll[LDS_D];
     __shared__ double sDummy[2];
-    static_assert(FPW * HESS_PACKED + 64 <= 2 * U1, "stage area");
-    double *sU1 = sAll, *sLam = sAll + U1;
-    double *sR = sAll + FPW * IN_D, *sTab = sAll + 2 * U1 - FPW * TAB_D;
-    static_assert(FPW * IN_D + FPW * 225 <= 2 * U1 - FPW * TAB_D, "R sits between the records and the block tables");
+    double *sU1 = sAll;
+    double *sR = sAll + FPW * IN_D, *sTab = sAll + FPW * IN_D + FPW * RD;
     const int lane = threadIdx.x;
     const long long grp = factor_group_of_block((A.F + FPW - 1) / FPW);
     if (grp < 0) return;
@@ -698,10 +705,11 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
         dcol = h2_diag_col(blk, (q < 15) ? q / 3 : 0, (q < 15) ? q % 3 : 0);
     }
 
-    // ---- row phase: row q of Lam and of Z, y_q
-    double *lam = sLam + f * MAT_D, *zx = sU1 + f * MAT_D;
+    // ---- row phase: row q of Lam and of Z, y_q -- in registers; Lam (+ y in column 15) goes to the exchange array first
+    double *xch = sAll + f * MAT_D;
+    double z[15], y;
     {
-        double l[15], z[15], own[15];
+        double l[15], own[15];
 #pragma unroll
         for (int k = 0; k < 15; k++) {
             if constexpr (TRI) { const double v = sR[f * RD + qr * (qr + 1) / 2 + min(k, qr)]; own[k] = (k <= qr) ? v : 0.0; }
@@ -709,60 +717,68 @@ __global__ __launch_bounds__(64, 2) void cpi_factor_hessian_kernel(FactorArgs A,
         }
         lambda_row_dpp<0>(own, l);
         tab_h1t(l, T, z);
-        double y = tmul<TB_ERR>(T, l[0]);
+        y = tmul<TB_ERR>(T, l[0]);
         tab_edot<1>(y, l, T);
-        wave_lds_fence();     // every lane has read R (and its table entries) before the areas become zx / lam
+        wave_lds_fence();     // every lane has read R (and its table entries) before the area becomes the exchange array
 #pragma unroll
-        for (int c = 0; c < 15; c++) { lam[qr * ROWP + c] = l[c]; zx[qr * ROWP + c] = z[c]; }
-        zx[qr * ROWP + 15] = y;
+        for (int c = 0; c < 15; c++) xch[qr * ROWP + c] = l[c];
+        xch[qr * ROWP + 15] = y;
     }
     wave_lds_fence();
 
-    // ---- column phase: everything the lane stores, into registers (hsn::lane_columns; the exchange arrays die here)
+    // ---- column phase, part 1 (needs Lam): the G22 / g2 run t.  hsn::lane_columns is the host twin of the whole phase.
+    const int j = (q < 15) ? q / 3 : 0;
     double g[15], u[15], t[15], fq;
     {
-        const int j = (q < 15) ? q / 3 : 0;
+        double w[15];
+        rows_comb(xch, j, dcol, w);
+#pragma unroll
+        for (int c = 0; c < 15; c++) w[c] = (q == 15) ? -xch[c * ROWP + 15] : w[c];      // lane 15: w = -y
+        tab_h2t(w, T, t);
+    }
+    wave_lds_fence();         // Lam is consumed: the Z rows take its place (column 15 keeps y)
+#pragma unroll
+    for (int c = 0; c < 15; c++) xch[qr * ROWP + c] = z[c];
+    wave_lds_fence();
+    // ---- part 2 (needs Z): the G11 / g1 / f run g, fq and the G12 run u
+    {
         const double sgn = (q == 15) ? -1.0 : 1.0;
-        {
-            double zc[15];
+        double zc[15];
 #pragma unroll
-            for (int k = 0; k < 15; k++) zc[k] = sgn * zx[k * ROWP + q];       // column q of Z; for q = 15: -y
-            tab_h1t(zc, T, g);
-            double acc = tmul<TB_ERR>(T, zc[0]);
-            tab_edot<1>(acc, zc, T);
-            fq = -acc;
-        }
-        {
-            double w[15];
-            rows_comb(lam, j, dcol, w);
-#pragma unroll
-            for (int c = 0; c < 15; c++) w[c] = (q == 15) ? -zx[c * ROWP + 15] : w[c];      // lane 15: w = -y
-            tab_h2t(w, T, t);
-        }
-        rows_comb(zx, j, dcol, u);
+        for (int k = 0; k < 15; k++) zc[k] = sgn * xch[k * ROWP + q];       // column q of Z; for q = 15: -y
+        tab_h1t(zc, T, g);
+        double acc = tmul<TB_ERR>(T, zc[0]);
+        tab_edot<1>(acc, zc, T);
+        fq = -acc;
+        rows_comb(xch, j, dcol, u);
     }
     wave_lds_fence();
 
-    // ---- out through the stage: the four factors' packed triangles are one contiguous 15.9 KB run of the output
-    double *st = sAll + f * HESS_PACKED;
-    double *trash = sAll + FPW * HESS_PACKED + lane;
-    {
-        double *pg = st + ((q < 15) ? pk(0, q) : pk(0, 30));
-        double *pt = st + ((q < 15) ? pk(15, 15 + q) : pk(15, 30));
-        double *pu = (q < 15) ? st + pk(0, 15 + q) : trash;
+    // ---- out through the stage, two factors at a time: their packed triangles are one contiguous 7.9 KB run of the output
 #pragma unroll
-        for (int r = 14; r >= 0; r--) pg[r] = g[r];        // descending: the owner of an entry stores it after every trespasser
+    for (int pass = 0; pass < 2; pass++) {
+        const int cnt = min(2, nf - 2 * pass);               // wave-uniform
+        if (cnt <= 0) break;
+        double *trash = sAll + 2 * HESS_PACKED + lane;
+        if ((f >> 1) == pass) {
+            double *st = sAll + (f & 1) * HESS_PACKED;
+            double *pg = st + ((q < 15) ? pk(0, q) : pk(0, 30));
+            double *pt = st + ((q < 15) ? pk(15, 15 + q) : pk(15, 30));
+            double *pu = (q < 15) ? st + pk(0, 15 + q) : trash;
+#pragma unroll
+            for (int r = 14; r >= 0; r--) pg[r] = g[r];        // descending: the owner of an entry stores it after every trespasser
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 15; r++) pt[r] = t[r];
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 15; r++) (q < 15 ? pu + r : trash)[0] = u[r];
+            *((q == 15) ? st + pk(30, 30) : trash) = fq;
+        }
         wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 15; r++) pt[r] = t[r];
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 15; r++) (q < 15 ? pu + r : trash)[0] = u[r];
-        *((q == 15) ? st + pk(30, 30) : trash) = fq;
-    }
-    wave_lds_fence();
-    for (int idx = lane; idx < nf * (HESS_PACKED / 2); idx += 64) {
-        st16_nt(hess + f0 * HESS_PACKED + 2 * idx, sAll[2 * idx], sAll[2 * idx + 1]);
+        for (int idx = lane; idx < cnt * (HESS_PACKED / 2); idx += 64)
+            st16_nt(hess + (f0 + 2 * pass) * HESS_PACKED + 2 * idx, sAll[2 * idx], sAll[2 * idx + 1]);
+        wave_lds_fence();     // the flush has read the stage (in-order DS) before the next pair overwrites it
     }
 }
 

@@ -90,18 +90,18 @@ def test_the_full_extra_rows_land_in_bench_extra_json(driver_run):
     assert doc["headline"]["value"] == r["value"] and doc["headline"]["config"]["library_build"] == r["config"]["library_build"]
     # the compact per-row summary of the line agrees with the file
     import bench
-    key = lambda x: "%s@%d%s" % (x["workload"], x["units_per_step"], "" if x.get("samples") in (None, bench.WORKLOADS.get(x["workload"], {}).get("N")) else "x%d" % x["samples"])
+    key = bench.row_key
     assert set(r["extra_rows"]) == {key(x) for x in rows}
     by = {key(x): x for x in rows}
     # round 6: the reference's own window lengths (10 / 20 samples) with roofline AND the reference's CPU leg at that length
-    for k in ("v1_mean@1000000x10", "v1_mean@1000000x20", "v1_full@1000000x10", "v2_full@1000000x20"):
+    for k in ("v1_mean@1Mx10", "v1_mean@1Mx20", "v1_full@1Mx10", "v2_full@1Mx20"):
         assert by[k]["roofline"]["frac"] > 0 and by[k]["cpu_baseline"]["value"] > 0 and "%d-sample" % by[k]["samples"] in by[k]["cpu_baseline"]["sample"], k
-    assert by["v1_mean@1000000x20"]["roofline"]["frac"] >= 0.50
+    assert by["v1_mean@1Mx20"]["roofline"]["frac"] >= 0.50
     # ... and the packed-triangle rows of ABI 3 beside their dense twins
-    assert by["sqrt_info_packed@1000000"]["launch_ms"] < 0.70 * by["sqrt_info@1000000"]["launch_ms"]
+    assert by["sqrt_info_packed@1M"]["launch_ms"] < 0.70 * by["sqrt_info@1M"]["launch_ms"]
     # (rows of one run are measured minutes apart at whatever clock the box holds then: the same-box alternating A/B of the two
     #  forms is profiles/r06_packed.md; here only "not slower beyond the noise")
-    assert by["factor_v1_whitened_tri@1000000"]["launch_ms"] < 1.05 * by["factor_v1_whitened@1000000"]["launch_ms"]
+    assert by["factor_v1_whitened_tri@1M"]["launch_ms"] < 1.05 * by["factor_v1_whitened@1M"]["launch_ms"]
 
 
 def test_no_extra_no_cpu_still_prints_one_contract_line():
