@@ -1060,83 +1060,27 @@ def rccl_info(rehearsal, eng):
 def link_types():
     """What connects the GPUs of this node (`rocm-smi --showtopotype`: XGMI / PCIE per pair), so that the first scaling record says
     whether the gather really went over xGMI.  {"GPU0": {"GPU1": "XGMI", ...}, ...}, or a short error string; never raises."""
+    import re
     import subprocess
     try:
-        p = subprocess.run(["rocm-smi", "--showtopotype", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
-        d = json.loads(p.stdout[p.stdout.index("{"):])
-        out = {}
-        for k, v in (d.get("system", d) or {}).items():            # "Link Type between DRM devices 0 and 1": "XGMI" (one key per pair)
-            words = k.replace(":", " ").split()
-            ids = [w for w in words if w.isdigit()]
-            if len(ids) >= 2 and isinstance(v, str):
-                out.setdefault("GPU" + ids[0], {})["GPU" + ids[1]] = v
-        return out or {"raw": p.stdout.strip()[:300]}
+        p = subprocess.run(["rocm-smi", "--showtopotype"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20)
+        return parse_link_types(p.stdout) or {"raw": " ".join(p.stdout.split())[:300]}
     except Exception as ex:
         return "unavailable: %r" % (ex,)
 
 
-def verify_gather(eng, wl, tm, world, rank, base_seed, rehearsal):
-    """After the timed region: rank 0 regenerates EVERY rank's batch of the last timed step (the synthetic generator is
-    seeded per rank and batch), computes it on its own GPU with the launch geometry the owning rank used, and asserts that
-    the block that arrived through the exchange is BITWISE equal; then the same windows as ONE unsharded call of world x W
-    windows (the auto lane split of the mean kernel may differ there: compared at the 2e-13 regression gate, not bitwise)."""
-    import torch.distributed as dist
-    from cpi_amd import synth
-    ok, maxdiff, why = None, None, None
-    if wl.kind != "pre":
-        why = "not verified: only the dense-layout workloads regenerate another rank's batch"
-    elif rank == 0:
-        try:
-            g = tm.get("gathered")
-            b = tm["last_step"] % wl.nbatch
-            ok, maxdiff = g is not None, 0.0
-            parts = []
-            k = getattr(wl, "k", 1) if tm.get("mode") == "chunked-eager" else 1
-
-            def recompute(kn, lin, q):
-                """with the launch geometry the owning rank used: the chunked schedule launches W / k windows at a time (the mean
-                kernel's automatic lane split depends on the launch size)"""
-                if k <= 1:
-                    return eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
-                from cpi_amd.dist import chunk_bounds
-                pieces = []
-                for c in range(k):
-                    lo, hi, _ = chunk_bounds(wl.W, c, k)
-                    if hi > lo:
-                        pieces.append(eng.preintegrate(kn[lo:hi], lin[lo:hi], q[lo:hi] if wl.model != 3 else None, wl.prm, want=wl.want))
-                return {name: torch.cat([p_[name] for p_ in pieces], dim=0) for name in pieces[0]}
-            for r in range(world if g is not None else 0):
-                kn, lin, q = synth.make_windows(wl.W, wl.N, seed=base_seed(r) + 101 * b, device=eng.device)
-                out = recompute(kn, lin, q)
-                torch.cuda.synchronize()
-                for name, n in wl.outs[0]["_fields"]:
-                    ok = ok and torch.equal(g[name][r].reshape(out[name].shape), out[name])
-                parts.append((kn, lin, q))
-                del out
-            if ok and world * wl.W * (wl.N + 1) * 56 <= (64 << 30):
-                kn = torch.cat([p[0] for p in parts]); lin = torch.cat([p[1] for p in parts]); q = torch.cat([p[2] for p in parts])
-                del parts
-                out = eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
-                torch.cuda.synchronize()
-                for name, n in wl.outs[0]["_fields"]:
-                    got, ref = g[name].reshape(out[name].shape), out[name]
-                    scale = ref.abs().amax().clamp_min(1.0) if name != "P" else ref.abs().amax().clamp_min(1e-300)
-                    maxdiff = max(maxdiff, float(((got - ref).abs().amax() / scale).item()))
-                ok = ok and maxdiff <= 2e-13
-        except Exception as ex:      # the verification must never cost the timing record (e.g. no memory for N regenerated batches)
-            ok, why = None, "not verified: %r" % (ex,)
-            torch.cuda.empty_cache()
-    flag = torch.tensor([1.0 if ok else (0.0 if ok is not None else -1.0)], dtype=torch.float64, device="cpu" if rehearsal else eng.device)
-    dist.broadcast(flag, src=0)
-    if flag.item() == 0.0:
-        # a mismatch is reported IN the line (gather_verified: false) so that the timing record survives; CPI_BENCH_STRICT=1 (the
-        # tests) turns it into a non-zero exit on every rank
-        sys.stderr.write("bench.py: the gathered outputs of the last timed step DIFFER from rank 0's recomputation\n")
-        if os.environ.get("CPI_BENCH_STRICT"):
-            raise SystemExit(3)
-    how = why or ("rank 0 recomputed every rank's last-step batch: gathered blocks %s; one unsharded call over all %d x %d windows "
-                  "agrees to %.1e (relative; gate 2e-13)" % ("bitwise equal" if ok else "DIFFER (or the unsharded call is off the gate)", world, wl.W, maxdiff or 0.0))
-    return {"gather_verified": (bool(ok) if ok is not None else None) if rank == 0 else None, "gather_verified_how": how}
+def parse_link_types(text):
+    """The matrix `rocm-smi --showtopotype` prints (header row "GPU0 GPU1 ...", then one row per device: "GPU0 0 XGMI ...") ->
+    {"GPU0": {"GPU1": "XGMI", ...}, ...}; the diagonal ("0") is dropped; a 1-GPU box gives {"GPU0": {}}."""
+    import re
+    head, out = None, {}
+    for ln in text.splitlines():
+        w = ln.split()
+        if w and all(re.fullmatch(r"GPU\d+", x) for x in w):
+            head = w
+        elif head and w and re.fullmatch(r"GPU\d+", w[0]) and len(w) == len(head) + 1:
+            out[w[0]] = {h: v for h, v in zip(head, w[1:]) if h != w[0]}
+    return out
 
 
 def row_key(r):

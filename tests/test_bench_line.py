@@ -53,3 +53,22 @@ def test_emit_without_extra_rows_is_the_plain_headline(tmp_path, monkeypatch, ca
     bench.emit({"metric": "m", "value": 1.0}, None)
     assert json.loads(capsys.readouterr().out.strip()) == {"metric": "m", "value": 1.0}
     assert not (tmp_path / "bench_extra.json").exists()
+
+
+def test_link_types_are_parsed_from_rocm_smi_text():
+    one = """============================ ROCm System Management Interface ============================
+=============================== Link Type between two GPUs ===============================
+       GPU0         
+GPU0   0            
+================================== End of ROCm SMI Log ==================================="""
+    assert bench.parse_link_types(one) == {"GPU0": {}}
+    four = """=============================== Link Type between two GPUs ===============================
+       GPU0         GPU1         GPU2         GPU3         
+GPU0   0            XGMI         XGMI         PCIE         
+GPU1   XGMI         0            XGMI         XGMI         
+GPU2   XGMI         XGMI         0            XGMI         
+GPU3   PCIE         XGMI         XGMI         0            
+"""
+    lt = bench.parse_link_types(four)
+    assert lt["GPU0"] == {"GPU1": "XGMI", "GPU2": "XGMI", "GPU3": "PCIE"} and lt["GPU3"]["GPU0"] == "PCIE" and len(lt) == 4
+    assert bench.parse_link_types("WARNING: No JSON data to report") == {}
