@@ -1083,6 +1083,70 @@ def parse_link_types(text):
     return out
 
 
+def verify_gather(eng, wl, tm, world, rank, base_seed, rehearsal):
+    """After the timed region: rank 0 regenerates EVERY rank's batch of the last timed step (the synthetic generator is
+    seeded per rank and batch), computes it on its own GPU with the launch geometry the owning rank used, and asserts that
+    the block that arrived through the exchange is BITWISE equal; then the same windows as ONE unsharded call of world x W
+    windows (the auto lane split of the mean kernel may differ there: compared at the 2e-13 regression gate, not bitwise)."""
+    import torch.distributed as dist
+    from cpi_amd import synth
+    ok, maxdiff, why = None, None, None
+    if wl.kind != "pre":
+        why = "not verified: only the dense-layout workloads regenerate another rank's batch"
+    elif rank == 0:
+        try:
+            g = tm.get("gathered")
+            b = tm["last_step"] % wl.nbatch
+            ok, maxdiff = g is not None, 0.0
+            parts = []
+            k = getattr(wl, "k", 1) if tm.get("mode") == "chunked-eager" else 1
+
+            def recompute(kn, lin, q):
+                """with the launch geometry the owning rank used: the chunked schedule launches W / k windows at a time (the mean
+                kernel's automatic lane split depends on the launch size)"""
+                if k <= 1:
+                    return eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
+                from cpi_amd.dist import chunk_bounds
+                pieces = []
+                for c in range(k):
+                    lo, hi, _ = chunk_bounds(wl.W, c, k)
+                    if hi > lo:
+                        pieces.append(eng.preintegrate(kn[lo:hi], lin[lo:hi], q[lo:hi] if wl.model != 3 else None, wl.prm, want=wl.want))
+                return {name: torch.cat([p_[name] for p_ in pieces], dim=0) for name in pieces[0]}
+            for r in range(world if g is not None else 0):
+                kn, lin, q = synth.make_windows(wl.W, wl.N, seed=base_seed(r) + 101 * b, device=eng.device)
+                out = recompute(kn, lin, q)
+                torch.cuda.synchronize()
+                for name, n in wl.outs[0]["_fields"]:
+                    ok = ok and torch.equal(g[name][r].reshape(out[name].shape), out[name])
+                parts.append((kn, lin, q))
+                del out
+            if ok and world * wl.W * (wl.N + 1) * 56 <= (64 << 30):
+                kn = torch.cat([p[0] for p in parts]); lin = torch.cat([p[1] for p in parts]); q = torch.cat([p[2] for p in parts])
+                del parts
+                out = eng.preintegrate(kn, lin, q if wl.model != 3 else None, wl.prm, want=wl.want)
+                torch.cuda.synchronize()
+                for name, n in wl.outs[0]["_fields"]:
+                    got, ref = g[name].reshape(out[name].shape), out[name]
+                    scale = ref.abs().amax().clamp_min(1.0) if name != "P" else ref.abs().amax().clamp_min(1e-300)
+                    maxdiff = max(maxdiff, float(((got - ref).abs().amax() / scale).item()))
+                ok = ok and maxdiff <= 2e-13
+        except Exception as ex:      # the verification must never cost the timing record (e.g. no memory for N regenerated batches)
+            ok, why = None, "not verified: %r" % (ex,)
+            torch.cuda.empty_cache()
+    flag = torch.tensor([1.0 if ok else (0.0 if ok is not None else -1.0)], dtype=torch.float64, device="cpu" if rehearsal else eng.device)
+    dist.broadcast(flag, src=0)
+    if flag.item() == 0.0:
+        # a mismatch is reported IN the line (gather_verified: false) so that the timing record survives; CPI_BENCH_STRICT=1 (the
+        # tests) turns it into a non-zero exit on every rank
+        sys.stderr.write("bench.py: the gathered outputs of the last timed step DIFFER from rank 0's recomputation\n")
+        if os.environ.get("CPI_BENCH_STRICT"):
+            raise SystemExit(3)
+    how = why or ("rank 0 recomputed every rank's last-step batch: gathered blocks %s; one unsharded call over all %d x %d windows "
+                  "agrees to %.1e (relative; gate 2e-13)" % ("bitwise equal" if ok else "DIFFER (or the unsharded call is off the gate)", world, wl.W, maxdiff or 0.0))
+    return {"gather_verified": (bool(ok) if ok is not None else None) if rank == 0 else None, "gather_verified_how": how}
+
+
 def row_key(r):
     """Key of an extra row in the line's compact `extra_rows`: workload@units ("1M", "100k" ... for round counts), "xN" appended for the
     short-window rows (samples != the workload's own N)."""

@@ -72,3 +72,28 @@ GPU3   PCIE         XGMI         XGMI         0
     lt = bench.parse_link_types(four)
     assert lt["GPU0"] == {"GPU1": "XGMI", "GPU2": "XGMI", "GPU3": "PCIE"} and lt["GPU3"]["GPU0"] == "PCIE" and len(lt) == 4
     assert bench.parse_link_types("WARNING: No JSON data to report") == {}
+
+
+def test_every_global_name_bench_py_uses_is_defined():
+    """A refactoring slip once deleted a helper that only the N > 1 path calls (found by the GPU rehearsals, not here): every global
+    name loaded anywhere in bench.py must be a builtin, an import or a module-level definition."""
+    import ast
+    import builtins
+    src = open(bench.__file__).read()
+    tree = ast.parse(src)
+    defined = set(dir(builtins)) | set(vars(bench))
+    local_scopes = set()
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.FunctionDef, ast.Lambda)):
+            a = node.args
+            local_scopes.update(x.arg for x in a.args + a.kwonlyargs + ([a.vararg] if a.vararg else []) + ([a.kwarg] if a.kwarg else []))
+        if isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+            local_scopes.add(node.id)
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            local_scopes.update((al.asname or al.name).split(".")[0] for al in node.names)
+        if isinstance(node, ast.ExceptHandler) and node.name:
+            local_scopes.add(node.name)
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            local_scopes.add(node.name)
+    missing = sorted({n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)} - defined - local_scopes)
+    assert not missing, missing

@@ -133,6 +133,49 @@ def main():
         if not (np.abs(hess.cpu().numpy() - want_h) / np.abs(want_h).max(axis=1, keepdims=True)).max() < 1e-12:
             fails += 1
             print("FAIL hessian case", case, F, model, flush=True)
+    # ABI 3 (round 6): the packed triangles are the dense forms' own entries -- P_sym out of random preintegrations (every model, averaging,
+    # ragged counts), R_tri and the whitened / Hessian sweeps on it against the dense pipeline, BIT FOR BIT; and the state prediction
+    # (rebuilt in round 6: one coalesced burst per wavefront) against the restatement with random gathered indices
+    npk = 0
+    for case in range(max(6, cases // 10)):
+        F = int(rng.integers(1, 2500))
+        N = int(rng.integers(1, 60))
+        model = int(rng.integers(1, 4))
+        avg = int(rng.integers(0, 2)) if model < 3 else 0
+        kn, lin, q = synth.make_windows(F, N, seed=seed * 3000 + case, device=eng.device, edge_cases=bool(rng.integers(0, 2)))
+        cnt = torch.from_numpy(rng.integers(0, N + 1, F).astype(np.int32)).to(eng.device) if rng.integers(0, 2) else None
+        prm = eng.make_params(model, avg, 1)
+        qq = q if model != 3 else None
+        both = eng.preintegrate(kn, lin, qq, prm, want=("mean", "jac", "cov", "cov_sym"), count=cnt)
+        only = eng.preintegrate(kn, lin, qq, prm, want=("cov_sym",), count=cnt)
+        torch.cuda.synchronize()
+        ok = torch.equal(both["P_sym"], cpi_amd.pack_sym(both["P"])) and torch.equal(only["P_sym"], both["P_sym"])
+        if model != 3:
+            ok = ok and torch.equal(cpi_amd.unpack_sym(both["P_sym"]), both["P"])
+        if ok and model != 3 and cnt is None and N >= 8:
+            R, Rt = eng.sqrt_information(both["P"]), eng.sqrt_information(both["P_sym"])
+            xi, xj = synth.make_states(both["alpha"], both["beta"], both["q"], both["DT"], lin, model, device=eng.device, seed=seed * 13 + case)
+            S = int(rng.integers(1, F + 2))
+            states = torch.cat([xi, xj], 0)[:max(S, 2)].contiguous()
+            ii = torch.from_numpy(rng.integers(-2, states.shape[0] + 2, F).astype(np.int32)).to(eng.device)
+            jj = torch.from_numpy(rng.integers(-2, states.shape[0] + 2, F).astype(np.int32)).to(eng.device)
+            m = {k: v for k, v in both.items() if k not in ("P", "P_sym")}
+            q2 = q if model == 2 else None
+            wd, wt = eng.factor_eval(model, m, lin, q2, states, ii, jj, sqrt_info=R), eng.factor_eval(model, m, lin, q2, states, ii, jj, sqrt_info=Rt)
+            hd, ht = eng.factor_hessian(model, m, lin, q2, states, R, ii, jj), eng.factor_hessian(model, m, lin, q2, states, Rt, ii, jj)
+            xp = eng.predict(model, m, states, idx_i=ii)
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(cpi_amd.unpack_tri(Rt), R) and all(torch.equal(wd[k], wt[k]) for k in wd) and torch.equal(hd, ht)
+            n = min(F, 400)
+            sel = ii[:n].clamp(0, states.shape[0] - 1).long()
+            rec = op.factor_records({k: v[:n].cpu().numpy() for k, v in m.items()}, lin[:n].cpu().numpy(), q[:n].cpu().numpy() if model == 2 else None)
+            want_x = op.oracle().predict(model, rec, states[sel].cpu().numpy())
+            ok = ok and np.abs(xp[:n].cpu().numpy() - want_x).max() <= 1e-9 * max(1.0, np.abs(want_x).max())
+        npk += 1
+        if not ok:
+            fails += 1
+            print("FAIL packed-forms case", case, F, N, model, avg, flush=True)
+    print("campaign seed %d: %d packed-triangle / prediction cases" % (seed, npk), flush=True)
     # the zero-copy stream entry: random streams (irregular sampling, repeated stamps) cut at random update times -- against
     # the oracle's deque-loop restatement and BIT FOR BIT against the host-assembled ragged layout, random lane splits / outputs
     from cpi_amd import stream as st

@@ -74,6 +74,8 @@ PY
   for m in 1 2 3; do run "test_facade model $m (ASan+UBSan: facade, C-ABI host code, host pipeline)" build/san/test_facade_asan build/san/w48.bin $m; done
   run "test_group 1 device" build/san/test_group_asan build/san/w48.bin 1 1
   run "test_group 5 ranks on one device (slab gather, RCCL stand-in)" env CPI_AMD_RCCL_LIB=$FAKE build/san/test_group_asan build/san/w48.bin 2 5 shared
+  run "test_group 1 device, exchange in 3 sub-blocks (cpi_group_gather_chunk, packed covariance in the slab)" build/san/test_group_asan build/san/w48.bin 1 1 native 3
+  run "test_group 5 ranks on one device, exchange in 3 sub-blocks (RCCL stand-in)" env CPI_AMD_RCCL_LIB=$FAKE build/san/test_group_asan build/san/w48.bin 2 5 shared 3
   run "test_threads 4 host threads (ASan+UBSan)" build/san/test_threads_asan build/san/thr.bin 4
   python - <<'PY'
 import numpy as np
