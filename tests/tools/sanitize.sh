@@ -24,6 +24,16 @@ run() {   # run <label> <cmd...>: a sanitizer report (or a non-zero exit) fails 
   local label=$1; shift
   local log=build/san/$(echo "$label" | tr ' /' '__').log
   "$@" > $log 2>&1; local rc=$?
+  # Known artefact of ROCm's ASan runtime, NOT a report about this code: at process exit libamdhip64's finaliser tears libhsa-runtime64
+  # down, an `operator delete` there makes ASan recycle a quarantined chunk of its DEVICE allocator after that allocator has flagged the
+  # runtime as unloaded, and the sanitizer aborts on its own CHECK (sanitizer_allocator_device.h: "!dev_runtime_unloaded_").  Seen since
+  # round 6 on the facade host that lets worker threads create thread-local contexts.  Accepted only when the report is that CHECK,
+  # there is no AddressSanitizer ERROR / UBSan report, and NO frame of the stack lies in libcpi_amd, the facade or the test program.
+  if grep -q "CHECK failed: sanitizer_allocator_device.h" $log && ! grep -qE "ERROR: AddressSanitizer|runtime error:|WARNING: ThreadSanitizer|ERROR: LeakSanitizer" $log \
+     && ! grep -E "^ +#[0-9]+ " $log | grep -qE "libcpi_amd|cpi_host|test_[a-z_]+_asan|cpi_abi"; then
+    say "clean $label   [ASan-runtime CHECK in the HSA teardown at exit (all frames inside the sanitizer / libhsa-runtime64 / libamdhip64 / libc): ignored]"
+    return
+  fi
   if [ $rc -ne 0 ] || grep -qE "ERROR: AddressSanitizer|runtime error:|WARNING: ThreadSanitizer|ERROR: LeakSanitizer" $log; then
     say "FAIL  $label (rc=$rc)"; grep -E "Sanitizer|runtime error" $log | head -5 | tee -a $OUT; tail -3 $log | tee -a $OUT; FAIL=1
   else
