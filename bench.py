@@ -811,7 +811,7 @@ EXTRA_ROWS = (("v1_mean", 30000, 1000), ("v1_mean", 100000, 300), ("v1_mean", 10
               # cpi_compare/launch/synthetic_test.launch:27-28; (name, windows, steps, samples)
               ("v1_mean", 1000000, 40, 10), ("v1_mean", 1000000, 40, 20), ("v1_mean", 10000, 1000, 10), ("v1_mean", 10000, 1000, 20),
               ("v1_full", 1000000, 5, 10), ("v1_full", 1000000, 3, 20), ("v2_full", 1000000, 3, 10), ("v2_full", 1000000, 3, 20),
-              ("v1_mean_tiled", 1000000, 40, 10), ("v1_mean_tiled", 1000000, 40, 20), ("v1_mean_stream", 1000000, 40, 20))
+              ("v1_mean_tiled", 1000000, 40, 10), ("v1_mean_tiled", 1000000, 40, 20), ("v1_mean_stream", 1000000, 40, 10), ("v1_mean_stream", 1000000, 40, 20))
 
 
 def main():

@@ -97,9 +97,9 @@ typedef struct {
     double *O_a;    /* [W][9]    alpha wrt q_k_lin (model 2) */
     double *O_b;    /* [W][9]    beta wrt q_k_lin  (model 2) */
     double *P;      /* [W][225]  P_meas, dense column-major (the drop-in form: Eigen::Map<Matrix<double,15,15>>) */
-    double *P_sym;  /* [W][120]  P_meas as its packed upper triangle (CPI_SYM_PACKED below; P_meas is symmetric -- the
+    double *P_sym;  /* [W][120]  P_meas as its packed upper triangle (CPI_TRI_INDEX below; P_meas is symmetric -- the
                                  reference itself asserts it, CpiV1.h:352-353 -- so the dense form carries 105 redundant doubles
-                                 = 840 of the 2 320 bytes a window writes).  P and P_sym are independent: either, both or
+                                 = 840 of the 2 248 bytes a model-1 window writes with everything out).  P and P_sym are independent: either, both or
                                  neither; the entries of P_sym are bit for bit the entries (i, j), i <= j, of P */
 } cpi_outputs;
 
@@ -107,7 +107,7 @@ typedef struct {
  * square-root information R) as its non-zero part, both COLUMN by column -- LAPACK's packed 'U' order, the order
  * cpi_factor_hessian_batch already writes its 31 x 31 triangle in:
  *     entry (i, j), i <= j, at  CPI_TRI_INDEX(i, j) = i + j (j + 1) / 2,      120 doubles = 960 bytes instead of 1 800.
- * Column j is the run [j (j + 1) / 2, j (j + 1) / 2 + j].  INTEGRATION.md section 3b shows the Eigen one-liners
+ * Column j is the run [j (j + 1) / 2, j (j + 1) / 2 + j].  INTEGRATION.md section 4a shows the Eigen one-liners
  * (selfadjointView<Upper> / triangularView<Upper>) a GTSAM-side binding unpacks them with; cpi_amd.unpack_sym / unpack_tri /
  * pack_sym are the Python mirrors. */
 #define CPI_TRI_DOUBLES 120
@@ -333,7 +333,7 @@ void cpi_shard_bounds(int64_t W, int rank, int n, int64_t *lo, int64_t *hi);
 int cpi_group_gather(cpi_group *g, int root, int64_t W, const cpi_outputs *local, const cpi_outputs *root_out);
 int cpi_group_last_gather_messages(const cpi_group *g);
 /* The exchange INSIDE one batch (ABI 3; DESIGN.md section 7 has the wire budget that asks for it: at configs[4]'s full-V1 outputs a
- * peer's slab is 1.5 - 2.3 GB over ONE xGMI link, about as long as the kernels that produce it -- issued after them, all of it is
+ * peer's slab is 1.4 - 2.2 GB over ONE xGMI link (18 - 29 ms at 76.8 GB/s one way), about as long as the 26 ms of kernels that produce it -- issued after them, all of it is
  * exposed).  Every rank's block is cut into `chunks` sub-blocks of cper = ceil(ceil(W / n) / chunks) windows
  * (cpi_shard_chunk_bounds: sub-block c of rank r = [lo_r + c cper, min(hi_r, lo_r + (c + 1) cper)); trailing ones may be short or
  * empty).  The host enqueues the ordinary entries for sub-block c on cpi_group_ctx(g, r) and then calls

@@ -80,10 +80,10 @@ def test_the_full_extra_rows_land_in_bench_extra_json(driver_run):
     r = json.loads([ln for ln in stdout.splitlines() if ln.strip()][-1])
     doc = json.load(open(extra_path))
     rows = doc["rows"]
-    assert len(rows) >= 44
+    assert len(rows) >= 45
     assert not [x for x in rows if "error" in x], [x for x in rows if "error" in x]
     with_roof = [x for x in rows if "roofline" in x]
-    assert len(with_roof) >= 43
+    assert len(with_roof) >= 44
     for x in with_roof:
         rf = x["roofline"]
         assert rf["achieved"] > 0 and rf["kernel"] and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
