@@ -60,24 +60,12 @@ bool mean_lanes_supported(int L) {
 #ifndef CPI_MEAN_BIG_NMIN
 #define CPI_MEAN_BIG_NMIN 16
 #endif
-// cpi_mean_block_kernel (N <= CPI_MEAN_BLOCK_NMAX = 11, one lane per window): from this many windows (0 = whenever one lane per window runs)
-#ifndef CPI_MEAN_BLOCK_W
-#define CPI_MEAN_BLOCK_W 0
-#endif
 template <int MODEL, bool JAC, bool AVG>
 static void launch_mean_L(int L, const PreArgs &a, hipStream_t st) {
     // 0: plain knots; 1: windows cut by cpi_cut_windows_kernel (workspace route); 2: the wavefront cuts its own windows
     // (mean-only requests of cpi_preintegrate_stream; no analytic-Jacobian instantiations -- the caller never asks)
     const int cut = a.update != nullptr ? 2 : (a.tstart != nullptr ? 1 : 0);
     if constexpr (!JAC) {
-        // short windows (the reference's own 10 samples per window): the wavefront's knots as one linear LDS block (cpi_mean_block_kernel)
-        const bool blockable = (cut == 2 && a.K >= 4) || (cut == 0 && a.first == nullptr && a.count == nullptr);
-        if (L == 1 && blockable && a.N >= 1 && a.N <= CPI_MEAN_BLOCK_NMAX && a.W >= CPI_MEAN_BLOCK_W) {
-            const unsigned nb = (unsigned)((a.W + 63) / 64);
-            if (cut == 2) hipLaunchKernelGGL((cpi_mean_block_kernel<MODEL, AVG, 2>), dim3(nb), dim3(64), 0, st, a);
-            else hipLaunchKernelGGL((cpi_mean_block_kernel<MODEL, AVG, 0>), dim3(nb), dim3(64), 0, st, a);
-            return;
-        }
         const long long wmin = MODEL == 2 ? (long long)CPI_MEAN_BIG_W_M2 : (cut != 0 ? (long long)CPI_MEAN_BIG_W : (long long)CPI_MEAN_BIG_W_DENSE);
         const bool admitted = cut != 0 ? (a.K > 0 && a.K < (1ll << 26)) : (a.first == nullptr && a.count == nullptr);
         if (L == 1 && admitted && a.W >= wmin && a.N >= CPI_MEAN_BIG_NMIN) {

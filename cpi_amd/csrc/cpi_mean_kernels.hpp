@@ -410,125 +410,6 @@ __global__ __launch_bounds__(64, BIG ? 2 : (((MODEL == 2 && !JAC) || (MODEL == 1
 }
 
 // ============================================================================================
-// mean kernel for SHORT windows: the wavefront's knots as ONE linear block (round 6)
-// ============================================================================================
-// The reference itself preintegrates 10 samples per window (imurate / camrate, synthetic_test.launch:27-28).  At that length the
-// 64 windows of a wavefront are one contiguous run of <= 64 N + 1 knots -- 39 KB at N = 11 -- in BOTH layouts: the dense one
-// (window w = knots [w (N + 1), w (N + 1) + N]) and a stream cut in place (consecutive windows share their boundary knot).  The
-// chunked staging of cpi_mean_kernel visits 64 windows 112-168 bytes at a time (traffic 1.33-1.48 x algorithmic, 4.6-5 TB/s of DRAM
-// efficiency: profiles/r05_mean_traffic.md); here the whole run is fetched ONCE, linearly, by LDS-DMA (global_load_lds_dwordx4: no
-// staging registers, every request in flight at once), and each lane then walks its own window out of LDS.  One lane per window,
-// mean outputs only, N <= CPI_MEAN_BLOCK_NMAX; the same mean_step sequence as the one-lane instantiation of cpi_mean_kernel, so the
-// results are the same bits.  CUT = 0: dense layout (first == count == NULL); CUT = 2: the fused stream cut (cpi_preintegrate_stream,
-// mean-only) -- the window's first knot takes the stamp t_start, a partial tail interval is the last real knot held until t_end.
-// A wavefront whose run does not fit (a truncated window skips knots: the next window then starts far away) reads its knots from
-// global memory directly -- same arithmetic, rare.
-#ifndef CPI_MEAN_BLOCK_NMAX
-#define CPI_MEAN_BLOCK_NMAX 11
-#endif
-constexpr int MEAN_BLOCK_CAP = 64 * CPI_MEAN_BLOCK_NMAX + 2;      // knots of the LDS block (39 536 bytes: 4 wavefronts per CU)
-template <int MODEL, bool AVG, int CUT>
-__global__ __launch_bounds__(64) void cpi_mean_block_kernel(PreArgs A) {
-    static_assert(CUT == 0 || CUT == 2, "dense layout or the fused stream cut");
-    __shared__ __attribute__((aligned(1024))) double blk[MEAN_BLOCK_CAP * 7];
-    const int lane = threadIdx.x;
-    long long w = (long long)blockIdx.x * 64 + lane;
-    const bool valid = w < A.W;
-    if (!valid) w = A.W - 1;
-    int n;
-    long long k0;
-    double t_start = 0.0, t_end = 0.0;
-    bool tail = false;
-    if constexpr (CUT == 2) {
-        // the arithmetic of cpi_cut_windows_kernel (GraphSolver_IMU.cpp:50-69 as a closed form), exactly as cpi_mean_kernel<..., CUT = 2>
-        const double ts0 = A.knots[0], ts1 = A.knots[(A.K - 1) * 7];
-        const double T = A.update[w], Tp = A.update[w > 0 ? w - 1 : 0];
-        double stT, stP;
-        const long long cT = knots_not_after_near(A.knots, A.K, ts0, ts1, T, stT);
-        const long long cP = knots_not_after_near(A.knots, A.K, ts0, ts1, Tp, stP);
-        const long long fp = (w > 0) ? max(cP - 1, 0ll) : 0ll;
-        t_start = (w > 0) ? fmax(Tp, ts0) : ts0;
-        const long long fu = max(max(cT - 1, 0ll), fp);
-        const int m = (int)min(fu - fp, (long long)0x3fffffff);
-        const double front_t = (m > 0) ? stT : t_start;
-        const bool tl = (T - front_t) > 0;
-        const int cnt = m + (tl ? 1 : 0);
-        if (valid) A.count_out[w] = cnt;                                 // the TRUE count (cpi_stream_counts)
-        k0 = fp;
-        n = min(cnt, A.N);
-        t_end = T;
-        tail = tl && cnt <= A.N;                                         // a truncated window has lost its tail
-    } else {
-        n = A.N;
-        k0 = w * (long long)(A.N + 1);
-    }
-    const int n_mem = n - (tail ? 1 : 0);          // knots after the window's first that exist in memory
-    // the wavefront's run [k_lo, k_lo + span): windows are ordered, but nothing here relies on it
-    const long long kf = readfirstlane64(k0);
-    const long long k_lo = kf - (long long)wave_max((int)min(max(kf - k0, 0ll), 0x7fffffffll));
-    const int span = wave_max((int)min(k0 + n_mem - k_lo, 0x7ffffffell)) + 1;
-    const bool fits = span <= MEAN_BLOCK_CAP;      // wave-uniform
-    const V3 bw = ldv3(A.lin + w * 6), ba = ldv3(A.lin + w * 6 + 3);
-    V3 gk = mk(0, 0, 0);
-    if (MODEL == 2) gk = mul(quat_2_Rot(ldq4(A.qk + w * 4)), mk(A.grav[0], A.grav[1], A.grav[2]));
-    if (fits) {
-        // ---- linear fetch: instruction j moves bytes [1024 j, 1024 j + 1024) of the run; the last, partial one runs with the lanes
-        // past the end masked off; a run of odd length ends in the middle of a 16-byte piece: its last double comes through a register
-        const int total = span * 56;
-        const char *src = reinterpret_cast<const char *>(A.knots + k_lo * 7);
-        const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) double *)blk);
-        const unsigned v16 = 16u * (unsigned)lane;
-        const int nfull = total >> 10;
-        for (int j = 0; j < nfull; ++j) glds16(v16, src + ((long long)j << 10), lds_base + ((unsigned)j << 10));
-        const unsigned off = (unsigned)(nfull << 10) + v16;
-        if ((int)(off + 16u) <= total) glds16(off, src, lds_base + ((unsigned)nfull << 10));
-        double lastd = 0.0;
-        const bool patch = (total & 15) != 0;
-        if (patch) lastd = *reinterpret_cast<const double *>(src + total - 8);
-        asm volatile("" : "+v"(lastd));
-        wait_vmcnt<0>();                           // the wave's own counted wait orders its ds_reads behind its LDS-DMA
-        if (patch && lane == 0) blk[span * 7 - 1] = lastd;
-        wave_lds_fence();
-    }
-    const int maxlen = __builtin_amdgcn_readfirstlane(wave_max(n));
-    MeanState<false> st;
-    mean_init(st);
-    auto run = [&](const double *kb) {             // kb: the window's first knot, in LDS or in global memory
-        double pk[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) pk[i] = kb[i];
-        if (CUT == 2) pk[0] = t_start;
-        for (int s = 0; s < maxlen; ++s) {
-            const double *nk = kb + 7 * min(s + 1, n_mem);     // past the window's last knot in memory: that knot again (never consumed)
-            double q[7];
-#pragma unroll
-            for (int i = 0; i < 7; i++) q[i] = nk[i];
-            if (CUT == 2) {                        // the tail knot: the predecessor's reading under the update time
-                const bool here = tail && s == n - 1;
-                q[0] = here ? t_end : q[0];
-#pragma unroll
-                for (int i = 1; i < 7; i++) q[i] = here ? pk[i] : q[i];
-            }
-            mean_step<MODEL, false, AVG>(st, pk[0], q[0], mk(pk[1], pk[2], pk[3]), mk(pk[4], pk[5], pk[6]),
-                                         mk(q[1], q[2], q[3]), mk(q[4], q[5], q[6]), bw, ba, gk, s < n);
-#pragma unroll
-            for (int i = 0; i < 7; i++) pk[i] = q[i];
-        }
-    };
-    if (fits) run(blk + (k0 - k_lo) * 7); else run(A.knots + k0 * 7);
-    if (valid && A.write_means) {
-        if (A.out.DT) A.out.DT[w] = st.DT;
-        if (A.out.alpha) stv3(A.out.alpha + w * 3, st.alpha);
-        if (A.out.beta) stv3(A.out.beta + w * 3, st.beta);
-        if (A.out.q) {
-            const Q4 q = rot_2_quat(st.R);
-            double *p = A.out.q + w * 4;
-            p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
-        }
-    }
-}
-
-// ============================================================================================
 // mean kernel on the TILED layout: knots of 64 windows interleaved per step (cpi_preintegrate_tiled_batch)
 // ============================================================================================
 // tiles[b][s][k][i] = field k (t, w, a) of knot s of window 64 b + i.  A wavefront owns tile b, lane i window 64 b + i, and

@@ -100,73 +100,3 @@ def test_full_outputs_short_windows_vs_reference_sample(eng, model, N, W):
     check_pre({k: v[pick].cpu().numpy() for k, v in out.items() if k != "P_sym"}, ref, v2=(model == 2), regression=from_ref,
               label="N=%d W=%d model %d full" % (N, W, model))
 
-
-# ---------------------------------------------------------------------------------------------------------------------------------
-# cpi_mean_block_kernel (round 6): N <= 11, one lane per window -- the wavefront's knots fetched ONCE as a linear LDS block.  Same
-# mean_step sequence as the one-lane instantiation of cpi_mean_kernel: BIT FOR BIT against it (a CSR `first` array is never admitted
-# to the block kernel, so the same windows through first / count run the chunked kernel).
-@pytest.mark.parametrize("model", [1, 2])
-@pytest.mark.parametrize("N", [1, 2, 7, 10, 11])
-def test_block_kernel_dense_layout_bitwise_vs_the_chunked_one_lane_kernel(eng, model, N):
-    for W in (1, 63, 64, 65, 1000, 200001):
-        kn, lin, q = synth.make_windows(W, N, seed=800 + N + W % 97, device=eng.device)
-        first = (torch.arange(W, device=eng.device, dtype=torch.int64) * (N + 1)).contiguous()
-        count = torch.full((W,), N, dtype=torch.int32, device=eng.device)
-        for avg in (False, True):
-            prm = eng.make_params(model, avg, lanes_per_window=1)
-            blk = eng.preintegrate(kn, lin, q, prm, want=("mean",))                                   # dense, one lane: the block kernel
-            csr = eng.preintegrate(kn.reshape(-1, 7), lin, q, prm, want=("mean",), first=first, count=count, N=N)
-            torch.cuda.synchronize()
-            for k in ("DT", "alpha", "beta", "q"):
-                assert torch.equal(blk[k], csr[k]), (model, N, W, avg, k)
-    # N = 12 is past the block kernel's limit: same answer from the chunked kernel either way (the launcher's boundary)
-    kn, lin, q = synth.make_windows(3000, 12, seed=5, device=eng.device)
-    a = eng.preintegrate(kn, lin, q, eng.make_params(model, lanes_per_window=1), want=("mean",))
-    b = eng.preintegrate(kn.reshape(-1, 7), lin, q, eng.make_params(model, lanes_per_window=1), want=("mean",),
-                         first=(torch.arange(3000, device=eng.device, dtype=torch.int64) * 13).contiguous(),
-                         count=torch.full((3000,), 12, dtype=torch.int32, device=eng.device), N=12)
-    torch.cuda.synchronize()
-    assert all(torch.equal(a[k], b[k]) for k in a)
-
-
-@pytest.mark.parametrize("model", [1, 2])
-def test_block_kernel_stream_cut_ragged_truncated_and_at_the_end_of_the_buffer(eng, model):
-    """The fused stream cut inside the block kernel: jittered update times (ragged windows of 6 ... 11 intervals, mostly with a tail),
-    one update exactly on a reading, a gap in the update grid that makes one window 40 intervals long (truncated to the bound, and
-    the wavefront's run no longer fits the LDS block: the direct-read path), the last window ending PAST the last stamp with NaNs right
-    behind the stream in memory -- against the same windows through the CSR layout (chunked one-lane kernel) bit for bit, the TRUE
-    counts exactly, and a strided sample against the compiled reference."""
-    from tests.test_stream import _torch_cut
-    W, N = 70000, 8
-    stream, upd, lin, q = synth.make_stream(W, N, seed=31 + model, device=eng.device, phase=0.37)
-    g = torch.Generator(device=eng.device); g.manual_seed(9)
-    upd = upd + (torch.rand(upd.shape, generator=g, dtype=torch.float64, device=eng.device) * 3.0 - 2.0) / 200.0   # -2 ... +1 samples
-    upd = torch.sort(upd).values.contiguous()
-    upd[7] = stream[7 * N + 3, 0]                                    # one update exactly ON a reading: no tail interval
-    upd[30000:] += 40 * 0.005                                        # a gap: window 30 000 holds ~48 intervals
-    upd = torch.sort(upd).values.contiguous()
-    upd[-1] = stream[-1, 0] + 0.003                                  # the last window ends past the last stamp
-    K = stream.shape[0]
-    big = torch.full((K + 64, 7), float("nan"), dtype=torch.float64, device=eng.device)
-    big[:K] = stream
-    ds = big[:K]
-    knots, first, count = _torch_cut(stream, upd)
-    cnt_np = count.cpu().numpy()
-    assert cnt_np.max() > 40 and np.median(cnt_np) <= 10 and len(np.unique(cnt_np)) >= 5
-    Nb = 11                                                          # the bound: the long window is truncated to 11 intervals
-    for avg in (False, True):
-        prm = eng.make_params(model, avg, lanes_per_window=1)
-        out, cnt = eng.preintegrate_stream(ds, upd, lin, q, prm, want=("mean",), N=Nb, return_counts=True, check_counts=False)
-        csr = eng.preintegrate(knots, lin, q, prm, want=("mean",), first=first, count=count, N=Nb)
-        torch.cuda.synchronize()
-        assert torch.equal(cnt.to(torch.int32), count), (model, avg)
-        for k in ("DT", "alpha", "beta", "q"):
-            assert bool(torch.isfinite(out[k]).all()), (model, avg, k)
-            assert torch.equal(out[k], csr[k]), (model, avg, k)
-    # sample against the compiled reference: the picked windows' knots from the CSR arrays (truncated like the kernels truncate)
-    pick = np.unique(np.concatenate([np.linspace(0, W - 1, 120).astype(np.int64), [7, 29999, 30000, 30001, W - 1]]))
-    f_np = first.cpu().numpy()
-    dense = np.stack([knots[int(f_np[u]) + np.minimum(np.arange(Nb + 1), min(int(cnt_np[u]), Nb))].cpu().numpy() for u in pick])
-    ref, from_ref = _cpu((model, 1, 1), dense, lin[pick].cpu().numpy(), q[pick].cpu().numpy())
-    check_pre({k: out[k][pick].cpu().numpy() for k in ("DT", "alpha", "beta", "q")}, {k: ref[k] for k in ("DT", "alpha", "beta", "q")},
-              what=("mean",), regression=from_ref, label="block kernel, stream cut, model %d" % model)
