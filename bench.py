@@ -20,14 +20,22 @@ each peer sends ONE packed slab straight to the root over its own xGMI link).  T
              closing barrier is outside the timed region.
   pipelined  every step's slab is gathered, on a side stream, while the next step computes (double-buffered outputs and
              receive buffers): the schedule for steps that last milliseconds (`--scaling strong`, cfg5_*).
+  chunked    the exchange INSIDE a step (round 6; `--gather-chunks k`): the batch in k sub-blocks, each computed by its own launch into a
+             slab of its own, sub-block c on the wire while c + 1 computes -- what ONE batch with "a final gather" (configs[4]) needs;
+             the torch.distributed twin of cpi_group_gather_chunk.  `--workload cfg5_full_sym` sends the covariance as its packed upper
+             triangle (1 408 instead of 2 248 bytes per window).
+`config.predicted` (N > 1) states what the exchange SHOULD cost on xGMI -- slab bytes per peer over one link at 76.8 GB/s one way -- and the
+expected wall time of the timed region under the schedule in use, from the kernel time measured in the same run.
 `kernel_ms` (HIP events around the K steps), `gather_ms` (the exposed tail after the last kernel) and the rate without any
 exchange (`value_without_gather`) are reported beside `value`.  `--workload cfg5_mean | cfg5_full` is BASELINE configs[4]:
 1 M windows x 100 samples per GPU, generated on the device.
 
 Output contract (rank 0): the LAST stdout line is ONE JSON object of < 6 KB -- the headline (metric, value, ms_per_step,
-config, `roofline`, `cpu_baseline`), `goal_40pct_hbm`, a compact `configs2` object (BASELINE configs[2]), the end-to-end route
+config, `roofline`, `cpu_baseline`), `value_full_integrator` (= configs2.value: `value` is the LIGHTEST configuration, mean-only) and
+`value_overlapped`, `goal_40pct_hbm`, a compact `configs2` object (BASELINE configs[2]), the end-to-end route
 table of a 1 M x 50 batch held as one IMU stream (`routes_1M_x_50`) and one [launch ms, roofline fraction] pair per extra row.
-The full extra rows (26 workloads incl. the SURVEY 8(f) rows, each with its own `roofline`, counters and `cpu_baseline`) are
+The full extra rows (45 workloads incl. the SURVEY 8(f) rows, the packed-triangle rows of ABI 3 and the reference's own window
+lengths -- 10 / 20 samples, keyed `...@1Mx10` --, each with its own `roofline`, counters and `cpu_baseline`) are
 written to bench_extra.json beside this file (copied to gpurun_out/ when that directory exists); tests/test_gpu_bench.py runs
 the driver's command verbatim and checks both.  N > 1 adds `config.rccl` (what the collective library saw), `value_kernel_only`
 and `gather_verified` (rank 0 recomputes every rank's last-step batch and compares the gathered blocks bitwise).
