@@ -426,6 +426,10 @@ __device__ __forceinline__ void dpp_fmac(double &acc, double b, double x) {     
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(K));
 }
 template <int K>
+__device__ __forceinline__ void dpp_fnmac(double &acc, double b, double x) {     // acc -= bcast_K(b) * x: the DPP encoding carries source modifiers
+    asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(x), "n"(K));
+}
+template <int K>
 __device__ __forceinline__ double dpp_mul(double b, double x) {   // v_mul_f64 is VOP3-only (no DPP form): a chain starts from zero
     double r = 0.0;
     dpp_fmac<K>(r, b, x);
@@ -434,17 +438,7 @@ __device__ __forceinline__ double dpp_mul(double b, double x) {   // v_mul_f64 i
 // 1 / sqrt(a) for the pivots: the Newton sequence of mag_and_inverse (cpi_math.hpp) WITHOUT its clamp, so that a non-positive or
 // NaN pivot poisons the factor by itself -- v_rsq_f64 gives NaN for a < 0 and +inf for 0, and 0 x inf = NaN carries it through the
 // iteration -- where a clamp (v_max) plus a compare and two selects per step stood.  Same bits as before for a > 1e-280.
-__device__ __forceinline__ double pivot_rsqrt(double a) {
-    const double y = __builtin_amdgcn_rsq(a);
-    double g = a * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    const double d = fma(-g, g, a);
-    g = fma(d, h, g);
-    r = fma(-h, g, 0.5);
-    h = fma(h, r, h);
-    return 2.0 * h;
-}
+__device__ __forceinline__ double pivot_rsqrt(double a) { return inv_sqrt_unclamped(a); }
 // No per-lane selects in the sweep (round 6: 763 -> see resource table; the packed form of this kernel is VALU-bound).  With
 // acc[] started at -[i == j] instead of 0, row k of column j of U is -acc[k] / b_kk for EVERY lane and row:
 //   k <  j : acc[k] = sum_m B[k][m] U[m][j], as before;
@@ -453,6 +447,12 @@ __device__ __forceinline__ double pivot_rsqrt(double a) {
 //            acc[i] += B[i][k] * (-0) leaves every running sum as it is.
 // The trailing update of the working matrix needs no "finished lane" select either: a lane j >= k is never read again (the
 // broadcasts of the remaining steps come from lanes < k), so whatever its dead registers turn into is nobody's input.
+// -1.0 in the lanes of `mask` (a wave-uniform constant: it lives in a scalar register pair), 0.0 elsewhere
+__device__ __forceinline__ double neg_delta_of_lane(unsigned long long mask) {
+    int hi;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(0xBFF00000), "s"(mask));
+    return __hiloint2double(hi, 0);
+}
 template <int K>
 __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], double (&acc)[15]) {
     if constexpr (K >= 0) {
@@ -504,10 +504,15 @@ __global__ __launch_bounds__(64 * CPI_SQRT_WPB, 3) void cpi_sqrt_info_kernel(lon
     wave_lds_fence();
     const int fc = min(fl, nf - 1), jc = min(j, 14);   // idle lanes (j == 15, missing factors) redo a valid column
     double a[15], u[15], acc[15];
+    // (the packed form is bound by its instruction count: one select per element between two addresses whose constant parts are
+    //  instruction offsets -- rows i <= j of the lane's column sit at T(j) + i, the others at T(i) + j -- and the -[i == j] start of
+    //  the running sums from a CONSTANT lane mask, lanes i, 16 + i, 32 + i, 48 + i, instead of a compare per element)
+    const double *colp = sA + fc * MD + jc * (jc + 1) / 2, *rowp = sA + fc * MD + jc;
 #pragma unroll
     for (int i = 0; i < 15; i++) {
-        a[i] = PACKED ? sA[fc * MD + ((i <= jc) ? jc * (jc + 1) / 2 + i : i * (i + 1) / 2 + jc)] : sA[fc * MD + jc * 15 + i];
-        acc[i] = (i == j) ? -1.0 : 0.0;
+        if constexpr (PACKED) a[i] = ((i <= jc) ? colp + (i - i * (i + 1) / 2) : rowp)[i * (i + 1) / 2];
+        else a[i] = sA[fc * MD + jc * 15 + i];
+        acc[i] = neg_delta_of_lane(0x0001000100010001ull << i);
     }
     chol_inv_step<14>(a, u, acc);
     wave_lds_fence();   // the column reads above are complete (in-order DS) before the staging area is reused
@@ -620,8 +625,8 @@ __device__ __forceinline__ void tab_h1t(const double (&v)[15], const BlkTab &T, 
     put3(g + 9, -h);
 }
 template <int C>
-__device__ __forceinline__ void tab_edot(double &acc, const double (&v)[15], const BlkTab &T) {   // + e . v
-    if constexpr (C < 15) { tfmac<TB_ERR + C>(acc, T, v[C]); tab_edot<C + 1>(acc, v, T); }
+__device__ __forceinline__ void tab_nedot(double &acc, const double (&v)[15], const BlkTab &T) {   // - e . v
+    if constexpr (C < 15) { dpp_fnmac<((TB_ERR + C) & 15)>(acc, T.r[(TB_ERR + C) >> 4], v[C]); tab_nedot<C + 1>(acc, v, T); }
 }
 // hsn::h2t_vec
 __device__ __forceinline__ void tab_h2t(const double (&w)[15], const BlkTab &T, double (&t)[15]) {
@@ -640,17 +645,33 @@ __device__ __forceinline__ void tab_h2t(const double (&w)[15], const BlkTab &T, 
 // only then do the Z rows take their place -- and the stage is filled and flushed two factors at a time: [records | R | tables] is
 // the largest tenant, 11.1 KB with R packed (14.5 KB dense): 12 (11) wavefronts per CU at three per SIMD.  Same arithmetic in the
 // same order as before (tests/hostsim's lane emulation and the whitened sweep still pin it).
+// Late round 6: the table's STAGE keeps only what is not in the record already -- the 54 state-dependent entries and the residual,
+// 69 doubles (pitch BLK_P) instead of 112 per factor -- which takes [records | R | tables] with R packed from 11.1 to 9.8 KB: sixteen
+// wavefronts per CU, FOUR per SIMD (the registers, 128, allowed that all along); 13.1 KB and three per SIMD with R dense.  By then the
+// kernel was bound by its INSTRUCTION COUNT (1 754 vector instructions per wavefront, the vector pipe 87 % busy by the counters),
+// so the rest of the late changes remove instructions, not bytes: the quaternion products normalise by a reciprocal square root
+// (cpi_math.hpp: CPI_QUAT_RECIP; -250), lane 15 gets w = -y out of the other lanes' row combination (below; -45 and 8 LDS reads),
+// -y and f come out of negated multiply-adds (dpp_fnmac), the triangle's rows are read unclamped, the output slots and the flush are
+// instruction offsets from pointers formed once (-40): 1 516 per wavefront, 1.30 -> 1.20 ms per 1 M factors with R packed, 1.42 ->
+// 1.27 dense (profiles/r06_small_sweeps.md section 5).
 #ifndef CPI_HESS_WPS
 #define CPI_HESS_WPS 3
 #endif
+#ifndef CPI_HESS_WPS_TRI
+#define CPI_HESS_WPS_TRI 4
+#endif
+constexpr int TBK_ERR = TB_JB, BLK_P = 70;      // where the residual sits in the stage; the stage's pitch (even: 16-byte rows)
+static_assert(TBK_ERR + (TB_END - TB_ERR) <= BLK_P, "the stage holds the state-dependent blocks and the residual");
 template <int MODEL, bool TRI = false>
-__global__ __launch_bounds__(64, CPI_HESS_WPS) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
+__global__ __launch_bounds__(64, TRI ? CPI_HESS_WPS_TRI : CPI_HESS_WPS) void cpi_factor_hessian_kernel(FactorArgs A, double *hess) {
     using namespace hsn;
     constexpr int FPW = 4, IN_D = fin::IN_D, RD = TRI ? CPI_TRI_DOUBLES : 225;
-    // [input records | R | block tables] -> ONE exchange array (Lam, then Z) -> the output stage of two factors (+ 64 trash slots)
-    constexpr int U1 = FPW * MAT_D, HEAD = FPW * IN_D + FPW * RD + FPW * TAB_D, STAGE = 2 * HESS_PACKED + 64;
+    // [input records | R | block tables] -> ONE exchange array (Lam, then Z) -> the output stage of two factors (+ 128 trash slots)
+    // the exchange array of a factor: 15 rows of Lam / Z pitched ROWP, -y in column 15 AND as a sixteenth row (see the column phase)
+    constexpr int XM = 16 * ROWP + 14;     // 302 doubles = 28 dwords mod 64 apart, as the 270 of the 15-row array were
+    constexpr int U1 = FPW * XM, HEAD = FPW * IN_D + FPW * RD + FPW * BLK_P, STAGE = 2 * HESS_PACKED + 128;
     constexpr int LDS_D = (HEAD > U1 ? HEAD : U1) > STAGE ? (HEAD > U1 ? HEAD : U1) : STAGE;
-    static_assert(TB_END <= TAB_D && MAT_D >= 15 * ROWP && ROWP >= 16, "table / exchange geometry");
+    static_assert(TB_END <= TAB_D && XM >= 16 * ROWP && ROWP >= 16 && B_RK + 9 <= TBK_ERR, "table / exchange geometry");
     __shared__ __attribute__((aligned(16))) double sAll[LDS_D];
     __shared__ double sDummy[2];
     double *sU1 = sAll;
@@ -682,7 +703,7 @@ __global__ __launch_bounds__(64, CPI_HESS_WPS) void cpi_factor_hessian_kernel(Fa
     BlkTab T;
     V3 dcol;                                                 // the lane's column of its diagonal block of H2
     {
-        double *blk = sTab + f * TAB_D;
+        double *blk = sTab + f * BLK_P;
         {
             const FactorMeas m = factor_meas_of(sU1 + f * IN_D, A.grav);
             FactorShared S;
@@ -691,7 +712,7 @@ __global__ __launch_bounds__(64, CPI_HESS_WPS) void cpi_factor_hessian_kernel(Fa
             if (q < 3) state_blocks_column<MODEL>(S, m, q, blk);
             else if (q == 4) {
 #pragma unroll
-                for (int a = 0; a < 5; a++) { blk[TB_ERR + 3 * a] = e5[a].x; blk[TB_ERR + 3 * a + 1] = e5[a].y; blk[TB_ERR + 3 * a + 2] = e5[a].z; }
+                for (int a = 0; a < 5; a++) { blk[TBK_ERR + 3 * a] = e5[a].x; blk[TBK_ERR + 3 * a + 1] = e5[a].y; blk[TBK_ERR + 3 * a + 2] = e5[a].z; }
             }
         }
         wave_lds_fence();
@@ -700,40 +721,50 @@ __global__ __launch_bounds__(64, CPI_HESS_WPS) void cpi_factor_hessian_kernel(Fa
         for (int r = 0; r < TAB_R; r++) {                              // entries past TB_END: never used
             const int i = r * 16 + q;
             const bool from_record = (r * 16 + 15 >= TB_JB) && (r * 16 < TB_ERR) && i >= TB_JB && i < TB_ERR;
-            T.r[r] = *(from_record ? rec + i : blk + i);
+            const int bi = (i < TB_JB) ? i : min(i, TB_END - 1) - (TB_ERR - TBK_ERR);      // the stage skips what the record holds
+            T.r[r] = *(from_record ? rec + i : blk + bi);
         }
-        dcol = h2_diag_col(blk, (q < 15) ? q / 3 : 0, (q < 15) ? q % 3 : 0);
+        dcol = h2_diag_col(blk, (q < 15) ? q / 3 : 1, (q < 15) ? q % 3 : 0);      // lane 15: a column of an identity block, (1, 0, 0)
     }
 
     // ---- row phase: row q of Lam and of Z, y_q -- in registers; Lam (+ y in column 15) goes to the exchange array first
-    double *xch = sAll + f * MAT_D;
-    double z[15], y;
+    double *xch = sAll + f * XM;
+    double z[15];
     {
         double l[15], own[15];
 #pragma unroll
         for (int k = 0; k < 15; k++) {
-            if constexpr (TRI) { const double v = sR[f * RD + qr * (qr + 1) / 2 + min(k, qr)]; own[k] = (k <= qr) ? v : 0.0; }
+            // (rows past the diagonal read on into the next columns of the same triangle -- T(qr) + 14 <= 119 -- and are replaced by the zeros)
+            if constexpr (TRI) { const double v = sR[f * RD + qr * (qr + 1) / 2 + k]; own[k] = (k <= qr) ? v : 0.0; }
             else own[k] = sR[f * 225 + qr * 15 + k];
         }
+        // the selects above are VALU writes and lambda_row_dpp reads own[] as DPP sources right away: all of them complete, then two
+        // wait states (the hazard recogniser does not see into the inline assembly of dpp_fmac; tests/tools/dpp_hazards.py does)
+        asm volatile("s_nop 1" : "+v"(own[0]), "+v"(own[1]), "+v"(own[2]), "+v"(own[3]), "+v"(own[4]), "+v"(own[5]), "+v"(own[6]), "+v"(own[7]),
+                     "+v"(own[8]), "+v"(own[9]), "+v"(own[10]), "+v"(own[11]), "+v"(own[12]), "+v"(own[13]), "+v"(own[14]));
         lambda_row_dpp<0>(own, l);
         tab_h1t(l, T, z);
-        y = tmul<TB_ERR>(T, l[0]);
-        tab_edot<1>(y, l, T);
+        double ny = 0.0;      // -y_q = -(Lam e)_q: the running sum takes its terms negated (source modifier of the DPP multiply-add)
+        tab_nedot<0>(ny, l, T);
         wave_lds_fence();     // every lane has read R (and its table entries) before the area becomes the exchange array
 #pragma unroll
         for (int c = 0; c < 15; c++) xch[qr * ROWP + c] = l[c];
-        xch[qr * ROWP + 15] = y;
+        // -y twice: as column 15 (what lane 15 reads as "its column of Z" in part 2 -- the Z rows leave it alone) and as row 15, which
+        // lane 15 combines in part 1 with the identity column (1, 0, 0) as its block column: w = -y by the code of the other lanes,
+        // where fifteen reads, negations and selects stood
+        xch[qr * ROWP + 15] = ny;
+        xch[15 * ROWP + qr] = ny;
     }
     wave_lds_fence();
 
     // ---- column phase, part 1 (needs Lam): the G22 / g2 run t.  hsn::lane_columns is the host twin of the whole phase.
-    const int j = (q < 15) ? q / 3 : 0;
+    // rows 3 j .. 3 j + 2 of the array for a lane q < 15; lane 15: row 15 three times (the other two meet the zeros of its dcol)
+    const double *xr0 = xch + ((q < 15) ? 3 * (q / 3) : 15) * ROWP;
+    const int xrs = (q < 15) ? ROWP : 0;
     double g[15], u[15], t[15], fq;
     {
         double w[15];
-        rows_comb(xch, j, dcol, w);
-#pragma unroll
-        for (int c = 0; c < 15; c++) w[c] = (q == 15) ? -xch[c * ROWP + 15] : w[c];      // lane 15: w = -y
+        rows_comb3(xr0, xr0 + xrs, xr0 + 2 * xrs, dcol, w);
         tab_h2t(w, T, t);
     }
     wave_lds_fence();         // Lam is consumed: the Z rows take its place (column 15 keeps y)
@@ -742,43 +773,53 @@ __global__ __launch_bounds__(64, CPI_HESS_WPS) void cpi_factor_hessian_kernel(Fa
     wave_lds_fence();
     // ---- part 2 (needs Z): the G11 / g1 / f run g, fq and the G12 run u
     {
-        const double sgn = (q == 15) ? -1.0 : 1.0;
         double zc[15];
 #pragma unroll
-        for (int k = 0; k < 15; k++) zc[k] = sgn * xch[k * ROWP + q];       // column q of Z; for q = 15: -y
+        for (int k = 0; k < 15; k++) zc[k] = xch[k * ROWP + q];             // column q of Z; for q = 15: -y
         tab_h1t(zc, T, g);
-        double acc = tmul<TB_ERR>(T, zc[0]);
-        tab_edot<1>(acc, zc, T);
-        fq = -acc;
-        rows_comb(xch, j, dcol, u);
+        fq = 0.0;
+        tab_nedot<0>(fq, zc, T);                                            // lane 15: f = -(e . -y)
+        rows_comb3(xr0, xr0 + xrs, xr0 + 2 * xrs, dcol, u);
     }
     wave_lds_fence();
 
-    // ---- out through the stage, two factors at a time: their packed triangles are one contiguous 7.9 KB run of the output
+    // ---- out through the stage, two factors at a time: their packed triangles are one contiguous 7.9 KB run of the output.
+    // (late round 6: the lane's slots are formed once, every store and every piece of the flush is an instruction offset from them --
+    //  the runs that have no place in the triangle, lane 15's u and the other lanes' f, go to trash slots of their own instead of
+    //  through a select per element; a full pair of factors is flushed by eight unrolled pieces per lane, the last one by 48 lanes)
+    {
+        double *st = sAll + (f & 1) * HESS_PACKED, *trash = sAll + 2 * HESS_PACKED;
+        double *pg = st + ((q < 15) ? pk(0, q) : pk(0, 30));
+        double *pt = st + ((q < 15) ? pk(15, 15 + q) : pk(15, 30));
+        double *pu = (q < 15) ? st + pk(0, 15 + q) : trash + (lane >> 4) * 15;
+        double *pf = (q == 15) ? st + pk(30, 30) : trash + 64 + lane;
+        const double *piece = sAll + 2 * lane;
 #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int cnt = min(2, nf - 2 * pass);               // wave-uniform
-        if (cnt <= 0) break;
-        double *trash = sAll + 2 * HESS_PACKED + lane;
-        if ((f >> 1) == pass) {
-            double *st = sAll + (f & 1) * HESS_PACKED;
-            double *pg = st + ((q < 15) ? pk(0, q) : pk(0, 30));
-            double *pt = st + ((q < 15) ? pk(15, 15 + q) : pk(15, 30));
-            double *pu = (q < 15) ? st + pk(0, 15 + q) : trash;
+        for (int pass = 0; pass < 2; pass++) {
+            const int cnt = min(2, nf - 2 * pass);               // wave-uniform
+            if (cnt <= 0) break;
+            if ((f >> 1) == pass) {
 #pragma unroll
-            for (int r = 14; r >= 0; r--) pg[r] = g[r];        // descending: the owner of an entry stores it after every trespasser
+                for (int r = 14; r >= 0; r--) pg[r] = g[r];        // descending: the owner of an entry stores it after every trespasser
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 0; r < 15; r++) pt[r] = t[r];
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 0; r < 15; r++) pu[r] = u[r];
+                *pf = fq;
+            }
             wave_lds_fence();
+            double *dst = hess + (f0 + 2 * pass) * HESS_PACKED + 2 * lane;
+            if (cnt == 2) {
 #pragma unroll
-            for (int r = 0; r < 15; r++) pt[r] = t[r];
-            wave_lds_fence();
-#pragma unroll
-            for (int r = 0; r < 15; r++) (q < 15 ? pu + r : trash)[0] = u[r];
-            *((q == 15) ? st + pk(30, 30) : trash) = fq;
+                for (int it = 0; it < 8; it++)
+                    if (it < 7 || lane < HESS_PACKED - 7 * 64) st16_nt(dst + 128 * it, piece[128 * it], piece[128 * it + 1]);
+            } else {                                             // the odd factor at the end of a launch
+                for (int idx = lane; idx < HESS_PACKED / 2; idx += 64) st16_nt(dst + 2 * (idx - lane), sAll[2 * idx], sAll[2 * idx + 1]);
+            }
+            wave_lds_fence();     // the flush has read the stage (in-order DS) before the next pair overwrites it
         }
-        wave_lds_fence();
-        for (int idx = lane; idx < cnt * (HESS_PACKED / 2); idx += 64)
-            st16_nt(hess + (f0 + 2 * pass) * HESS_PACKED + 2 * idx, sAll[2 * idx], sAll[2 * idx + 1]);
-        wave_lds_fence();     // the flush has read the stage (in-order DS) before the next pair overwrites it
     }
 }
 

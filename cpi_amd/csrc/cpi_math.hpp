@@ -253,6 +253,28 @@ CPI_HD void mag_and_inverse(double m2, double &mag, double &im) {
 #endif
 }
 
+// 1 / sqrt(a): the Newton sequence of mag_and_inverse WITHOUT its clamp -- v_rsq_f64 gives NaN for a < 0 and +inf for 0, and
+// 0 x inf = NaN carries either through the iteration, so a non-positive or NaN argument poisons whatever is scaled by the result
+// (the pivots of cpi_sqrt_info_kernel rely on that; so does the normalisation of a zero quaternion).  <= 1 ulp for a > 1e-280.
+#ifndef CPI_QUAT_RECIP
+#define CPI_QUAT_RECIP 1
+#endif
+CPI_HD double inv_sqrt_unclamped(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double d = fma(-g, g, a);
+    g = fma(d, h, g);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    return 2.0 * h;
+#else
+    return 1.0 / sqrt(a);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // quaternion helpers (quat_ops.h)
 CPI_HD Q4 rot_2_quat(const M3 &R) {  // quat_ops.h:45-86
@@ -310,12 +332,31 @@ CPI_HD Q4 quat_multiply(Q4 q, Q4 p) {  // quat_ops.h:115-128
     r.z = q.w * p.z - c.z + q.z * p.w;
     r.w = q.w * p.w - dot(qv, pv);
     if (r.w < 0) { r.x = -r.x; r.y = -r.y; r.z = -r.z; r.w = -r.w; }
-    const double n = sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+    const double n2 = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+#if defined(__HIP_DEVICE_COMPILE__) && CPI_QUAT_RECIP
+    // q / |q| as q * (1 / |q|), 1 / |q| from one v_rsq_f64 seed (<= 1 ulp; a zero product still normalises to NaN as the reference's
+    // 0 / 0 does): 15 instructions where an IEEE square root and four IEEE divisions took ~60, five times per factor -- the sweeps that
+    // are bound by their instruction count (Hessian: 1 754 -> see profiles/r06_small_sweeps.md) feel it; <= 2 ulp per component.
+    const double in = inv_sqrt_unclamped(n2);
+    r.x *= in; r.y *= in; r.z *= in; r.w *= in;
+#else
+    const double n = sqrt(n2);
     r.x /= n; r.y /= n; r.z /= n; r.w /= n;
+#endif
     return r;
 }
 CPI_HD Q4 quat_inv(Q4 q) { Q4 r; r.x = -q.x; r.y = -q.y; r.z = -q.z; r.w = q.w; return r; }
 CPI_HD M3 Exp_so3(V3 w) {  // quat_ops.h:145-162
+#if defined(__HIP_DEVICE_COMPILE__) && CPI_QUAT_RECIP
+    {
+        // |w| and 1 / |w| from one seed (mag_and_inverse: w = 0 is clamped to |w| = 1e-140, whose coefficients sin(t) / t = 1 and
+        // (1 - cos t) / t^2 = 0 give the identity as quat_ops.h:148-150 does) instead of a square root and two divisions
+        double theta, ith, s, c;
+        mag_and_inverse(dot(w, w), theta, ith);
+        sincos_fast(theta, s, c);
+        return poly_wx(w, 1.0, s * ith, ((1 - c) * ith) * ith);
+    }
+#endif
     const double theta = sqrt(dot(w, w));
     // theta == 0 returns the identity (quat_ops.h:148-150); branch-free: with w = 0 any finite coefficients give I
     const double th = (theta == 0) ? 1.0 : theta;
@@ -1335,8 +1376,7 @@ CPI_HD V3 h2_diag_col(const double *blk, int j, int n) {
 }
 // out[c] = sum_m d[m] rows[(3 j + m) * ROWP + c]: column n of (block row j of a matrix)^T D_j -- applied to Z: a column
 // of G12; applied to Lam: the vector w below
-CPI_HD void rows_comb(const double *mat, int j, V3 d, double out[15]) {
-    const double *r0 = mat + (3 * j) * ROWP, *r1 = r0 + ROWP, *r2 = r1 + ROWP;
+CPI_HD void rows_comb3(const double *r0, const double *r1, const double *r2, V3 d, double out[15]) {
 #pragma unroll
     for (int c0 = 0; c0 < 15; c0 += 5) {      // five columns at a time: 15 doubles of rows in flight, not 45
 #pragma unroll
@@ -1344,6 +1384,9 @@ CPI_HD void rows_comb(const double *mat, int j, V3 d, double out[15]) {
         CPI_PIN3(out[c0], out[c0 + 1], out[c0 + 2]);      // (without the pins: the same registers, the same 1.39 ms)
         CPI_PIN1(out[c0 + 3]); CPI_PIN1(out[c0 + 4]);
     }
+}
+CPI_HD void rows_comb(const double *mat, int j, V3 d, double out[15]) {
+    rows_comb3(mat + (3 * j) * ROWP, mat + (3 * j + 1) * ROWP, mat + (3 * j + 2) * ROWP, d, out);
 }
 // t[3 i + m] = (D_i^T w_i)[m]: from w = (D_j^T Lam_j.)[n, :] the column of G22; from w = -y the g2 part of column 30
 CPI_HD void h2t_vec(const double w[15], const double *blk, double t[15]) {
