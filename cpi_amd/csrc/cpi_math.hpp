@@ -1009,10 +1009,7 @@ CPI_HD void cov_stage_M(const CovLane<MODEL> &L, int s, const M3 &Rs, double M[9
 // puts the p lanes in one 4-lane DPP bank and the v lanes a fixed distance below (model 1: lanes 12-14 <- 6-8), the
 // kernel takes them with masked row_shr DPP moves instead of sending 3 of the 9 exchange rows through LDS (the LDS pipe,
 // shared by the 8 wavefronts of a CU, is what bounds the covariance kernels; the VALU has slack).
-#ifndef CPI_COV1_PSYM
-#define CPI_COV1_PSYM 1
-#endif
-template <int MODEL> struct CovPBySymmetry { static const bool V = (MODEL == 1) ? (CPI_COV1_PSYM != 0) : (CPI_COV2_PSYM != 0); };
+template <int MODEL> struct CovPBySymmetry { static const bool V = (MODEL == 1) || (CPI_COV2_PSYM != 0); };
 // the p lanes of a window group and the distance to their v lanes (same DPP row): model 1 lanes 12-15 <- 6-9, model 2 (lane
 // map above) lanes 28-31 <- 22-25
 template <int MODEL> struct CovPLanes { static const int FIRST = (MODEL == 1) ? 12 : 28, SHIFT = 6; };
