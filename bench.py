@@ -791,6 +791,9 @@ def respawn(gpus):
     os.execve(sys.executable, cmd, env)
 
 
+EXTRA_PRERAMP_MS = 100.0   # the extra rows: their kernels are heavier in arithmetic than the headline's, the controller takes longer to settle
+
+
 def preramp(wl, ms):
     """Untimed clock pre-ramp, separate from the W warm-up steps: an idle MI355X needs tens of milliseconds of load to reach
     its steady shader clock, so a short (K, W) would otherwise time the ramp (K = 20: 14.9 us per launch instead of 12.0)."""
@@ -988,10 +991,14 @@ def main():
             try:
                 Nx = rest[0] if rest else WORKLOADS[name]["N"]
                 w2 = Workload(eng, name, Wx, Nx, seed=4242)
+                # untimed, like the headline's: a row that starts on an idle GPU (the previous row's CPU leg) would otherwise time the power
+                # controller's transient -- the launches of `sqrt_info_packed` in one 260-launch trace: 345-363 us at the idle clock, 600 us a
+                # dozen launches later, 395-400 us from the hundredth on (profiles/r06_raw/r06_seq.txt); the steady state is the rate of a sweep
+                preramp(w2, EXTRA_PRERAMP_MS)
                 t2 = time_steps(w2, steps, max(2, steps // 10), graph=not a.eager)
                 ls = t2["kernel_ms"] * 1e-3 / steps
                 row = {"workload": name, "units_per_step": Wx, "samples": Nx, "value": Wx * steps / t2["wall"],
-                       "unit": ("factors" if w2.is_factor else "windows") + "/s", "launch_ms": ls * 1e3, "launch_mode": t2["mode"],
+                       "unit": ("factors" if w2.is_factor else "windows") + "/s", "launch_ms": ls * 1e3, "launch_mode": t2["mode"], "clock_preramp_ms": EXTRA_PRERAMP_MS,
                        "roofline": roofline_of(name, Wx, Nx, ls, pmc_rows, pmc_note)}
                 if w2.assembly:
                     asm = dict(w2.assembly)

@@ -179,6 +179,9 @@ __device__ __forceinline__ void whiten_col_dpp(const double (&Rc)[15], double (&
 #ifndef CPI_FACTOR_W3
 #define CPI_FACTOR_W3 1
 #endif
+#ifndef CPI_FACTOR_CORE_ONE_LANE
+#define CPI_FACTOR_CORE_ONE_LANE 1
+#endif
 template <int MODEL, bool WHITEN, int LPF, bool TRI = false>
 __global__ __launch_bounds__(64, (CPI_FACTOR_W3 && WHITEN && LPF == 16) ? 3 : CPI_FACTOR_WPS) void cpi_factor_kernel(FactorArgs A) {
     static_assert(WHITEN || !TRI, "TRI is a layout of the whitening matrix");
@@ -214,7 +217,32 @@ __global__ __launch_bounds__(64, (CPI_FACTOR_W3 && WHITEN && LPF == 16) ? 3 : CP
     // ---- shared algebra; the residual goes to the staging area at once.  Lane q of a factor publishes rows
     // q, q + LPF, ... of the 15-vector.
     FactorShared S;
-    {
+    if constexpr (CPI_FACTOR_CORE_ONE_LANE != 0 && WHITEN && LPF == 16) {
+        // ONE lane of a factor runs the core; the others pick its results up from LDS.  Same instructions for the wavefront (plus 13
+        // 16-byte reads), 1 / 16 of the FP64 lanes switching during a third of the kernel: these sweeps run at the clock the power
+        // controller leaves them (profiles/r06_small_sweeps.md section 6: whitened sweep with R packed 0.985 -> 0.925 ms per 1 M factors).
+        // Not for the plain sweep (eight lanes per factor, bound by its 3.7 KB of output per factor): 2-3 % slower with it.  The results overwrite the parts of the factor's own record
+        // that only the core reads in this kernel -- alpha, beta, q, lin (doubles 0-15) and q_K_lin, state_j (53-72); the bias Jacobians
+        // in between are read again by factor_H1_column -- in-order DS: the core's reads are complete before its writes land.
+        static_assert(fin::O_JB == 16 && fin::O_QK == 53 && fin::O_JQ >= 63, "the core's results overlay what only the core reads");
+        double *rec = sIn + fl * IN_D;
+        if (q == 0) {
+            V3 e5[5];
+            factor_shared_core<MODEL>(m, S, e5);
+#pragma unroll
+            for (int a = 0; a < 5; a++) put3(se + fl * 15 + 3 * a, e5[a]);
+            const Q4 qs[5] = { S.q_n, S.q_m, S.q_rminus, S.q_r, S.q_kR };
+#pragma unroll
+            for (int a = 0; a < 5; a++) {
+                double *o = rec + (a < 4 ? 4 * a : fin::O_QK);
+                o[0] = qs[a].x; o[1] = qs[a].y; o[2] = qs[a].z; o[3] = qs[a].w;
+            }
+            put3(rec + fin::O_QK + 4, S.Ra); put3(rec + fin::O_QK + 7, S.Rb);
+        }
+        wave_lds_fence();
+        S.q_n = ldq(rec); S.q_m = ldq(rec + 4); S.q_rminus = ldq(rec + 8); S.q_r = ldq(rec + 12); S.q_kR = ldq(rec + fin::O_QK);
+        S.Ra = ldv(rec + fin::O_QK + 4); S.Rb = ldv(rec + fin::O_QK + 7);
+    } else {
         V3 e5[5];
         factor_shared_core<MODEL>(m, S, e5);
 #pragma unroll
@@ -453,11 +481,25 @@ __device__ __forceinline__ double neg_delta_of_lane(unsigned long long mask) {
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(0xBFF00000), "s"(mask));
     return __hiloint2double(hi, 0);
 }
+#ifndef CPI_SQRT_PIVOT_ONE_LANE
+#define CPI_SQRT_PIVOT_ONE_LANE 1
+#endif
 template <int K>
-__device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], double (&acc)[15]) {
+__device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], double (&acc)[15], int j) {
     if constexpr (K >= 0) {
         // pivot: 1 / b_kk, b_kk = sqrt(A[k][k]); a non-positive (or NaN) pivot poisons the factor with NaNs
+#if CPI_SQRT_PIVOT_ONE_LANE
+        // Lane k alone runs the eleven-instruction Newton sequence on ITS a[k] and the result is broadcast, instead of the argument
+        // being broadcast and all sixteen lanes of the factor running it: the same instructions for the wavefront, a sixteenth of the
+        // FP64 lanes switching during 29 % of the kernel -- these kernels run at the clock the power controller leaves them
+        // (profiles/r06_small_sweeps.md section 6).
+        double mine = a[K];
+        if (j == K) mine = pivot_rsqrt(mine);
+        asm volatile("s_nop 1" : "+v"(mine));    // a VALU result read as a DPP source: two wait states
+        const double inv = row_share<K>(mine);
+#else
         const double inv = pivot_rsqrt(row_share<K>(a[K]));
+#endif
         u[K] = -acc[K] * inv;                    // row k of column j of U
         // trailing update of column j (all rows < k) with B[j][k] = A[k][j] / b_kk (symmetry: a static register of lane j).
         // B[i][k] = A[i][k] / b_kk sits in lane k: both updates take it as the broadcast operand of a DPP multiply-add, the
@@ -472,7 +514,7 @@ __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], 
         }
         asm volatile("s_nop 1");
         __builtin_amdgcn_sched_barrier(0);   // keep the steps in order: hoisted broadcasts would cost ~200 registers
-        chol_inv_step<K - 1>(a, u, acc);
+        chol_inv_step<K - 1>(a, u, acc, j);
     }
 }
 // PACKED (cpi_sqrt_information_packed_batch): P arrives as its upper triangle and R leaves as its non-zero triangle, 120 doubles
@@ -514,7 +556,7 @@ __global__ __launch_bounds__(64 * CPI_SQRT_WPB, 3) void cpi_sqrt_info_kernel(lon
         else a[i] = sA[fc * MD + jc * 15 + i];
         acc[i] = neg_delta_of_lane(0x0001000100010001ull << i);
     }
-    chol_inv_step<14>(a, u, acc);
+    chol_inv_step<14>(a, u, acc, j);
     wave_lds_fence();   // the column reads above are complete (in-order DS) before the staging area is reused
     if (j < 15 && fl < nf) {
         if constexpr (PACKED) {
@@ -660,6 +702,9 @@ __device__ __forceinline__ void tab_h2t(const double (&w)[15], const BlkTab &T, 
 #ifndef CPI_HESS_WPS_TRI
 #define CPI_HESS_WPS_TRI 4
 #endif
+#ifndef CPI_HESS_CORE_LANES
+#define CPI_HESS_CORE_LANES 5
+#endif
 constexpr int TBK_ERR = TB_JB, BLK_P = 70;      // where the residual sits in the stage; the stage's pitch (even: 16-byte rows)
 static_assert(TBK_ERR + (TB_END - TB_ERR) <= BLK_P, "the stage holds the state-dependent blocks and the residual");
 template <int MODEL, bool TRI = false>
@@ -704,7 +749,9 @@ __global__ __launch_bounds__(64, TRI ? CPI_HESS_WPS_TRI : CPI_HESS_WPS) void cpi
     V3 dcol;                                                 // the lane's column of its diagonal block of H2
     {
         double *blk = sTab + f * BLK_P;
-        {
+        if (q < CPI_HESS_CORE_LANES) {
+            // (only lanes 0-2 and 4 of a factor use what the core computes: the others sit it out -- the same instructions for the
+            //  wavefront, a quarter of the FP64 lanes switching during a third of the kernel; CPI_HESS_CORE_LANES = 16: everybody)
             const FactorMeas m = factor_meas_of(sU1 + f * IN_D, A.grav);
             FactorShared S;
             V3 e5[5];

@@ -347,22 +347,21 @@ CPI_HD Q4 quat_multiply(Q4 q, Q4 p) {  // quat_ops.h:115-128
 }
 CPI_HD Q4 quat_inv(Q4 q) { Q4 r; r.x = -q.x; r.y = -q.y; r.z = -q.z; r.w = q.w; return r; }
 CPI_HD M3 Exp_so3(V3 w) {  // quat_ops.h:145-162
+    double s, c;
 #if defined(__HIP_DEVICE_COMPILE__) && CPI_QUAT_RECIP
-    {
-        // |w| and 1 / |w| from one seed (mag_and_inverse: w = 0 is clamped to |w| = 1e-140, whose coefficients sin(t) / t = 1 and
-        // (1 - cos t) / t^2 = 0 give the identity as quat_ops.h:148-150 does) instead of a square root and two divisions
-        double theta, ith, s, c;
-        mag_and_inverse(dot(w, w), theta, ith);
-        sincos_fast(theta, s, c);
-        return poly_wx(w, 1.0, s * ith, ((1 - c) * ith) * ith);
-    }
-#endif
+    // |w| and 1 / |w| from one seed (mag_and_inverse: w = 0 is clamped to |w| = 1e-140, whose coefficients sin(t) / t = 1 and
+    // (1 - cos t) / t^2 = 0 give the identity as quat_ops.h:148-150 does) instead of a square root and two divisions
+    double theta, ith;
+    mag_and_inverse(dot(w, w), theta, ith);
+    sincos_fast(theta, s, c);
+    return poly_wx(w, 1.0, s * ith, ((1 - c) * ith) * ith);
+#else
     const double theta = sqrt(dot(w, w));
     // theta == 0 returns the identity (quat_ops.h:148-150); branch-free: with w = 0 any finite coefficients give I
     const double th = (theta == 0) ? 1.0 : theta;
-    double s, c;
     sincos_fast(theta, s, c);
     return poly_wx(w, 1.0, s / th, (1 - c) / (th * th));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
