@@ -880,7 +880,7 @@ def main():
     wl = Workload(eng, a.workload, W, N, seed=base_seed(rank), lanes=a.lanes, min_out_sets=2 if (do_gather and schedule in ("pipelined", "chunked")) else 1)
     if schedule == "chunked":
         wl.make_chunks(max(1, a.gather_chunks))
-    PRERAMP_MS = 60.0
+    PRERAMP_MS = float(os.environ.get("CPI_BENCH_PRERAMP_MS", "60"))     # (the override is for A/B runs of the pre-ramp itself)
     preramp(wl, PRERAMP_MS)
     wl.i = 0     # the pre-ramp runs for a TIME, i.e. a rank-dependent number of steps: every rank walks the batch pool from the same index
     tm = time_steps(wl, a.steps, a.warmup, dist_on, a.gather, schedule, graph=not a.eager)
