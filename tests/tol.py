@@ -15,7 +15,8 @@ TOL_FACTOR = 1e-9    # evaluateError residual and H1/H2 : max-abs
 REG_MEAN = 2e-13
 REG_COV = 2e-13
 REG_JAC = 3e-11
-REG_FACTOR = 1e-12   # evaluateError on the golden cases vs the restatement (measured floor 2e-14 on O(10) entries)
+REG_FACTOR = 1e-12   # evaluateError on the golden cases vs the restatement (measured floor 2e-14 on O(10) entries in round 2; 2.7e-15 on the
+                     # 256 golden cases with round 6's reciprocal quaternion normalisation: tests/tools/measure_factor_floor.py)
 # SURVEY 8(f) rows (round 3; floors measured on MI355X with tests/tools/measure_floors.py, gates = ~100 x):
 #   f4 Forster comparator, HIP (sparse, permuted, one exchange) vs the dense restatement oracle/forster_oracle.c on the
 #      golden + seeded inputs: means <= 8.9e-15, bias Jacobians <= 2.9e-15, covariance <= 9.7e-15 relative
