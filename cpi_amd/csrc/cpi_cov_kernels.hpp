@@ -14,6 +14,9 @@ namespace {
 #ifndef CPI_COV_WPS
 #define CPI_COV_WPS 2
 #endif
+#ifndef CPI_FORSTER_MEAN_LANES
+#define CPI_FORSTER_MEAN_LANES 6
+#endif
 template <int MODEL, bool AVG>
 __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
     typedef CovDims<MODEL> D;
@@ -254,8 +257,10 @@ __global__ __launch_bounds__(64, CPI_COV_WPS) void cpi_cov_kernel(PreArgs A) {
 // (GraphSolver_IMU.cpp:149-199) and its call-site conversions (:204-225, swapcovariance :240-254).
 // 16 lanes per window, 4 windows per wavefront.  Lane j < 15 owns column j of the 15x15 covariance (already in the
 // block order [theta b_g v b_a p] the call site swaps it into); lanes 0-2 also carry column j of the three gyro-bias
-// Jacobians, lanes 3-5 column j-3 of the two accelerometer-bias Jacobians; every lane carries the means (the SIMD
-// cost is the same as one lane doing it).  P' = F P F^T + G per interval: F x is lane-local (F is sparse), the
+// Jacobians, lanes 3-5 column j-3 of the two accelerometer-bias Jacobians; those six lanes carry the means (until late in
+// round 6 every lane did -- "the SIMD cost is the same as one lane doing it": the instruction count is, the power is not, and
+// this is the most FP64-dense kernel of the library: 0.777 -> 0.725 ms per 100 k x 50 with ten lanes of sixteen sitting the mean
+// and Jacobian steps out; CPI_FORSTER_MEAN_LANES).  P' = F P F^T + G per interval: F x is lane-local (F is sparse), the
 // transposed product arrives through ONE 9-row LDS exchange per interval (the continuous models need four, one per
 // RK4 stage).  F depends on the interval alone, so phase A (one lane per interval: Exp, its right Jacobian) needs no
 // prefix scan.
@@ -348,8 +353,10 @@ __global__ __launch_bounds__(64, 2) void cpi_forster_kernel(PreArgs A) {
         for (int sl = 0; sl < cnt; ++sl) {
             const double *ir = irs + (g * CH + sl) * IRD;   // group-uniform address: LDS broadcast
             const fsd::Rec r = fsd::get_rec(ir);
-            fsd::jac_step(J, m.R, r, ek, eg);               // uses the rotation BEFORE this interval
-            fsd::mean_step(m, r);
+            if (j < CPI_FORSTER_MEAN_LANES) {               // lanes 0-5 carry the Jacobian columns (and lane 0 stores the means): the
+                fsd::jac_step(J, m.R, r, ek, eg);           // others sit these ~80 FP64 instructions out -- same instruction stream for the
+                fsd::mean_step(m, r);                       // wavefront, 6 / 16 of the lanes switching (profiles/r06_small_sweeps.md section 6)
+            }                                               // (jac_step uses the rotation BEFORE this interval)
             double y[15];
             fsd::F_apply(r, x, y);
             if (j < 15) {
