@@ -88,8 +88,10 @@ def test_the_full_extra_rows_land_in_bench_extra_json(driver_run):
         rf = x["roofline"]
         assert rf["achieved"] > 0 and rf["kernel"] and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert doc["headline"]["value"] == r["value"] and doc["headline"]["config"]["library_build"] == r["config"]["library_build"]
-    # the compact per-row summary of the line agrees with the file
+    # every measured row is pre-ramped like the headline (late round 6: a row that starts on an idle GPU timed the power controller's transient)
     import bench
+    assert all(x.get("clock_preramp_ms") == bench.EXTRA_PRERAMP_MS for x in with_roof) and r["config"]["clock_preramp_ms"] > 0
+    # the compact per-row summary of the line agrees with the file
     key = bench.row_key
     assert set(r["extra_rows"]) == {key(x) for x in rows}
     by = {key(x): x for x in rows}
