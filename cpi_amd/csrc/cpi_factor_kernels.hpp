@@ -484,7 +484,10 @@ __device__ __forceinline__ double neg_delta_of_lane(unsigned long long mask) {
 #ifndef CPI_SQRT_PIVOT_ONE_LANE
 #define CPI_SQRT_PIVOT_ONE_LANE 1
 #endif
-template <int K>
+#ifndef CPI_SQRT_SPLIT_MASK
+#define CPI_SQRT_SPLIT_MASK 1     // packed form only (the dense form is bound by its 7.2 KB per factor: 1 % slower with it)
+#endif
+template <int K, bool SPLIT>
 __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], double (&acc)[15], int j) {
     if constexpr (K >= 0) {
         // pivot: 1 / b_kk, b_kk = sqrt(A[k][k]); a non-positive (or NaN) pivot poisons the factor with NaNs
@@ -507,14 +510,30 @@ __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], 
         // multiply-adds stood).  Rows descend so that the pivot of the next step (a[K-1]) is the OLDEST write of this loop,
         // and the s_nop covers K = 1 -- inline assembly is invisible to the compiler's DPP hazard check in both directions.
         const double ca = -inv * (a[K] * inv), cu = inv * u[K];
+        if constexpr (SPLIT) {
+        // At step k a lane needs EITHER update: its running sums change only if its u[k] is non-zero (j >= k), its column of the working
+        // matrix is read again only if it is still to be pivoted (j < k).  Two exec-masked loops -- lane k stays active in both: it is
+        // the DPP source -- halve the FP64 lane activity of these 2 k instructions (the sums first: they read lane k's column before
+        // lane k's own, dead, update overwrites it).
+        if (j >= K) {
+#pragma unroll
+            for (int i = K - 1; i >= 0; i--) dpp_fmac<K>(acc[i], a[i], cu);
+        }
+        if (j <= K) {
+#pragma unroll
+            for (int i = K - 1; i >= 0; i--) dpp_fmac<K>(a[i], a[i], ca);
+        }
+        // (steady state of 300-launch runs: packed 0.355 -> 0.336 ms per 1 M factors = 0.71 of 8 TB/s, past the plain copy of its mix)
+        } else {
 #pragma unroll
         for (int i = K - 1; i >= 0; i--) {
             dpp_fmac<K>(acc[i], a[i], cu);
             dpp_fmac<K>(a[i], a[i], ca);
         }
+        }
         asm volatile("s_nop 1");
         __builtin_amdgcn_sched_barrier(0);   // keep the steps in order: hoisted broadcasts would cost ~200 registers
-        chol_inv_step<K - 1>(a, u, acc, j);
+        chol_inv_step<K - 1, SPLIT>(a, u, acc, j);
     }
 }
 // PACKED (cpi_sqrt_information_packed_batch): P arrives as its upper triangle and R leaves as its non-zero triangle, 120 doubles
@@ -556,7 +575,7 @@ __global__ __launch_bounds__(64 * CPI_SQRT_WPB, 3) void cpi_sqrt_info_kernel(lon
         else a[i] = sA[fc * MD + jc * 15 + i];
         acc[i] = neg_delta_of_lane(0x0001000100010001ull << i);
     }
-    chol_inv_step<14>(a, u, acc, j);
+    chol_inv_step<14, PACKED && (CPI_SQRT_SPLIT_MASK != 0)>(a, u, acc, j);
     wave_lds_fence();   // the column reads above are complete (in-order DS) before the staging area is reused
     if (j < 15 && fl < nf) {
         if constexpr (PACKED) {
