@@ -511,25 +511,25 @@ __device__ __forceinline__ void chol_inv_step(double (&a)[15], double (&u)[15], 
         // and the s_nop covers K = 1 -- inline assembly is invisible to the compiler's DPP hazard check in both directions.
         const double ca = -inv * (a[K] * inv), cu = inv * u[K];
         if constexpr (SPLIT) {
-        // At step k a lane needs EITHER update: its running sums change only if its u[k] is non-zero (j >= k), its column of the working
-        // matrix is read again only if it is still to be pivoted (j < k).  Two exec-masked loops -- lane k stays active in both: it is
-        // the DPP source -- halve the FP64 lane activity of these 2 k instructions (the sums first: they read lane k's column before
-        // lane k's own, dead, update overwrites it).
-        if (j >= K) {
+            // At step k a lane needs EITHER update: its running sums change only if its u[k] is non-zero (j >= k), its column of the
+            // working matrix is read again only if it is still to be pivoted (j < k).  Two exec-masked loops -- lane k stays active in
+            // both: it is the DPP source -- halve the FP64 lane activity of these 2 k instructions (the sums first: they read lane k's
+            // column before lane k's own, dead, update overwrites it).  Steady state of 300-launch runs: packed 0.355 -> 0.336 ms per
+            // 1 M factors = 0.71 of 8 TB/s, past the plain copy of its mix.
+            if (j >= K) {
 #pragma unroll
-            for (int i = K - 1; i >= 0; i--) dpp_fmac<K>(acc[i], a[i], cu);
-        }
-        if (j <= K) {
+                for (int i = K - 1; i >= 0; i--) dpp_fmac<K>(acc[i], a[i], cu);
+            }
+            if (j <= K) {
 #pragma unroll
-            for (int i = K - 1; i >= 0; i--) dpp_fmac<K>(a[i], a[i], ca);
-        }
-        // (steady state of 300-launch runs: packed 0.355 -> 0.336 ms per 1 M factors = 0.71 of 8 TB/s, past the plain copy of its mix)
+                for (int i = K - 1; i >= 0; i--) dpp_fmac<K>(a[i], a[i], ca);
+            }
         } else {
 #pragma unroll
-        for (int i = K - 1; i >= 0; i--) {
-            dpp_fmac<K>(acc[i], a[i], cu);
-            dpp_fmac<K>(a[i], a[i], ca);
-        }
+            for (int i = K - 1; i >= 0; i--) {
+                dpp_fmac<K>(acc[i], a[i], cu);
+                dpp_fmac<K>(a[i], a[i], ca);
+            }
         }
         asm volatile("s_nop 1");
         __builtin_amdgcn_sched_barrier(0);   // keep the steps in order: hoisted broadcasts would cost ~200 registers
@@ -702,7 +702,7 @@ __device__ __forceinline__ void tab_h2t(const double (&w)[15], const BlkTab &T, 
 // fetch; the lane's column of R is completed with the zeros the dense form stores below the diagonal -- same registers, same bits.
 // Round 6: LDS is what capped this kernel's occupancy once the pinned core (cpi_math.hpp: CPI_CORE_PIN) had taken its registers from
 // 190 / 238 to 128: the two exchange arrays (Lam, Z: 2 x 8.6 KB) and the four-factor output stage (16.4 KB) allowed 9 wavefronts per CU.
-// They now TIME-SHARE one array -- Lam rows (with y in their spare 16th column) are written, combined into the G22 / g2 runs (t), and
+// They now TIME-SHARE one array -- Lam rows (with -y in their spare 16th column) are written, combined into the G22 / g2 runs (t), and
 // only then do the Z rows take their place -- and the stage is filled and flushed two factors at a time: [records | R | tables] is
 // the largest tenant, 11.1 KB with R packed (14.5 KB dense): 12 (11) wavefronts per CU at three per SIMD.  Same arithmetic in the
 // same order as before (tests/hostsim's lane emulation and the whitened sweep still pin it).
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(64, TRI ? CPI_HESS_WPS_TRI : CPI_HESS_WPS) void cpi
         rows_comb3(xr0, xr0 + xrs, xr0 + 2 * xrs, dcol, w);
         tab_h2t(w, T, t);
     }
-    wave_lds_fence();         // Lam is consumed: the Z rows take its place (column 15 keeps y)
+    wave_lds_fence();         // Lam is consumed: the Z rows take its place (column 15 keeps -y)
 #pragma unroll
     for (int c = 0; c < 15; c++) xch[qr * ROWP + c] = z[c];
     wave_lds_fence();
